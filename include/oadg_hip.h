@@ -1,0 +1,94 @@
+/*
+ * oadg_hip.h - C ABI of liboadg_hip.so: the MI355X (gfx950) kernels behind OA-DG's training hot path.
+ *
+ * The reference (WoojuLee24/OA-DG, an mmdetection 2.20 fork) has no FFI of its own: its native
+ * arithmetic is reached through Python modules resolved by registry name.  Each entry
+ * point below names the reference interface it stands in for; the Python modules of `oa-dg_amd/`
+ * registered under the reference's names are the callers (INTEGRATION.md shows the ctypes binding).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`; the caller owns all memory
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work: no allocation, no
+ *     synchronisation, no global mutable state (re-entrant across streams with distinct workspaces)
+ *   - return value: 0 = ok, < 0 = argument error (OADG_EARG -1, OADG_ESIZE -2), > 0 = hipError_t
+ *   - tensors are dense row-major in the stated shape; images/feature maps are NHWC
+ */
+#ifndef OADG_HIP_H
+#define OADG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * OA-Loss: instance-level supervised contrastive loss
+ *   replaces ContrastiveLossPlus.forward   mmdet/models/losses/oadg/contrastive_loss_plus.py:31-50
+ *            supcontrast / supcontrast_mask mmdet/models/losses/oadg/contrastive_loss.py:147-232
+ * feats [B, D] fp32 raw contrastive features (D in {64,128,256}); labels [n_labels] int64, rows
+ * n_labels..B-1 (random proposals) take labels[n_labels-1]; ori_size = rows per view of the sampled
+ * block (reference: 512*num_views), rp_size = random-proposal rows per view.  out_loss[0] =
+ * loss_weight * loss (0 when #foreground rows <= min_samples).  The workspace written by _fwd must be
+ * passed unchanged to _bwd; grad_out is a 1-float device scalar (NULL = 1.0).
+ */
+size_t oadg_supcon_workspace_bytes(int B, int D);
+int oadg_supcon_fwd(const float* feats, const int64_t* labels, int B, int D, int n_labels, int ori_size,
+                    int rp_size, float temper, int min_samples, float loss_weight, void* workspace,
+                    size_t workspace_bytes, float* out_loss, void* stream);
+int oadg_supcon_bwd(const int64_t* labels, int B, int D, int n_labels, int ori_size, int rp_size,
+                    float temper, float loss_weight, const float* grad_out, void* workspace,
+                    size_t workspace_bytes, float* dfeats, void* stream);
+int oadg_supcon_status(const void* workspace_host_copy);
+
+/* ------------------------------------------------------------------------------------------------
+ * OA-Loss: view-1 cross-entropy + two-view Jensen-Shannon consistency
+ *   replaces CrossEntropyLossPlus.forward  mmdet/models/losses/oadg/cross_entropy_loss_plus.py:418-500
+ *            cross_entropy :11-58, binary_cross_entropy :82-130, jsdv1_3_2aug :264-319
+ * logits [R, C] fp32, rows [0,R/2) = view 1, [R/2,R) = view 2; labels [R] int64 (only the first R/2 are
+ * read); weights [R] fp32 or NULL.  mode 0: sigmoid rows (C == 1, target = (label == 0), RPN);
+ * mode 1: softmax rows (RoI head).  out3 = {total, ce_part, jsd_part}.
+ */
+size_t oadg_cls_loss_workspace_bytes(void);
+int oadg_ce_jsd_fwd(const float* logits, const int64_t* labels, const float* weights, long R, int C,
+                    int mode, float avg_factor, float loss_weight, float lambda_jsd, void* workspace,
+                    size_t workspace_bytes, float* out3, void* stream);
+int oadg_ce_jsd_bwd(const float* logits, const int64_t* labels, const float* weights, long R, int C,
+                    int mode, float avg_factor, float loss_weight, float lambda_jsd, const float* grad_out,
+                    float* dlogits, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RoIAlign over an FPN pyramid (aligned / avg / adaptive grid), level assignment included
+ *   replaces mmcv.ops.RoIAlign fwd+bwd as built at
+ *              mmdet/models/roi_heads/roi_extractors/base_roi_extractor.py:54-59
+ *            SingleRoIExtractor.map_roi_levels + per-level loop
+ *              mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:36-55,89-146
+ * feats_host[l] -> [N, H_l, W_l, C] (dtype 0 fp32 / 1 bf16); rois [K,5] fp32 (batch,x1,y1,x2,y2);
+ * out [K, PH, PW, C] same dtype.  levels == 1 is the plain single-map RoIAlign.  _bwd accumulates
+ * (atomically) into caller-zeroed fp32 maps dfeats_host[l].
+ */
+int oadg_roi_align_fwd(const void* const* feats_host, const int* heights_host, const int* widths_host,
+                       const float* scales_host, int levels, int N, int C, int dtype, float finest_scale,
+                       const float* rois, int K, int PH, int PW, int sampling_ratio, int aligned,
+                       void* out, void* stream);
+int oadg_roi_align_bwd(float* const* dfeats_host, const int* heights_host, const int* widths_host,
+                       const float* scales_host, int levels, int N, int C, int dtype, float finest_scale,
+                       const float* rois, int K, int PH, int PW, int sampling_ratio, int aligned,
+                       const void* grad_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Greedy NMS, batched over images
+ *   replaces mmcv.ops.batched_nms -> nms as called at mmdet/models/dense_heads/rpn_head.py:231
+ * boxes [n_images, Mmax, 4] fp32 sorted by descending score per image, class offsets already added;
+ * counts [n_images] int32 valid boxes; keep [n_images, Mmax] int32; keep_cnt [n_images] int32.
+ */
+size_t oadg_nms_workspace_bytes(int n_images, int Mmax);
+int oadg_nms_batched(const float* boxes, const int* counts, int n_images, int Mmax, float iou_thr,
+                     int max_keep, void* workspace, size_t workspace_bytes, int* keep, int* keep_cnt,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OADG_HIP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of liboadg_hip.so (C ABI: include/oadg_hip.h).
+
+Nothing here computes: it validates tensors, hands device pointers and the current HIP stream to the
+library and raises on any non-zero return code.  A missing library is a hard error at first use.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, c_char_p, c_float, c_int, c_int64, c_long, c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'liboadg_hip.so')
+_lib = None
+
+vp, ci, cf, cl, cs = c_void_p, c_int, c_float, c_long, c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/oadg_hip.h declares
+SIGNATURES = {
+    'oadg_supcon_workspace_bytes': (cs, [ci, ci]),
+    'oadg_supcon_fwd': (ci, [vp, vp, ci, ci, ci, ci, ci, cf, ci, cf, vp, cs, vp, vp]),
+    'oadg_supcon_bwd': (ci, [vp, ci, ci, ci, ci, ci, cf, cf, vp, vp, cs, vp, vp]),
+    'oadg_supcon_status': (ci, [vp]),
+    'oadg_cls_loss_workspace_bytes': (cs, []),
+    'oadg_ce_jsd_fwd': (ci, [vp, vp, vp, cl, ci, ci, cf, cf, cf, vp, cs, vp, vp]),
+    'oadg_ce_jsd_bwd': (ci, [vp, vp, vp, cl, ci, ci, cf, cf, cf, vp, vp, vp]),
+    'oadg_roi_align_fwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
+                                vp, ci, ci, ci, ci, ci, vp, vp]),
+    'oadg_roi_align_bwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
+                                vp, ci, ci, ci, ci, ci, vp, vp]),
+    'oadg_nms_workspace_bytes': (cs, [ci, ci]),
+    'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise loudly if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C oa-dg_amd/csrc`). There is no CPU fallback for the OA-DG hot ops.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = 'argument error' if rc < 0 else 'hipError_t'
+        raise RuntimeError(f'{what} failed: {kind} {rc}')
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('OA-DG hot ops run on the MI355X only (got a CPU tensor); '
+                               'there is no CPU fallback')

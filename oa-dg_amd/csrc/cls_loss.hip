@@ -1,0 +1,266 @@
+// OA-Loss classification consistency: view-1 cross-entropy + two-view Jensen-Shannon divergence,
+// fused forward and fused backward, for gfx950.
+//
+// Replaces, behind the C ABI in include/oadg_hip.h:
+//   mmdet/models/losses/oadg/cross_entropy_loss_plus.py:11-58     cross_entropy        (RoI head)
+//   mmdet/models/losses/oadg/cross_entropy_loss_plus.py:82-130    binary_cross_entropy (RPN)
+//   mmdet/models/losses/oadg/cross_entropy_loss_plus.py:264-319   jsdv1_3_2aug
+//   mmdet/models/losses/oadg/cross_entropy_loss_plus.py:418-500   CrossEntropyLossPlus.forward
+//
+// Rows [0, R/2) are view 1 (the clean image), rows [R/2, R) view 2 (OA-Mix); row r pairs with r + R/2.
+//   loss = loss_weight * sum_{r<R/2} w_r CE(x_r, y_r) / avg_factor
+//        + lambda      * sum_{r<R/2} JSD(p(x_r), p(x_{r+R/2})) / avg_factor
+// JSD = 1/2 sum_c [ p1 (ln p1 - ln M) + p2 (ln p2 - ln M) ],  M = clamp((p1+p2)/2, 1e-7, 1)
+// with p = [sigmoid(x), 1 - sigmoid(x)] for the 1-logit RPN rows and softmax(x) for RoI rows.
+// (jsdv1_3_2aug's "/ len(p_aug1)" divides by 1 - the tensor was reshaped to (1, R/2, C) - :299-310.)
+// A probability that is exactly 0 contributes 0 to value and gradient (xlogy convention; the
+// reference's autograd yields NaN there, which we do not reproduce).
+//
+// HBM-bound streaming kernels: one pass to reduce (per-block fp64 partials, fixed order => run-to-run
+// deterministic), one pass to write d(logits).  Algorithmic traffic RPN: 2 x (4 B logit) + 8 B label +
+// 4 B weight per pair forward, + 8 B of gradient backward.
+#include "common.h"
+
+namespace {
+
+constexpr int IGNORE_INDEX = -100;
+constexpr int MAXBLOCKS = 2048;
+
+__device__ __forceinline__ float xlogy_term(float t, float logm) {
+    // F.kl_div(logM, t) = t * (ln t - logM), 0 at t == 0
+    return t > 0.f ? t * (logf(t) - logm) : 0.f;
+}
+// d/dt of 1/2 [t1(ln t1 - ln M) + t2(ln t2 - ln M)] w.r.t. t1, M = clamp((t1+t2)/2, 1e-7, 1)
+__device__ __forceinline__ float jsd_dterm(float t1, float t2, float mraw, float m, float logm) {
+    if (!(t1 > 0.f)) return 0.f;
+    float g = 0.5f * (logf(t1) + 1.0f - logm);
+    if (mraw >= 1e-7f && mraw <= 1.0f) g -= 0.5f * (t1 + t2) * 0.5f / m;
+    return g;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float bce_logits(float x, float t) {
+    // torch binary_cross_entropy_with_logits: (1-t) x + max(-x,0) + log(exp(-max) + exp(-x-max))
+    const float mx = fmaxf(-x, 0.f);
+    return (1.0f - t) * x + mx + logf(expf(-mx) + expf(-x - mx));
+}
+
+// ---------------------------------------------------------------- sigmoid (RPN) rows
+template <bool BWD>
+__global__ void sig_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                           const float* __restrict__ weights, long half, float k_ce, float k_jsd,
+                           const float* __restrict__ gout, double* __restrict__ part,
+                           float* __restrict__ dx) {
+    __shared__ double red[16];
+    double ce = 0.0, js = 0.0;
+    const float g0 = BWD ? (gout ? gout[0] : 1.0f) : 0.f;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < half; r += (long)gridDim.x * blockDim.x) {
+        const float x1 = x[r], x2 = x[r + half];
+        const int64_t lab = labels[r];
+        const bool valid = lab >= 0 && lab != IGNORE_INDEX;
+        const float t = (valid && lab == 0) ? 1.0f : 0.0f;  // _expand_onehot_labels, 1 channel
+        const float w = weights ? (valid ? weights[r] : 0.f) : (valid ? 1.f : 0.f);
+        const float p1 = sigmoidf_(x1), q1 = 1.0f - p1;
+        const float p2 = sigmoidf_(x2), q2 = 1.0f - p2;
+        const float mpr = (p1 + p2) / 2.0f, mqr = (q1 + q2) / 2.0f;
+        const float mp = fminf(fmaxf(mpr, 1e-7f), 1.0f), mq = fminf(fmaxf(mqr, 1e-7f), 1.0f);
+        const float lmp = logf(mp), lmq = logf(mq);
+        if (!BWD) {
+            ce += (double)(w * bce_logits(x1, t));
+            const float kl1 = xlogy_term(p1, lmp) + xlogy_term(q1, lmq);
+            const float kl2 = xlogy_term(p2, lmp) + xlogy_term(q2, lmq);
+            js += (double)((kl1 + kl2) / 2.0f);
+        } else {
+            const float d1 = jsd_dterm(p1, p2, mpr, mp, lmp) - jsd_dterm(q1, q2, mqr, mq, lmq);
+            const float d2 = jsd_dterm(p2, p1, mpr, mp, lmp) - jsd_dterm(q2, q1, mqr, mq, lmq);
+            const float g1 = k_ce * w * (p1 - t) + k_jsd * p1 * (1.0f - p1) * d1;
+            const float g2 = k_jsd * p2 * (1.0f - p2) * d2;
+            dx[r] = g0 * g1;
+            dx[r + half] = g0 * g2;
+        }
+    }
+    if (!BWD) {
+        const double a = block_sum_d(ce, red);
+        const double b = block_sum_d(js, red);
+        if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+    }
+}
+
+// ---------------------------------------------------------------- softmax (RoI) rows, one wave per pair
+constexpr int MAXC_PER_LANE = 4;  // C <= 256
+
+template <bool BWD>
+__global__ void sm_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                          const float* __restrict__ weights, long half, int C, float k_ce, float k_jsd,
+                          const float* __restrict__ gout, double* __restrict__ part,
+                          float* __restrict__ dx) {
+    __shared__ double red[16];
+    const int lane = threadIdx.x & 63;
+    const long wid = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * (blockDim.x >> 6);
+    const float g0 = BWD ? (gout ? gout[0] : 1.0f) : 0.f;
+    double ce = 0.0, js = 0.0;
+    for (long r = wid; r < half; r += nw) {
+        const float* r1 = x + r * C;
+        const float* r2 = x + (r + half) * C;
+        float a1[MAXC_PER_LANE], a2[MAXC_PER_LANE];
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            a1[k] = c < C ? r1[c] : -INFINITY;
+            a2[k] = c < C ? r2[c] : -INFINITY;
+            m1 = fmaxf(m1, a1[k]);
+            m2 = fmaxf(m2, a2[k]);
+        }
+        m1 = wave_max(m1);
+        m2 = wave_max(m2);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            a1[k] = c < C ? expf(a1[k] - m1) : 0.f;
+            a2[k] = c < C ? expf(a2[k] - m2) : 0.f;
+            s1 += a1[k];
+            s2 += a2[k];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        const int64_t lab = labels[r];
+        const bool valid = lab != IGNORE_INDEX && lab >= 0 && lab < C;
+        const float w = valid ? (weights ? weights[r] : 1.f) : 0.f;
+        float jrow = 0.f, dot1 = 0.f, dot2 = 0.f, plab = 0.f;
+        float gd1[MAXC_PER_LANE], gd2[MAXC_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            gd1[k] = gd2[k] = 0.f;
+            if (c < C) {
+                const float p1 = a1[k] / s1, p2 = a2[k] / s2;
+                a1[k] = p1;
+                a2[k] = p2;
+                const float mr = (p1 + p2) / 2.0f;
+                const float m = fminf(fmaxf(mr, 1e-7f), 1.0f);
+                const float lm = logf(m);
+                if (c == (int)lab) plab = p1;
+                if (!BWD) {
+                    jrow += (xlogy_term(p1, lm) + xlogy_term(p2, lm)) / 2.0f;
+                } else {
+                    gd1[k] = jsd_dterm(p1, p2, mr, m, lm);
+                    gd2[k] = jsd_dterm(p2, p1, mr, m, lm);
+                    dot1 += p1 * gd1[k];
+                    dot2 += p2 * gd2[k];
+                }
+            }
+        }
+        if (!BWD) {
+            jrow = wave_sum(jrow);
+            plab = wave_sum(plab);  // exactly one lane holds it
+            if (lane == 0) {
+                js += (double)jrow;
+                // F.cross_entropy = -log_softmax[label]; log p = (x - m) - log s
+                if (valid) ce += (double)(w * -logf(plab));
+            }
+        } else {
+            dot1 = wave_sum(dot1);
+            dot2 = wave_sum(dot2);
+#pragma unroll
+            for (int k = 0; k < MAXC_PER_LANE; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) {
+                    const float p1 = a1[k], p2 = a2[k];
+                    const float onehot = (valid && c == (int)lab) ? 1.f : 0.f;
+                    const float g1 = k_ce * w * (p1 - onehot) + k_jsd * p1 * (gd1[k] - dot1);
+                    const float g2 = k_jsd * p2 * (gd2[k] - dot2);
+                    dx[r * C + c] = g0 * g1;
+                    dx[(r + half) * C + c] = g0 * g2;
+                }
+            }
+        }
+    }
+    if (!BWD) {
+        const double a = block_sum_d(ce, red);
+        const double b = block_sum_d(js, red);
+        if (threadIdx.x == 0) { part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = b; }
+    }
+}
+
+__global__ void cls_fin_kernel(const double* __restrict__ part, int nblocks, float k_ce, float k_jsd,
+                               float* __restrict__ out) {
+    __shared__ double red[16];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += part[2 * i]; b += part[2 * i + 1]; }
+    a = block_sum_d(a, red);
+    b = block_sum_d(b, red);
+    if (threadIdx.x == 0) {
+        const float ce = (float)a * k_ce, js = (float)b * k_jsd;
+        out[0] = ce + js;  // CrossEntropyLossPlus: loss_cls + lambda * additional
+        out[1] = ce;
+        out[2] = js;
+    }
+}
+
+int grid_for(long items, int per_block) {
+    long g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > MAXBLOCKS) g = MAXBLOCKS;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t oadg_cls_loss_workspace_bytes(void) { return (size_t)MAXBLOCKS * 2 * sizeof(double); }
+
+// mode: 0 = sigmoid rows (C must be 1), 1 = softmax rows
+int oadg_ce_jsd_fwd(const float* logits, const int64_t* labels, const float* weights, long R, int C,
+                    int mode, float avg_factor, float loss_weight, float lambda_jsd, void* workspace,
+                    size_t workspace_bytes, float* out3, void* stream) {
+    if (!logits || !labels || !workspace || !out3) return OADG_EARG;
+    if (R < 0 || (R & 1) || C < 1 || C > 64 * MAXC_PER_LANE || !(avg_factor > 0.f)) return OADG_EARG;
+    if (mode == 0 && C != 1) return OADG_EARG;
+    if (workspace_bytes < oadg_cls_loss_workspace_bytes()) return OADG_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const long half = R / 2;
+    double* part = (double*)workspace;
+    const float k_ce = loss_weight / avg_factor, k_jsd = lambda_jsd / avg_factor;
+    int g;
+    if (mode == 0) {
+        g = grid_for(half, 256 * 4);
+        hipLaunchKernelGGL((sig_kernel<false>), dim3(g), dim3(256), 0, st, logits, labels, weights, half,
+                           k_ce, k_jsd, (const float*)nullptr, part, (float*)nullptr);
+    } else {
+        g = grid_for(half, 4);
+        hipLaunchKernelGGL((sm_kernel<false>), dim3(g), dim3(256), 0, st, logits, labels, weights, half, C,
+                           k_ce, k_jsd, (const float*)nullptr, part, (float*)nullptr);
+    }
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(cls_fin_kernel, dim3(1), dim3(256), 0, st, (const double*)part, g, k_ce, k_jsd, out3);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_ce_jsd_bwd(const float* logits, const int64_t* labels, const float* weights, long R, int C,
+                    int mode, float avg_factor, float loss_weight, float lambda_jsd, const float* grad_out,
+                    float* dlogits, void* stream) {
+    if (!logits || !labels || !dlogits) return OADG_EARG;
+    if (R < 0 || (R & 1) || C < 1 || C > 64 * MAXC_PER_LANE || !(avg_factor > 0.f)) return OADG_EARG;
+    if (mode == 0 && C != 1) return OADG_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long half = R / 2;
+    if (half == 0) return OADG_OK;
+    const float k_ce = loss_weight / avg_factor, k_jsd = lambda_jsd / avg_factor;
+    if (mode == 0) {
+        hipLaunchKernelGGL((sig_kernel<true>), dim3(grid_for(half, 256 * 4)), dim3(256), 0, st, logits,
+                           labels, weights, half, k_ce, k_jsd, grad_out, (double*)nullptr, dlogits);
+    } else {
+        hipLaunchKernelGGL((sm_kernel<true>), dim3(grid_for(half, 4)), dim3(256), 0, st, logits, labels,
+                           weights, half, C, k_ce, k_jsd, grad_out, (double*)nullptr, dlogits);
+    }
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+}  // extern "C"

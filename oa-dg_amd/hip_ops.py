@@ -1,0 +1,190 @@
+"""torch.autograd glue over the C ABI of liboadg_hip.so.
+
+Each function here validates shapes, allocates outputs/workspaces as torch tensors (device memory is
+torch's, plumbing only) and enqueues the HIP kernels on torch's current stream.  No arithmetic of the
+hot path happens in Python and nothing here falls back to torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_cuda, stream_ptr
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
+
+
+# --------------------------------------------------------------------------------------- OA-Loss: supcon
+class _SupCon(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, feats, labels, n_labels, ori_size, rp_size, temper, min_samples, loss_weight):
+        require_cuda(feats, labels)
+        L = _lib.lib()
+        feats = feats.contiguous().float()
+        labels = labels.contiguous().view(-1).long()
+        B, D = feats.shape
+        nbytes = L.oadg_supcon_workspace_bytes(B, D)
+        ws = _ws(nbytes, feats.device)
+        out = torch.empty(1, dtype=torch.float32, device=feats.device)
+        check(L.oadg_supcon_fwd(ptr(feats), ptr(labels), B, D, n_labels, ori_size, rp_size,
+                                float(temper), int(min_samples), float(loss_weight), ptr(ws), nbytes,
+                                ptr(out), stream_ptr()), 'oadg_supcon_fwd')
+        ctx.save_for_backward(labels, ws)
+        ctx.args = (B, D, n_labels, ori_size, rp_size, float(temper), float(loss_weight), nbytes)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        labels, ws = ctx.saved_tensors
+        B, D, n_labels, ori_size, rp_size, temper, loss_weight, nbytes = ctx.args
+        L = _lib.lib()
+        g = gout.contiguous().float().view(1)
+        dfeats = torch.empty(B, D, dtype=torch.float32, device=ws.device)
+        check(L.oadg_supcon_bwd(ptr(labels), B, D, n_labels, ori_size, rp_size, temper, loss_weight,
+                                ptr(g), ptr(ws), nbytes, ptr(dfeats), stream_ptr()), 'oadg_supcon_bwd')
+        return dfeats, None, None, None, None, None, None, None
+
+
+def supcon_loss(feats, labels, ori_size, rp_size, temper=0.07, min_samples=10, loss_weight=1.0):
+    """loss_weight * supcontrast(normalize(feats), labels) -- contrastive_loss_plus.py:31-50.
+
+    feats [B, D]; labels [n_labels] (rows n_labels..B-1 inherit the last label)."""
+    n_labels = labels.numel()
+    return _SupCon.apply(feats, labels, n_labels, int(ori_size), int(rp_size), temper, min_samples,
+                         loss_weight)
+
+
+# --------------------------------------------------------------------------------------- OA-Loss: CE + JSD
+class _CeJsd(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, logits, labels, weights, mode, avg_factor, loss_weight, lambda_jsd):
+        require_cuda(logits, labels, weights)
+        L = _lib.lib()
+        logits = logits.contiguous().float()
+        R = logits.shape[0]
+        C = logits.numel() // max(R, 1)
+        labels = labels.contiguous().view(-1).long()
+        if weights is not None:
+            weights = weights.contiguous().view(-1).float()
+        nbytes = L.oadg_cls_loss_workspace_bytes()
+        ws = _ws(nbytes, logits.device)
+        out = torch.empty(3, dtype=torch.float32, device=logits.device)
+        check(L.oadg_ce_jsd_fwd(ptr(logits), ptr(labels), ptr(weights), R, C, mode, float(avg_factor),
+                                float(loss_weight), float(lambda_jsd), ptr(ws), nbytes, ptr(out),
+                                stream_ptr()), 'oadg_ce_jsd_fwd')
+        ctx.save_for_backward(logits, labels, weights)
+        ctx.args = (R, C, mode, float(avg_factor), float(loss_weight), float(lambda_jsd))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out
+
+    @staticmethod
+    def backward(ctx, gout, _gparts):
+        logits, labels, weights = ctx.saved_tensors
+        R, C, mode, avg_factor, loss_weight, lambda_jsd = ctx.args
+        L = _lib.lib()
+        g = gout.contiguous().float().view(1)
+        dlogits = torch.empty_like(logits)
+        check(L.oadg_ce_jsd_bwd(ptr(logits), ptr(labels), ptr(weights), R, C, mode, avg_factor,
+                                loss_weight, lambda_jsd, ptr(g), ptr(dlogits), stream_ptr()),
+              'oadg_ce_jsd_bwd')
+        return dlogits, None, None, None, None, None, None
+
+
+def ce_jsd_loss(logits, labels, weights, use_sigmoid, avg_factor, loss_weight=1.0, lambda_jsd=0.0):
+    """CrossEntropyLossPlus(additional_loss='jsdv1_3_2aug') for 2 views.
+
+    Returns (total, parts) with parts = [total, ce, lambda*jsd] (detached, for logging)."""
+    return _CeJsd.apply(logits, labels, weights, 0 if use_sigmoid else 1, avg_factor, loss_weight,
+                        lambda_jsd)
+
+
+# --------------------------------------------------------------------------------------- RoIAlign
+def _pyramid_args(maps, scales):
+    n = len(maps)
+    P = (ctypes.c_void_p * n)(*[m.data_ptr() for m in maps])
+    Hs = (ctypes.c_int * n)(*[m.shape[2] for m in maps])
+    Ws = (ctypes.c_int * n)(*[m.shape[3] for m in maps])
+    Ss = (ctypes.c_float * n)(*[float(s) for s in scales])
+    return P, Hs, Ws, Ss
+
+
+def _as_nhwc(x):
+    # logical [N,C,H,W] with channels_last strides == physical NHWC
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+class _RoIAlignFPN(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, rois, out_size, scales, finest_scale, sampling_ratio, aligned, *feats):
+        require_cuda(rois, *feats)
+        L = _lib.lib()
+        dt = feats[0].dtype
+        if dt not in (torch.float32, torch.bfloat16):
+            raise TypeError(f'RoIAlign supports fp32/bf16 feature maps, got {dt}')
+        feats = [_as_nhwc(f) for f in feats]
+        N, C = feats[0].shape[:2]
+        rois = rois.contiguous().float()
+        K = rois.shape[0]
+        PH, PW = out_size
+        out = torch.empty((K, C, PH, PW), dtype=dt, device=rois.device,
+                          memory_format=torch.channels_last)
+        P, Hs, Ws, Ss = _pyramid_args(feats, scales)
+        check(L.oadg_roi_align_fwd(P, Hs, Ws, Ss, len(feats), N, C, 0 if dt == torch.float32 else 1,
+                                   float(finest_scale), ptr(rois), K, PH, PW, int(sampling_ratio),
+                                   int(bool(aligned)), ptr(out), stream_ptr()), 'oadg_roi_align_fwd')
+        ctx.save_for_backward(rois)
+        ctx.meta = ([tuple(f.shape) for f in feats], dt, tuple(scales), float(finest_scale),
+                    int(sampling_ratio), int(bool(aligned)), (PH, PW))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (rois,) = ctx.saved_tensors
+        shapes, dt, scales, finest_scale, sampling_ratio, aligned, (PH, PW) = ctx.meta
+        L = _lib.lib()
+        gout = gout.contiguous(memory_format=torch.channels_last)
+        if gout.dtype != dt:
+            gout = gout.to(dt)
+        grads = [torch.zeros(s, dtype=torch.float32, device=rois.device,
+                             memory_format=torch.channels_last) for s in shapes]
+        N, C = shapes[0][:2]
+        P, Hs, Ws, Ss = _pyramid_args(grads, scales)
+        check(L.oadg_roi_align_bwd(P, Hs, Ws, Ss, len(grads), N, C, 0 if dt == torch.float32 else 1,
+                                   finest_scale, ptr(rois), rois.shape[0], PH, PW, sampling_ratio,
+                                   aligned, ptr(gout), stream_ptr()), 'oadg_roi_align_bwd')
+        grads = [g if dt == torch.float32 else g.to(dt) for g in grads]
+        return (None, None, None, None, None, None, *grads)
+
+
+def roi_align_fpn(feats, rois, out_size, scales, finest_scale=56, sampling_ratio=0, aligned=True):
+    """RoIAlign of rois [K,5] over a list of maps [N,C,H_l,W_l]; the level of each RoI follows
+    single_level_roi_extractor.py:36-55.  Returns [K,C,PH,PW] (channels_last memory)."""
+    if isinstance(out_size, int):
+        out_size = (out_size, out_size)
+    return _RoIAlignFPN.apply(rois, tuple(out_size), tuple(scales), finest_scale, sampling_ratio,
+                              aligned, *feats)
+
+
+# --------------------------------------------------------------------------------------- NMS
+def nms_sorted_batched(boxes, counts, iou_thr, max_keep=-1):
+    """Greedy NMS on boxes [I, Mmax, 4] already sorted by descending score (and class-offset).
+
+    counts [I] int32 = valid boxes per image.  Returns (keep [I, Mmax] int32, keep_cnt [I] int32);
+    keep[i, :keep_cnt[i]] are indices into the sorted order, ascending."""
+    require_cuda(boxes, counts)
+    L = _lib.lib()
+    boxes = boxes.contiguous().float()
+    counts = counts.contiguous().int()
+    n_img, Mmax = boxes.shape[:2]
+    nbytes = L.oadg_nms_workspace_bytes(n_img, Mmax)
+    ws = _ws(nbytes, boxes.device)
+    keep = torch.empty((n_img, Mmax), dtype=torch.int32, device=boxes.device)
+    keep_cnt = torch.empty((n_img,), dtype=torch.int32, device=boxes.device)
+    check(L.oadg_nms_batched(ptr(boxes), ptr(counts), n_img, Mmax, float(iou_thr), int(max_keep),
+                             ptr(ws), nbytes, ptr(keep), ptr(keep_cnt), stream_ptr()), 'oadg_nms_batched')
+    return keep, keep_cnt
