@@ -150,8 +150,8 @@ class _RoIAlignFPN(torch.autograd.Function):
         gout = gout.contiguous(memory_format=torch.channels_last)
         if gout.dtype != dt:
             gout = gout.to(dt)
-        grads = [torch.zeros(s, dtype=torch.float32, device=rois.device,
-                             memory_format=torch.channels_last) for s in shapes]
+        grads = [torch.empty(s, dtype=torch.float32, device=rois.device,
+                             memory_format=torch.channels_last).zero_() for s in shapes]
         N, C = shapes[0][:2]
         P, Hs, Ws, Ss = _pyramid_args(grads, scales)
         check(L.oadg_roi_align_bwd(P, Hs, Ws, Ss, len(grads), N, C, 0 if dt == torch.float32 else 1,
