@@ -9,3 +9,8 @@ calling a hot op without the library or off-GPU raises.
 __version__ = '0.1.0'
 
 from . import _lib  # noqa: F401
+from . import registry  # noqa: F401
+from .config import Config, ConfigDict  # noqa: F401
+from .registry import (MODELS, PIPELINES, build_detector, build_from_cfg)  # noqa: F401
+# importing the modules populates the registries with the reference's type strings
+from . import core, losses, backbones, necks, dense_heads, roi_heads, detectors  # noqa: F401,E402

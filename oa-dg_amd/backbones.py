@@ -1,0 +1,127 @@
+"""ResNet-50/101 backbone with mmdet's state_dict layout (mmdet/models/backbones/resnet.py:97-302,306-657,
+mmdet/models/utils/res_layer.py).  Frozen stem + stage 1, BN always in eval mode (norm_eval)."""
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from .layers import Conv2d, build_norm_layer, constant_init, kaiming_init
+from .registry import BACKBONES
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch',
+                 norm_cfg=dict(type='BN')):
+        super().__init__()
+        assert style in ('pytorch', 'caffe')
+        # resnet.py:154-159: the stride-2 layer is the 3x3 (pytorch) or the first 1x1 (caffe)
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        _, self.bn1 = build_norm_layer(norm_cfg, planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)
+        _, self.bn2 = build_norm_layer(norm_cfg, planes)
+        self.conv3 = Conv2d(planes, planes * self.expansion, 1, bias=False)
+        _, self.bn3 = build_norm_layer(norm_cfg, planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+def make_res_layer(inplanes, planes, num_blocks, stride, dilation, style, norm_cfg):
+    downsample = None
+    if stride != 1 or inplanes != planes * Bottleneck.expansion:
+        downsample = nn.Sequential(
+            Conv2d(inplanes, planes * Bottleneck.expansion, 1, stride=stride, bias=False),
+            build_norm_layer(norm_cfg, planes * Bottleneck.expansion)[1])
+    blocks = [Bottleneck(inplanes, planes, stride, dilation, downsample, style, norm_cfg)]
+    inplanes = planes * Bottleneck.expansion
+    for _ in range(1, num_blocks):
+        blocks.append(Bottleneck(inplanes, planes, 1, dilation, None, style, norm_cfg))
+    return nn.Sequential(*blocks)
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    arch_settings = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4,
+                 strides=(1, 2, 2, 2), dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch',
+                 deep_stem=False, avg_down=False, frozen_stages=-1, conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False,
+                 zero_init_residual=True, pretrained=None, init_cfg=None):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet (bottleneck depths only)')
+        assert not deep_stem and not avg_down and dcn is None and plugins is None and not with_cp
+        assert 1 <= num_stages <= 4 and len(strides) == len(dilations) == num_stages
+        assert max(out_indices) < num_stages
+        self.depth, self.out_indices, self.frozen_stages = depth, out_indices, frozen_stages
+        self.norm_eval, self.zero_init_residual, self.init_cfg = norm_eval, zero_init_residual, init_cfg
+        stem_channels = stem_channels or base_channels
+        self.conv1 = Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        _, self.bn1 = build_norm_layer(norm_cfg, stem_channels)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.res_layers = []
+        inplanes = stem_channels
+        for i, nb in enumerate(self.arch_settings[depth][:num_stages]):
+            planes = base_channels * 2 ** i
+            layer = make_res_layer(inplanes, planes, nb, strides[i], dilations[i], style, norm_cfg)
+            inplanes = planes * Bottleneck.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+        self.feat_dim = inplanes
+        self._freeze_stages()
+
+    def init_weights(self):
+        """resnet.py:405-424 defaults: Kaiming(fan_out, relu) convs, BN gamma 1, last BN of a block 0."""
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                kaiming_init(m)
+            elif isinstance(m, _BatchNorm):
+                constant_init(m, 1)
+        if self.zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    constant_init(m.bn3, 0)
+
+    def _freeze_stages(self):
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in (self.conv1, self.bn1):
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def forward(self, x):
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        outs = []
+        for i, name in enumerate(self.res_layers):
+            x = getattr(self, name)(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, _BatchNorm):
+                    m.eval()
+        return self

@@ -1,0 +1,325 @@
+"""IoU, assignment, sampling, box coding (mmdet/core/bbox/**, mmdet/core/evaluation/bbox_overlaps.py).
+
+Sampling consumes the global CPU torch generator exactly like the reference (random_sampler.py:58:
+``torch.randperm(n)`` with n = number of candidates), so seeded runs pick identical indices.
+"""
+import numpy as np
+import torch
+
+from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, BBOX_SAMPLERS, IOU_CALCULATORS
+
+
+# ----------------------------------------------------------------------------------------------- IoU
+def bbox_overlaps(b1, b2, mode='iou', is_aligned=False, eps=1e-6):
+    """torch IoU/IoF/GIoU of [.., m, 4] x [.., n, 4] (iou_calculators/iou2d_calculator.py:78-...)."""
+    assert mode in ('iou', 'iof', 'giou')
+    rows, cols = b1.size(-2), b2.size(-2)
+    batch = b1.shape[:-2]
+    if is_aligned:
+        assert rows == cols
+    if rows * cols == 0:
+        return b1.new(batch + ((rows,) if is_aligned else (rows, cols)))
+    a1 = (b1[..., 2] - b1[..., 0]) * (b1[..., 3] - b1[..., 1])
+    a2 = (b2[..., 2] - b2[..., 0]) * (b2[..., 3] - b2[..., 1])
+    if is_aligned:
+        lt = torch.max(b1[..., :2], b2[..., :2])
+        rb = torch.min(b1[..., 2:], b2[..., 2:])
+        wh = (rb - lt).clamp(min=0)
+        overlap = wh[..., 0] * wh[..., 1]
+        union = a1 + a2 - overlap if mode in ('iou', 'giou') else a1
+        if mode == 'giou':
+            elt = torch.min(b1[..., :2], b2[..., :2])
+            erb = torch.max(b1[..., 2:], b2[..., 2:])
+    else:
+        lt = torch.max(b1[..., :, None, :2], b2[..., None, :, :2])
+        rb = torch.min(b1[..., :, None, 2:], b2[..., None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        overlap = wh[..., 0] * wh[..., 1]
+        union = a1[..., None] + a2[..., None, :] - overlap if mode in ('iou', 'giou') else a1[..., None]
+        if mode == 'giou':
+            elt = torch.min(b1[..., :, None, :2], b2[..., None, :, :2])
+            erb = torch.max(b1[..., :, None, 2:], b2[..., None, :, 2:])
+    union = torch.max(union, union.new_tensor([eps]))
+    ious = overlap / union
+    if mode in ('iou', 'iof'):
+        return ious
+    ewh = (erb - elt).clamp(min=0)
+    earea = torch.max(ewh[..., 0] * ewh[..., 1], union.new_tensor([eps]))
+    return ious - (earea - union) / earea
+
+
+@IOU_CALCULATORS.register_module()
+class BboxOverlaps2D:
+
+    def __init__(self, scale=1., dtype=None):
+        self.scale, self.dtype = scale, dtype
+
+    def __call__(self, b1, b2, mode='iou', is_aligned=False):
+        if b2.size(-1) == 5:
+            b2 = b2[..., :4]
+        if b1.size(-1) == 5:
+            b1 = b1[..., :4]
+        return bbox_overlaps(b1, b2, mode, is_aligned)
+
+
+def bbox_overlaps_np(bboxes1, bboxes2, mode='iou', eps=1e-6):
+    """numpy fp32 IoU used by OA-Mix and the random-proposal generator
+    (mmdet/core/evaluation/bbox_overlaps.py:5-65, use_legacy_coordinate=False)."""
+    assert mode in ('iou', 'iof')
+    b1 = np.asarray(bboxes1).astype(np.float32)
+    b2 = np.asarray(bboxes2).astype(np.float32)
+    rows, cols = b1.shape[0], b2.shape[0]
+    if rows * cols == 0:
+        return np.zeros((rows, cols), dtype=np.float32)
+    swap = rows > cols
+    if swap:
+        b1, b2 = b2, b1
+    area1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    area2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    out = np.zeros((b1.shape[0], b2.shape[0]), dtype=np.float32)
+    for i in range(b1.shape[0]):
+        w = np.maximum(np.minimum(b1[i, 2], b2[:, 2]) - np.maximum(b1[i, 0], b2[:, 0]), 0)
+        h = np.maximum(np.minimum(b1[i, 3], b2[:, 3]) - np.maximum(b1[i, 1], b2[:, 1]), 0)
+        inter = w * h
+        if mode == 'iou':
+            union = area1[i] + area2 - inter
+        else:
+            union = area1[i] if not swap else area2
+        out[i, :] = inter / np.maximum(union, eps)
+    return out.T if swap else out
+
+
+# ----------------------------------------------------------------------------------------------- assign
+class AssignResult:
+    """assign_result.py: gt_inds 0 = negative, -1 = ignore, k>0 = gt k-1."""
+
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+    def add_gt_(self, gt_labels):
+        """Prepend the gts as self-matched proposals (assign_result.py add_gt_)."""
+        self_inds = torch.arange(1, len(gt_labels) + 1, dtype=torch.long, device=gt_labels.device)
+        self.gt_inds = torch.cat([self_inds, self.gt_inds])
+        self.max_overlaps = torch.cat([self.max_overlaps.new_ones(len(gt_labels)), self.max_overlaps])
+        if self.labels is not None:
+            self.labels = torch.cat([gt_labels, self.labels])
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner:
+    """max_iou_assigner.py:61-213.  The per-gt Python loop of low-quality matching (:195-201) is replaced by
+    an equivalent "last matching gt wins" reduction; no host synchronisation."""
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
+        self.gt_max_assign_all = gt_max_assign_all
+        self.ignore_iof_thr, self.ignore_wrt_candidates = ignore_iof_thr, ignore_wrt_candidates
+        self.match_low_quality = match_low_quality
+        self.gpu_assign_thr = gpu_assign_thr
+        self.iou_calculator = IOU_CALCULATORS.build(iou_calculator)
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)
+        if (self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0
+                and bboxes.numel() > 0):
+            if self.ignore_wrt_candidates:
+                ig = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)[0]
+            else:
+                ig = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
+            overlaps[:, ig > self.ignore_iof_thr] = -1
+        return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def assign_wrt_overlaps(self, overlaps, gt_labels=None):
+        num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
+        gt_inds = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+        if num_gts == 0 or num_bboxes == 0:
+            max_overlaps = overlaps.new_zeros((num_bboxes,))
+            if num_gts == 0:
+                gt_inds[:] = 0
+            labels = None if gt_labels is None else overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+            return AssignResult(num_gts, gt_inds, max_overlaps, labels=labels)
+        max_overlaps, argmax_overlaps = overlaps.max(dim=0)
+        gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+        if isinstance(self.neg_iou_thr, float):
+            gt_inds[(max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr)] = 0
+        elif isinstance(self.neg_iou_thr, tuple):
+            gt_inds[(max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1])] = 0
+        pos = max_overlaps >= self.pos_iou_thr
+        gt_inds = torch.where(pos, argmax_overlaps + 1, gt_inds)
+        if self.match_low_quality:
+            ok = gt_max_overlaps >= self.min_pos_iou                               # [k]
+            ids = torch.arange(1, num_gts + 1, device=overlaps.device)
+            if self.gt_max_assign_all:
+                hit = (overlaps == gt_max_overlaps[:, None]) & ok[:, None]         # [k, n]
+                last = (hit * ids[:, None]).max(dim=0)[0]                          # later gts overwrite
+                gt_inds = torch.where(last > 0, last, gt_inds)
+            else:
+                for i in range(num_gts):                                           # rare path, order matters
+                    if gt_max_overlaps[i] >= self.min_pos_iou:
+                        gt_inds[gt_argmax_overlaps[i]] = i + 1
+        if gt_labels is not None:
+            labels = gt_inds.new_full((num_bboxes,), -1)
+            p = gt_inds > 0
+            labels = torch.where(p, gt_labels[(gt_inds - 1).clamp(min=0)], labels)
+        else:
+            labels = None
+        return AssignResult(num_gts, gt_inds, max_overlaps, labels=labels)
+
+
+# ----------------------------------------------------------------------------------------------- sample
+class SamplingResult:
+    """sampling_result.py."""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
+        else:
+            if len(gt_bboxes.shape) < 2:
+                gt_bboxes = gt_bboxes.view(-1, 4)
+            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds.long(), :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+
+    @property
+    def bboxes(self):
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
+
+@BBOX_SAMPLERS.register_module()
+class RandomSampler:
+    """base_sampler.py:38-103 + random_sampler.py:32-82."""
+
+    def __init__(self, num, pos_fraction, neg_pos_ub=-1, add_gt_as_proposals=True, **kwargs):
+        self.num, self.pos_fraction = num, pos_fraction
+        self.neg_pos_ub, self.add_gt_as_proposals = neg_pos_ub, add_gt_as_proposals
+
+    @staticmethod
+    def random_choice(gallery, num):
+        assert len(gallery) >= num
+        # CPU generator, then moved: the draw depends only on gallery.numel() (random_sampler.py:58)
+        perm = torch.randperm(gallery.numel())[:num].to(device=gallery.device)
+        return gallery[perm]
+
+    def _sample(self, mask, num_expected):
+        inds = torch.nonzero(mask, as_tuple=False)
+        if inds.numel() != 0:
+            inds = inds.squeeze(1)
+        if inds.numel() <= num_expected:
+            return inds
+        return self.random_choice(inds, num_expected)
+
+    def sample(self, assign_result, bboxes, gt_bboxes, gt_labels=None, **kwargs):
+        if len(bboxes.shape) < 2:
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :4]
+        gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
+        if self.add_gt_as_proposals and len(gt_bboxes) > 0:
+            if gt_labels is None:
+                raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
+            bboxes = torch.cat([gt_bboxes, bboxes], dim=0)
+            assign_result.add_gt_(gt_labels)
+            gt_flags = torch.cat([bboxes.new_ones(gt_bboxes.shape[0], dtype=torch.uint8), gt_flags])
+        num_pos = int(self.num * self.pos_fraction)
+        pos_inds = self._sample(assign_result.gt_inds > 0, num_pos).unique()
+        num_neg = self.num - pos_inds.numel()
+        if self.neg_pos_ub >= 0:
+            num_neg = min(num_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
+        neg_inds = self._sample(assign_result.gt_inds == 0, num_neg).unique()
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+# ----------------------------------------------------------------------------------------------- coder
+def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+    """delta_xywh_bbox_coder.py:119-180, including the fork's zero-size guard (:152-160) and its
+    mismatched mask ``gy[nan_x] = py[nan_y]``."""
+    assert proposals.size() == gt.size()
+    proposals, gt = proposals.float(), gt.float()
+    px = (proposals[..., 0] + proposals[..., 2]) * 0.5
+    py = (proposals[..., 1] + proposals[..., 3]) * 0.5
+    pw = proposals[..., 2] - proposals[..., 0]
+    ph = proposals[..., 3] - proposals[..., 1]
+    gx = (gt[..., 0] + gt[..., 2]) * 0.5
+    gy = (gt[..., 1] + gt[..., 3]) * 0.5
+    gw = gt[..., 2] - gt[..., 0]
+    gh = gt[..., 3] - gt[..., 1]
+    nan_x, nan_y = (pw == 0), (ph == 0)
+    pw[nan_x] = 1e-6
+    ph[nan_y] = 1e-6
+    gw[nan_x] = 1e-6
+    gh[nan_y] = 1e-6
+    gx[nan_x] = px[nan_x]
+    gy[nan_x] = py[nan_y]
+    deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
+    means = deltas.new_tensor(means).unsqueeze(0)
+    stds = deltas.new_tensor(stds).unsqueeze(0)
+    return deltas.sub_(means).div_(stds)
+
+
+def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
+               wh_ratio_clip=16 / 1000, clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
+    """delta_xywh_bbox_coder.py:184-..."""
+    num_bboxes, num_classes = deltas.size(0), deltas.size(1) // 4
+    if num_bboxes == 0:
+        return deltas
+    deltas = deltas.reshape(-1, 4)
+    means = deltas.new_tensor(means).view(1, -1)
+    stds = deltas.new_tensor(stds).view(1, -1)
+    d = deltas * stds + means
+    dxy, dwh = d[:, :2], d[:, 2:]
+    rois_ = rois.repeat(1, num_classes).reshape(-1, 4)
+    pxy = (rois_[:, :2] + rois_[:, 2:]) * 0.5
+    pwh = rois_[:, 2:] - rois_[:, :2]
+    dxy_wh = pwh * dxy
+    max_ratio = np.abs(np.log(wh_ratio_clip))
+    if add_ctr_clamp:
+        dxy_wh = torch.clamp(dxy_wh, max=ctr_clamp, min=-ctr_clamp)
+        dwh = torch.clamp(dwh, max=max_ratio)
+    else:
+        dwh = dwh.clamp(min=-max_ratio, max=max_ratio)
+    gxy = pxy + dxy_wh
+    gwh = pwh * dwh.exp()
+    bboxes = torch.cat([gxy - gwh * 0.5, gxy + gwh * 0.5], dim=-1)
+    if clip_border and max_shape is not None:
+        bboxes[..., 0::2].clamp_(min=0, max=max_shape[1])
+        bboxes[..., 1::2].clamp_(min=0, max=max_shape[0])
+    return bboxes.reshape(num_bboxes, -1)
+
+
+@BBOX_CODERS.register_module()
+class DeltaXYWHBBoxCoder:
+
+    def __init__(self, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), clip_border=True,
+                 add_ctr_clamp=False, ctr_clamp=32):
+        self.means, self.stds = target_means, target_stds
+        self.clip_border, self.add_ctr_clamp, self.ctr_clamp = clip_border, add_ctr_clamp, ctr_clamp
+
+    def encode(self, bboxes, gt_bboxes):
+        assert bboxes.size(0) == gt_bboxes.size(0) and bboxes.size(-1) == gt_bboxes.size(-1) == 4
+        return bbox2delta(bboxes, gt_bboxes, self.means, self.stds)
+
+    def decode(self, bboxes, pred_bboxes, max_shape=None, wh_ratio_clip=16 / 1000):
+        assert pred_bboxes.size(0) == bboxes.size(0)
+        return delta2bbox(bboxes, pred_bboxes, self.means, self.stds, max_shape, wh_ratio_clip,
+                          self.clip_border, self.add_ctr_clamp, self.ctr_clamp)
+
+
+def bbox2roi(bbox_list):
+    """list of [n_i, >=4] boxes -> [sum n_i, 5] with the list position as batch index (transforms.py:75-94)."""
+    rois = []
+    for img_id, b in enumerate(bbox_list):
+        if b.size(0) > 0:
+            rois.append(torch.cat([b.new_full((b.size(0), 1), img_id), b[:, :4]], dim=-1))
+        else:
+            rois.append(b.new_zeros((0, 5)))
+    return torch.cat(rois, 0)

@@ -1,0 +1,268 @@
+"""RPN head (mmdet/models/dense_heads/{base_dense_head,anchor_head,rpn_head}.py).
+
+Host orchestration is torch tensor plumbing; the classification loss is the fused HIP CE+JSD kernel and the
+proposal NMS is the batched HIP NMS (one launch for all images instead of one mmcv call per image)."""
+import copy
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops
+from .core import anchor_inside_flags, images_to_levels, multi_apply, unmap
+from .layers import Conv2d, normal_init
+from .registry import (HEADS, build_assigner, build_bbox_coder, build_loss, build_prior_generator,
+                       build_sampler)
+
+
+class AnchorHead(nn.Module):
+
+    def __init__(self, num_classes, in_channels, feat_channels=256,
+                 anchor_generator=dict(type='AnchorGenerator', scales=[8, 16, 32], ratios=[0.5, 1.0, 2.0],
+                                       strides=[4, 8, 16, 32, 64]),
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True,
+                                 target_means=(.0, .0, .0, .0), target_stds=(1.0, 1.0, 1.0, 1.0)),
+                 reg_decoded_bbox=False,
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0),
+                 train_cfg=None, test_cfg=None, init_cfg=None):
+        super().__init__()
+        self.in_channels, self.num_classes, self.feat_channels = in_channels, num_classes, feat_channels
+        self.use_sigmoid_cls = loss_cls.get('use_sigmoid', False)
+        self.cls_out_channels = num_classes if self.use_sigmoid_cls else num_classes + 1
+        if self.cls_out_channels <= 0:
+            raise ValueError(f'num_classes={num_classes} is too small')
+        self.reg_decoded_bbox = reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if self.train_cfg:
+            self.assigner = build_assigner(self.train_cfg.assigner)
+            # anchor_head.py:96-101: sampling unless the cls loss is focal-style
+            self.sampling = loss_cls['type'] not in ['FocalLoss', 'GHMC', 'QualityFocalLoss']
+            sampler_cfg = self.train_cfg.sampler if self.sampling and hasattr(self.train_cfg, 'sampler') \
+                else dict(type='PseudoSampler')
+            self.sampler = build_sampler(sampler_cfg, context=self)
+        self.prior_generator = build_prior_generator(anchor_generator)
+        self.num_base_priors = self.prior_generator.num_base_priors[0]
+        self._init_layers()
+
+    # -- targets -------------------------------------------------------------------------------------
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        """anchor_head.py:171-199."""
+        multi_level_anchors = self.prior_generator.grid_priors(featmap_sizes, device=device)
+        anchor_list = [multi_level_anchors for _ in range(len(img_metas))]
+        valid_flag_list = [self.prior_generator.valid_flags(featmap_sizes, m['pad_shape'], device)
+                           for m in img_metas]
+        return anchor_list, valid_flag_list
+
+    def _get_targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore, gt_labels,
+                            img_meta, label_channels=1, unmap_outputs=True):
+        """anchor_head.py:201-297."""
+        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                           self.train_cfg.allowed_border)
+        if not inside_flags.any():
+            return (None,) * 7
+        anchors = flat_anchors[inside_flags, :]
+        assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore,
+                                             None if self.sampling else gt_labels)
+        sampling_result = self.sampler.sample(assign_result, anchors, gt_bboxes)
+        n = anchors.shape[0]
+        bbox_targets = torch.zeros_like(anchors)
+        bbox_weights = torch.zeros_like(anchors)
+        labels = anchors.new_full((n,), self.num_classes, dtype=torch.long)
+        label_weights = anchors.new_zeros(n, dtype=torch.float)
+        pos_inds, neg_inds = sampling_result.pos_inds, sampling_result.neg_inds
+        if len(pos_inds) > 0:
+            if not self.reg_decoded_bbox:
+                pos_t = self.bbox_coder.encode(sampling_result.pos_bboxes, sampling_result.pos_gt_bboxes)
+            else:
+                pos_t = sampling_result.pos_gt_bboxes
+            bbox_targets[pos_inds, :] = pos_t
+            bbox_weights[pos_inds, :] = 1.0
+            if gt_labels is None:
+                labels[pos_inds] = 0   # RPN: foreground is class 0
+            else:
+                labels[pos_inds] = gt_labels[sampling_result.pos_assigned_gt_inds]
+            label_weights[pos_inds] = 1.0 if self.train_cfg.pos_weight <= 0 else self.train_cfg.pos_weight
+        if len(neg_inds) > 0:
+            label_weights[neg_inds] = 1.0
+        if unmap_outputs:
+            total = flat_anchors.size(0)
+            labels = unmap(labels, total, inside_flags, fill=self.num_classes)
+            label_weights = unmap(label_weights, total, inside_flags)
+            bbox_targets = unmap(bbox_targets, total, inside_flags)
+            bbox_weights = unmap(bbox_weights, total, inside_flags)
+        return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, sampling_result
+
+    def get_targets(self, anchor_list, valid_flag_list, gt_bboxes_list, img_metas,
+                    gt_bboxes_ignore_list=None, gt_labels_list=None, label_channels=1, unmap_outputs=True):
+        """anchor_head.py:299-400."""
+        num_imgs = len(img_metas)
+        assert len(anchor_list) == len(valid_flag_list) == num_imgs
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        concat_anchors = [torch.cat(a) for a in anchor_list]
+        concat_flags = [torch.cat(f) for f in valid_flag_list]
+        if gt_bboxes_ignore_list is None:
+            gt_bboxes_ignore_list = [None] * num_imgs
+        if gt_labels_list is None:
+            gt_labels_list = [None] * num_imgs
+        results = multi_apply(self._get_targets_single, concat_anchors, concat_flags, gt_bboxes_list,
+                              gt_bboxes_ignore_list, gt_labels_list, img_metas,
+                              label_channels=label_channels, unmap_outputs=unmap_outputs)
+        all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_l, neg_l, _ = results[:7]
+        if any(l is None for l in all_labels):
+            return None
+        num_total_pos = sum(max(i.numel(), 1) for i in pos_l)
+        num_total_neg = sum(max(i.numel(), 1) for i in neg_l)
+        return (images_to_levels(all_labels, num_level_anchors),
+                images_to_levels(all_label_weights, num_level_anchors),
+                images_to_levels(all_bbox_targets, num_level_anchors),
+                images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
+
+    # -- loss ----------------------------------------------------------------------------------------
+    def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
+                    num_total_samples):
+        """anchor_head.py:402-452; NHWC-contiguous maps make the permute+reshape a free view."""
+        labels = labels.reshape(-1)
+        label_weights = label_weights.reshape(-1)
+        cls_score = cls_score.float().permute(0, 2, 3, 1).reshape(-1, self.cls_out_channels)
+        loss_cls = self.loss_cls(cls_score, labels, label_weights, avg_factor=num_total_samples)
+        bbox_targets = bbox_targets.reshape(-1, 4)
+        bbox_weights = bbox_weights.reshape(-1, 4)
+        bbox_pred = bbox_pred.float().permute(0, 2, 3, 1).reshape(-1, 4)
+        loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
+        return loss_cls, loss_bbox
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        """anchor_head.py:455-544."""
+        featmap_sizes = [f.size()[-2:] for f in cls_scores]
+        assert len(featmap_sizes) == self.prior_generator.num_levels
+        device = cls_scores[0].device
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
+        label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+        targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
+                                   gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                   label_channels=label_channels)
+        if targets is None:
+            return None
+        self.rpn_targets = targets
+        labels_l, lw_l, bt_l, bw_l, num_pos, num_neg = targets
+        num_total_samples = num_pos + num_neg if self.sampling else num_pos
+        losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, labels_l, lw_l, bt_l,
+                                              bw_l, num_total_samples=num_total_samples)
+        return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
+
+    def forward(self, feats):
+        return multi_apply(self.forward_single, feats)
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
+                      proposal_cfg=None, num_proposal_imgs=None, **kwargs):
+        """base_dense_head.py:302-342.  ``num_proposal_imgs`` limits proposal generation to the first images
+        (the contrastive RoI head only consumes the view-1 lists, contrastive_roi_head.py:85-95)."""
+        outs = self(x)
+        if gt_labels is None:
+            losses = self.loss(*outs, gt_bboxes, None, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        else:
+            losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
+                                        num_imgs=num_proposal_imgs)
+        return losses, proposal_list
+
+
+@HEADS.register_module()
+class RPNHead(AnchorHead):
+    """rpn_head.py:17-235."""
+
+    def __init__(self, in_channels, init_cfg=dict(type='Normal', layer='Conv2d', std=0.01), num_convs=1,
+                 **kwargs):
+        assert num_convs == 1, 'the named configs use a single 3x3 RPN conv'
+        self.num_convs = num_convs
+        super().__init__(1, in_channels, init_cfg=init_cfg, **kwargs)
+
+    def _init_layers(self):
+        self.rpn_conv = Conv2d(self.in_channels, self.feat_channels, 3, padding=1)
+        self.rpn_cls = Conv2d(self.feat_channels, self.num_base_priors * self.cls_out_channels, 1)
+        self.rpn_reg = Conv2d(self.feat_channels, self.num_base_priors * 4, 1)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):
+            normal_init(m, std=0.01)
+
+    def forward_single(self, x):
+        x = F.relu(self.rpn_conv(x), inplace=True)
+        return self.rpn_cls(x), self.rpn_reg(x)
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        losses = super().loss(cls_scores, bbox_preds, gt_bboxes, None, img_metas,
+                              gt_bboxes_ignore=gt_bboxes_ignore)
+        return dict(loss_rpn_cls=losses['loss_cls'], loss_rpn_bbox=losses['loss_bbox'])
+
+    @torch.no_grad()
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, num_imgs=None, **kwargs):
+        """base_dense_head.py:31-106 + rpn_head.py:103-235, batched over images.
+
+        Per image and level: stable descending sort, top nms_pre, decode against the anchors, drop
+        w/h <= min_bbox_size, then class(level)-aware NMS and the first max_per_img survivors."""
+        cfg = copy.deepcopy(self.test_cfg if cfg is None else cfg)
+        assert len(cls_scores) == len(bbox_preds)
+        n_img = cls_scores[0].shape[0] if num_imgs is None else min(num_imgs, cls_scores[0].shape[0])
+        device = cls_scores[0].device
+        featmap_sizes = [c.shape[-2:] for c in cls_scores]
+        mlvl_anchors = self.prior_generator.grid_priors(featmap_sizes, device=device)
+        nms_pre = cfg.get('nms_pre', -1)
+        sc_l, dl_l, an_l, id_l = [], [], [], []
+        for lvl, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
+            cs = cs[:n_img].detach().float().permute(0, 2, 3, 1)
+            if self.use_sigmoid_cls:
+                scores = cs.reshape(n_img, -1).sigmoid()
+            else:
+                scores = cs.reshape(n_img, -1, 2).softmax(dim=-1)[..., 0]
+            deltas = bp[:n_img].detach().float().permute(0, 2, 3, 1).reshape(n_img, -1, 4)
+            anchors = mlvl_anchors[lvl][None].expand(n_img, -1, -1)
+            if 0 < nms_pre < scores.shape[1]:
+                ranked, rank_inds = scores.sort(dim=1, descending=True, stable=True)
+                top = rank_inds[:, :nms_pre]
+                scores = ranked[:, :nms_pre]
+                deltas = torch.gather(deltas, 1, top[..., None].expand(-1, -1, 4))
+                anchors = torch.gather(anchors, 1, top[..., None].expand(-1, -1, 4))
+            sc_l.append(scores)
+            dl_l.append(deltas)
+            an_l.append(anchors)
+            id_l.append(scores.new_full((scores.shape[1],), lvl, dtype=torch.long))
+        scores = torch.cat(sc_l, 1)                 # [I, M]
+        deltas = torch.cat(dl_l, 1)
+        anchors = torch.cat(an_l, 1)
+        ids = torch.cat(id_l)[None].expand(n_img, -1)
+        M = scores.shape[1]
+        img_shape = img_metas[0]['img_shape']
+        assert all(tuple(m['img_shape'][:2]) == tuple(img_shape[:2]) for m in img_metas[:n_img]), \
+            'batched proposal decoding assumes one image shape per batch (true for padded synthetic batches)'
+        props = self.bbox_coder.decode(anchors.reshape(-1, 4), deltas.reshape(-1, 4),
+                                       max_shape=img_shape).view(n_img, M, 4)
+        valid = torch.ones_like(scores, dtype=torch.bool)
+        if cfg.min_bbox_size >= 0:
+            w = props[..., 2] - props[..., 0]
+            h = props[..., 3] - props[..., 1]
+            valid = (w > cfg.min_bbox_size) & (h > cfg.min_bbox_size)
+        nms_cfg = dict(cfg.nms)
+        assert nms_cfg.pop('type', 'nms') == 'nms'
+        thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+        # batched_nms (mmcv): offset every class by (max coordinate + 1); invalid boxes sort last
+        mx = torch.where(valid[..., None], props, props.new_zeros(())).amax(dim=(1, 2))   # [I]
+        offs = ids.to(props) * (mx + 1)[:, None]
+        key = torch.where(valid, scores, scores.new_full((), -1.0))
+        order = key.sort(dim=1, descending=True, stable=True)[1]
+        boxes_sorted = torch.gather(props + offs[..., None], 1, order[..., None].expand(-1, -1, 4))
+        counts = valid.sum(dim=1).int()
+        keep, keep_cnt = hip_ops.nms_sorted_batched(boxes_sorted, counts, thr, cfg.max_per_img)
+        cnt = keep_cnt.tolist()                      # one host read for the whole batch
+        out = []
+        for i in range(n_img):
+            sel = order[i, keep[i, :cnt[i]].long()]
+            out.append(torch.cat([props[i, sel], scores[i, sel, None]], dim=1))
+        return out

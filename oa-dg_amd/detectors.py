@@ -1,0 +1,195 @@
+"""Detectors (mmdet/models/detectors/{base,two_stage,faster_rcnn}.py)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .core import bbox_overlaps_np
+from .registry import DETECTORS, build_backbone, build_head, build_neck
+
+
+def integrate_data(data, train_cfg):
+    """base.py:22-48: concatenate the views along the batch axis (all originals first, then all OA-Mix
+    images) and extend/duplicate the per-image lists to match; inject ``num_views`` / ``batch_size``."""
+    batch_size = len(data['img'])
+    if 'inv' in train_cfg.keys():
+        if train_cfg['inv']:
+            data['img'] = torch.cat([data['img2'], data['img']], dim=0)
+    else:
+        data['img'] = torch.cat([v for k, v in data.items() if ('img' in k) and ('img_metas' not in k)], dim=0)
+    num_views = int(len(data['img']) / batch_size)
+    for i in range(2, num_views + 1):
+        for key in ['img', 'gt_bboxes', 'gt_labels', 'gt_instance_inds', 'img_metas', 'multilevel_boxes',
+                    'oamix_boxes']:
+            if f'{key}{i}' in data:
+                if key != 'img':
+                    data[key] += data[f'{key}{i}']
+                del data[f'{key}{i}']
+            elif key in data:
+                for b in range(batch_size):
+                    data[key].append(data[key][b])
+    data['num_views'] = num_views
+    data['batch_size'] = batch_size
+    return data
+
+
+def generate_random_bboxes_xy(img_size, num_bboxes, bboxes_xy=None, scales=(0.01, 0.2), ratios=(0.3, 1 / 0.3),
+                              max_iters=500, iou_max=1.0, iou_min=0.0, **kwargs):
+    """two_stage.py:389-419 (global numpy RNG, same draw order: x1, y1, scale, ratio per trial)."""
+    if isinstance(num_bboxes, (tuple, list)):
+        num_bboxes = np.random.randint(num_bboxes[0], num_bboxes[1] + 1)
+    img_width, img_height = img_size
+    out = np.zeros((num_bboxes, 5))
+    total = 0
+    for _ in range(max_iters):
+        if total >= num_bboxes:
+            break
+        x1, y1 = np.random.randint(0, img_width), np.random.randint(0, img_height)
+        scale = np.random.uniform(*scales) * img_height * img_width
+        ratio = np.random.uniform(*ratios)
+        w, h = int(np.sqrt(scale / ratio)), int(np.sqrt(scale * ratio))
+        box = np.array([[x1, y1, min(x1 + w, img_width), min(y1 + h, img_height), 1]])
+        if bboxes_xy is not None:
+            ious = bbox_overlaps_np(box, bboxes_xy)
+            if np.max(ious) > iou_max or np.max(ious) < iou_min:
+                continue
+        out[total, :] = box[0]
+        total += 1
+    return out[:total, :]
+
+
+class BaseDetector(nn.Module):
+
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.features, self.wandb_features = dict(), dict()
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        raise NotImplementedError('inference is outside the training hot path')
+
+    def _parse_losses(self, losses):
+        """base.py:234-277.  Same keys and values; the per-variable all-reduces + .item() of the reference
+        become one packed all-reduce and one host read."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        log_vars['loss'] = loss
+        names = list(log_vars.keys())
+        packed = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
+        if dist.is_available() and dist.is_initialized():
+            packed = torch.cat([packed, packed.new_tensor([float(len(names))])])
+            dist.all_reduce(packed)
+            assert int(round(packed[-1].item())) == len(names) * dist.get_world_size(), \
+                f'loss log variables are different across GPUs! rank {dist.get_rank()} keys: {names}'
+            packed = packed[:-1] / dist.get_world_size()
+        if getattr(self, 'log_vars_on_host', True):
+            vals = packed.tolist()
+            log_vars = OrderedDict(zip(names, vals))
+        else:   # benchmark mode: keep the packed device tensor, no host synchronisation per step
+            log_vars = OrderedDict(zip(names, packed.unbind(0)))
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        """base.py:413-455."""
+        self.features.clear()
+        self.wandb_features.clear()
+        data = integrate_data(data, self.train_cfg)
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+
+class TwoStageDetector(BaseDetector):
+    """two_stage.py:13-204."""
+
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        self.rpn_head = self.roi_head = None
+        if rpn_head is not None:
+            rpn_train_cfg = train_cfg.rpn if train_cfg is not None else None
+            rpn_head_ = dict(rpn_head)
+            rpn_head_.update(train_cfg=rpn_train_cfg, test_cfg=test_cfg.rpn if test_cfg is not None else None)
+            self.rpn_head = build_head(rpn_head_)
+        if roi_head is not None:
+            roi_head_ = dict(roi_head)
+            roi_head_.update(train_cfg=train_cfg.rcnn if train_cfg is not None else None,
+                             test_cfg=test_cfg.rcnn if test_cfg is not None else None)
+            self.roi_head = build_head(roi_head_)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    with_rpn = property(lambda self: self.rpn_head is not None)
+    with_neck = property(lambda self: self.neck is not None)
+
+    def init_weights(self):
+        self.backbone.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        if self.with_neck:
+            x = self.neck(x)
+        return x
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
+                      proposals=None, **kwargs):
+        x = self.extract_feat(img)
+        losses = dict()
+        if self.with_rpn:
+            proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn if self.test_cfg else None)
+            # the contrastive RoI head reads the view-1 proposal lists only (contrastive_roi_head.py:85-95)
+            n_prop = kwargs['batch_size'] if 'num_views' in kwargs else None
+            rpn_losses, proposal_list = self.rpn_head.forward_train(
+                x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
+                proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop)
+            losses.update(rpn_losses)
+        else:
+            proposal_list = proposals
+        if 'random_proposal_cfg' in self.train_cfg.keys():
+            kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
+        losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
+                                                  gt_bboxes_ignore, gt_masks, **kwargs))
+        return losses
+
+    def get_random_proposal_list(self, img, gt_bboxes, kwargs):
+        """two_stage.py:162-204, quirks kept: OA-Mix boxes are filtered against image 0's gts (:178,186);
+        ``img.shape[2:]`` = (H, W) is consumed as (width, height) (:164,193 vs :395); new boxes use the gts
+        of image ``i % num_views`` (:195)."""
+        cfg = self.train_cfg['random_proposal_cfg']
+        img_shape = img.shape[2:]
+        B = img.shape[0]
+        assert 'num_views' in kwargs, 'num_view is required'
+        assert cfg['bbox_from'] == 'oagrb', 'oagrb is required'
+        assert 'multilevel_bboxes' in kwargs or 'oamix_boxes' in kwargs, 'boxes are required'
+        device = img.device
+        gts = [g.detach().cpu().numpy() for g in gt_bboxes]   # one host copy of the gts per step
+        out = []
+        for b in kwargs.get('multilevel_boxes', []):
+            b = b.to(torch.float32).cpu().numpy()
+            out.append(b[np.max(bbox_overlaps_np(b, gts[0]), axis=1) < cfg['iou_max']])
+        for i, b in enumerate(kwargs.get('oamix_boxes', [])):
+            b = b.to(torch.float32).cpu().numpy()
+            b = b[np.max(bbox_overlaps_np(b, gts[0]), axis=1) < cfg['iou_max']]
+            out[i] = np.concatenate([out[i], b], axis=0)
+        for i in range(B):
+            new = generate_random_bboxes_xy(img_shape, num_bboxes=cfg['num_bboxes'],
+                                            bboxes_xy=gts[i % kwargs['num_views']], scales=cfg['scales'],
+                                            ratios=cfg['ratios'], iou_max=cfg['iou_max'], iou_min=cfg['iou_min'])
+            out[i] = np.concatenate([out[i], new[:, :4].astype(np.float32)], axis=0)
+        return [torch.as_tensor(o).float().to(device) for o in out]
+
+
+@DETECTORS.register_module()
+class FasterRCNN(TwoStageDetector):
+    pass

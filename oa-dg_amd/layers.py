@@ -1,0 +1,99 @@
+"""Convolution / normalisation bricks with mmcv-compatible parameter names.
+
+``conv2d`` is the single dispatch point of every convolution on the path: shapes covered by the hand-written
+MFMA implicit-GEMM kernels go to the HIP library, everything else to torch's convolution (MIOpen), which is
+library plumbing for plain convolutions exactly like the reference's cuDNN calls.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_CONV_IMPL = None   # set by hip_conv.enable(); signature (x, w, b, stride, padding, dilation) -> y or None
+
+
+def set_conv_impl(fn):
+    global _CONV_IMPL
+    _CONV_IMPL = fn
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    if _CONV_IMPL is not None and x.is_cuda:
+        y = _CONV_IMPL(x, weight, bias, stride, padding, dilation)
+        if y is not None:
+            return y
+    return F.conv2d(x, weight, bias, stride, padding, dilation)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same state_dict keys) routed through :func:`conv2d`."""
+
+    def forward(self, x):
+        assert self.groups == 1 and self.padding_mode == 'zeros'
+        return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+
+
+def build_norm_layer(cfg, num_features, postfix=''):
+    """mmcv.cnn.build_norm_layer for BN: returns (name, layer); ``requires_grad`` from the cfg."""
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    if t not in ('BN', 'BN2d'):
+        raise NotImplementedError(f'norm type {t} is not used by the named configs')
+    requires_grad = cfg.pop('requires_grad', True)
+    cfg.setdefault('eps', 1e-5)
+    layer = nn.BatchNorm2d(num_features, **cfg)
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return 'bn' + str(postfix), layer
+
+
+class ConvModule(nn.Module):
+    """conv [+ BN] [+ ReLU] with mmcv.cnn.ConvModule's attribute names (``conv``, ``bn``, ``activate``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias='auto',
+                 conv_cfg=None, norm_cfg=None, act_cfg=dict(type='ReLU'), inplace=True):
+        super().__init__()
+        assert conv_cfg is None or conv_cfg.get('type') in ('Conv2d', None)
+        self.with_norm = norm_cfg is not None
+        self.with_activation = act_cfg is not None
+        if bias == 'auto':
+            bias = not self.with_norm
+        self.conv = Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, bias=bias)
+        if self.with_norm:
+            _, self.bn = build_norm_layer(norm_cfg, out_channels)
+        if self.with_activation:
+            assert act_cfg['type'] == 'ReLU'
+            self.activate = nn.ReLU(inplace=inplace)
+        kaiming_init(self.conv)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.with_norm:
+            x = self.bn(x)
+        if self.with_activation:
+            x = self.activate(x)
+        return x
+
+
+def kaiming_init(m, a=0, mode='fan_out', nonlinearity='relu', bias=0):
+    nn.init.kaiming_normal_(m.weight, a=a, mode=mode, nonlinearity=nonlinearity)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def xavier_init(m, gain=1, bias=0, distribution='uniform'):
+    (nn.init.xavier_uniform_ if distribution == 'uniform' else nn.init.xavier_normal_)(m.weight, gain=gain)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def normal_init(m, mean=0, std=1, bias=0):
+    nn.init.normal_(m.weight, mean, std)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def constant_init(m, val, bias=0):
+    if getattr(m, 'weight', None) is not None:
+        nn.init.constant_(m.weight, val)
+    if getattr(m, 'bias', None) is not None:
+        nn.init.constant_(m.bias, bias)

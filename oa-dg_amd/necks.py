@@ -1,0 +1,59 @@
+"""FPN neck (mmdet/models/necks/fpn.py:12-205) for the configurations the named configs use:
+add_extra_convs=False, no norm/activation on the lateral/output convs, nearest-neighbour top-down path,
+extra levels by stride-2 subsampling (max_pool2d with kernel 1)."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .layers import ConvModule, xavier_init
+from .registry import NECKS
+
+
+@NECKS.register_module()
+class FPN(nn.Module):
+
+    def __init__(self, in_channels, out_channels, num_outs, start_level=0, end_level=-1,
+                 add_extra_convs=False, relu_before_extra_convs=False, no_norm_on_lateral=False,
+                 conv_cfg=None, norm_cfg=None, act_cfg=None, upsample_cfg=dict(mode='nearest'),
+                 init_cfg=dict(type='Xavier', layer='Conv2d', distribution='uniform')):
+        super().__init__()
+        assert isinstance(in_channels, list)
+        if add_extra_convs:
+            raise NotImplementedError('add_extra_convs is not used by the named configs')
+        assert norm_cfg is None and act_cfg is None
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_ins, self.num_outs = len(in_channels), num_outs
+        self.upsample_cfg = dict(upsample_cfg)
+        if end_level == -1:
+            self.backbone_end_level = self.num_ins
+            assert num_outs >= self.num_ins - start_level
+        else:
+            self.backbone_end_level = end_level
+            assert end_level <= len(in_channels) and num_outs == end_level - start_level
+        self.start_level, self.end_level = start_level, end_level
+        self.lateral_convs = nn.ModuleList()
+        self.fpn_convs = nn.ModuleList()
+        for i in range(self.start_level, self.backbone_end_level):
+            self.lateral_convs.append(ConvModule(in_channels[i], out_channels, 1, act_cfg=None, inplace=False))
+            self.fpn_convs.append(ConvModule(out_channels, out_channels, 3, padding=1, act_cfg=None,
+                                             inplace=False))
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                xavier_init(m, distribution='uniform')
+
+    def forward(self, inputs):
+        assert len(inputs) == len(self.in_channels)
+        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        n = len(laterals)
+        for i in range(n - 1, 0, -1):   # fpn.py:166-175
+            if 'scale_factor' in self.upsample_cfg:
+                laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], **self.upsample_cfg)
+            else:
+                laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
+                                                                  **self.upsample_cfg)
+        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        for _ in range(self.num_outs - len(outs)):   # fpn.py:184-188
+            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        return tuple(outs)

@@ -1,0 +1,353 @@
+"""RoI extractor, bbox heads and RoI heads (mmdet/models/roi_heads/**).
+
+RoI feature extraction is one HIP launch over the whole pyramid (level mapping in-kernel) instead of the
+reference's per-level nonzero/gather/scatter loop; every pyramid level is therefore always in the autograd
+graph (the reference needs a dummy-graph trick for that, single_level_roi_extractor.py:136-145)."""
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+from .core import bbox2roi, multi_apply
+from .layers import normal_init, xavier_init
+from .losses import accuracy
+from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_bbox_coder, build_head,
+                       build_loss, build_roi_extractor, build_sampler)
+
+
+def _pair(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+@ROI_LAYERS.register_module()
+class RoIAlign(nn.Module):
+    """mmcv.ops.RoIAlign signature: forward(feats [N,C,H,W], rois [K,5]) -> [K,C,oh,ow] (HIP, single map)."""
+
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+                 use_torchvision=False):
+        super().__init__()
+        assert pool_mode == 'avg', 'only average pooling is on the OA-DG path'
+        self.output_size = _pair(output_size)
+        self.spatial_scale, self.sampling_ratio, self.aligned = float(spatial_scale), int(sampling_ratio), aligned
+
+    def forward(self, input, rois):
+        assert rois.dim() == 2 and rois.size(1) == 5
+        return hip_ops.roi_align_fpn([input], rois, self.output_size, [self.spatial_scale],
+                                     sampling_ratio=self.sampling_ratio, aligned=self.aligned)
+
+
+@ROI_EXTRACTORS.register_module()
+class SingleRoIExtractor(nn.Module):
+    """base_roi_extractor.py:9-86 + single_level_roi_extractor.py:9-146."""
+
+    def __init__(self, roi_layer, out_channels, featmap_strides, finest_scale=56, init_cfg=None):
+        super().__init__()
+        cfg = dict(roi_layer)
+        layer_type = cfg.pop('type')
+        layer_cls = ROI_LAYERS.get(layer_type)
+        if layer_cls is None:
+            raise KeyError(f'{layer_type} is not a known RoI layer')
+        self.roi_layers = nn.ModuleList([layer_cls(spatial_scale=1 / s, **cfg) for s in featmap_strides])
+        self.out_channels, self.featmap_strides, self.finest_scale = out_channels, featmap_strides, finest_scale
+
+    @property
+    def num_inputs(self):
+        return len(self.featmap_strides)
+
+    def forward(self, feats, rois, roi_scale_factor=None):
+        assert roi_scale_factor is None, 'roi_scale_factor is not used on the OA-DG path'
+        l0 = self.roi_layers[0]
+        feats = feats[:self.num_inputs]
+        if len(rois) == 0:
+            return feats[0].new_zeros(0, self.out_channels, *l0.output_size)
+        return hip_ops.roi_align_fpn(list(feats), rois, l0.output_size,
+                                     [layer.spatial_scale for layer in self.roi_layers],
+                                     finest_scale=self.finest_scale, sampling_ratio=l0.sampling_ratio,
+                                     aligned=l0.aligned)
+
+
+class BBoxHead(nn.Module):
+    """bbox_head.py (targets + stock loss) - base of the conv-fc heads."""
+
+    def __init__(self, with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7, in_channels=256,
+                 num_classes=80,
+                 bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True, target_means=[0., 0., 0., 0.],
+                                 target_stds=[0.1, 0.1, 0.2, 0.2]),
+                 reg_class_agnostic=False, reg_decoded_bbox=False, reg_predictor_cfg=dict(type='Linear'),
+                 cls_predictor_cfg=dict(type='Linear'),
+                 loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                 loss_bbox=dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0), init_cfg=None):
+        super().__init__()
+        assert with_cls or with_reg
+        assert not with_avg_pool and not reg_decoded_bbox
+        assert reg_predictor_cfg['type'] == 'Linear' and cls_predictor_cfg['type'] == 'Linear'
+        self.with_avg_pool, self.with_cls, self.with_reg = with_avg_pool, with_cls, with_reg
+        self.roi_feat_size = _pair(roi_feat_size)
+        self.roi_feat_area = self.roi_feat_size[0] * self.roi_feat_size[1]
+        self.in_channels, self.num_classes = in_channels, num_classes
+        self.reg_class_agnostic, self.reg_decoded_bbox = reg_class_agnostic, reg_decoded_bbox
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.loss_cls = build_loss(loss_cls)
+        self.loss_bbox = build_loss(loss_bbox)
+        self.custom_activation = False
+
+    def _make_predictors(self, cls_dim, reg_dim):
+        if self.with_cls:
+            self.fc_cls = nn.Linear(cls_dim, self.num_classes + 1)
+        if self.with_reg:
+            self.fc_reg = nn.Linear(reg_dim, 4 if self.reg_class_agnostic else 4 * self.num_classes)
+
+    # -- targets (bbox_head.py:190-257,328-394) -------------------------------------------------------
+    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
+        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
+        n = num_pos + num_neg
+        labels = pos_bboxes.new_full((n,), self.num_classes, dtype=torch.long)
+        label_weights = pos_bboxes.new_zeros(n)
+        bbox_targets = pos_bboxes.new_zeros(n, 4)
+        bbox_weights = pos_bboxes.new_zeros(n, 4)
+        absolute = pos_bboxes.new_zeros(n, 4)
+        if num_pos > 0:
+            labels[:num_pos] = pos_gt_labels
+            label_weights[:num_pos] = 1.0 if cfg.pos_weight <= 0 else cfg.pos_weight
+            bbox_targets[:num_pos, :] = self.bbox_coder.encode(pos_bboxes, pos_gt_bboxes)
+            bbox_weights[:num_pos, :] = 1
+            absolute[:num_pos, :] = pos_gt_bboxes
+        if num_neg > 0:
+            label_weights[-num_neg:] = 1.0
+        return labels, label_weights, bbox_targets, bbox_weights, absolute
+
+    def get_targets_with_absolute(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        out = multi_apply(self._get_target_single, [r.pos_bboxes for r in sampling_results],
+                          [r.neg_bboxes for r in sampling_results],
+                          [r.pos_gt_bboxes for r in sampling_results],
+                          [r.pos_gt_labels for r in sampling_results], cfg=rcnn_train_cfg)
+        return tuple(torch.cat(o, 0) for o in out) if concat else out
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        return self.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg,
+                                              concat)[:4]
+
+    # -- loss ------------------------------------------------------------------------------------------
+    def _cls_reg_losses(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
+                        avg_factor, reduction_override=None):
+        losses = dict()
+        if cls_score is not None and cls_score.numel() > 0:
+            losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
+                                               reduction_override=reduction_override)
+            losses['acc'] = accuracy(cls_score, labels)
+        if bbox_pred is not None:
+            bg = self.num_classes
+            pos = (labels >= 0) & (labels < bg)
+            if pos.any():
+                if self.reg_class_agnostic:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), 4)[pos]
+                else:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pos, labels[pos]]
+                losses['loss_bbox'] = self.loss_bbox(pos_pred, bbox_targets[pos], bbox_weights[pos],
+                                                     avg_factor=bbox_targets.size(0),
+                                                     reduction_override=reduction_override)
+            else:
+                losses['loss_bbox'] = bbox_pred[pos].sum()
+        return losses
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
+             reduction_override=None, **kwargs):
+        """bbox_head.py:397-...: avg_factor = #(label_weights > 0) (one host read, as the reference)."""
+        avg = max(torch.sum(label_weights > 0).float().item(), 1.) if cls_score is not None else None
+        return self._cls_reg_losses(cls_score.float(), bbox_pred.float(), labels, label_weights, bbox_targets,
+                                    bbox_weights, avg, reduction_override)
+
+
+class ConvFCBBoxHead(BBoxHead):
+    """convfc_bbox_head.py restricted to fc branches (num_*_convs == 0 in every named config)."""
+
+    def __init__(self, num_shared_convs=0, num_shared_fcs=0, num_cls_convs=0, num_cls_fcs=0,
+                 num_reg_convs=0, num_reg_fcs=0, conv_out_channels=256, fc_out_channels=1024, conv_cfg=None,
+                 norm_cfg=None, init_cfg=None, *args, **kwargs):
+        super().__init__(*args, init_cfg=init_cfg, **kwargs)
+        assert num_shared_convs == num_cls_convs == num_reg_convs == 0
+        assert num_shared_fcs > 0
+        self.num_shared_fcs, self.num_cls_fcs, self.num_reg_fcs = num_shared_fcs, num_cls_fcs, num_reg_fcs
+        self.fc_out_channels = fc_out_channels
+        last = self.in_channels * self.roi_feat_area
+        self.shared_fcs = nn.ModuleList()
+        for i in range(num_shared_fcs):
+            self.shared_fcs.append(nn.Linear(last if i == 0 else fc_out_channels, fc_out_channels))
+        self.shared_out_channels = fc_out_channels
+        self.cls_fcs, self.reg_fcs = nn.ModuleList(), nn.ModuleList()
+        for i in range(num_cls_fcs):
+            self.cls_fcs.append(nn.Linear(fc_out_channels, fc_out_channels))
+        for i in range(num_reg_fcs):
+            self.reg_fcs.append(nn.Linear(fc_out_channels, fc_out_channels))
+        self.cls_last_dim = self.reg_last_dim = fc_out_channels
+        self.relu = nn.ReLU(inplace=True)
+        self._make_predictors(self.cls_last_dim, self.reg_last_dim)
+
+    def init_weights(self):
+        """bbox_head.py:83-94 + convfc init_cfg: fc_cls N(0,.01), fc_reg N(0,.001), shared/cls/reg fcs Xavier."""
+        if self.with_cls:
+            normal_init(self.fc_cls, std=0.01)
+        if self.with_reg:
+            normal_init(self.fc_reg, std=0.001)
+        for ml in (self.shared_fcs, self.cls_fcs, self.reg_fcs):
+            for m in ml:
+                xavier_init(m, distribution='uniform')
+
+    def _trunk(self, x):
+        x = x.flatten(1)            # (c, ph, pw) order, as the reference's NCHW flatten
+        for fc in self.shared_fcs:
+            x = self.relu(fc(x))
+        x_cls, x_reg = x, x
+        for fc in self.cls_fcs:
+            x_cls = self.relu(fc(x_cls))
+        for fc in self.reg_fcs:
+            x_reg = self.relu(fc(x_reg))
+        return x, x_cls, x_reg
+
+    def forward(self, x):
+        _, x_cls, x_reg = self._trunk(x)
+        return (self.fc_cls(x_cls) if self.with_cls else None,
+                self.fc_reg(x_reg) if self.with_reg else None)
+
+
+@HEADS.register_module()
+class Shared2FCBBoxHead(ConvFCBBoxHead):
+
+    def __init__(self, fc_out_channels=1024, *args, **kwargs):
+        super().__init__(num_shared_fcs=2, fc_out_channels=fc_out_channels, *args, **kwargs)
+        self.init_weights()
+
+
+@HEADS.register_module()
+class Shared2FCContrastiveHead(ConvFCBBoxHead):
+    """contrastive_head.py:14-366: shared 2 FC + cls / reg / contrastive branches."""
+
+    def __init__(self, fc_out_channels=1024, num_cls_convs=0, num_cls_fcs=0, with_cont=True,
+                 cont_predictor_cfg=dict(num_linear=2, feat_channels=256, return_relu=True),
+                 out_dim_cont=1024,
+                 loss_cont=dict(type='ContrastiveLossPlus', version='r-cnn', loss_weight=0.01),
+                 *args, **kwargs):
+        super().__init__(num_shared_fcs=2, num_cls_convs=num_cls_convs, num_cls_fcs=num_cls_fcs,
+                         fc_out_channels=fc_out_channels, *args, **kwargs)
+        self.with_cont, self.out_dim_cont = with_cont, out_dim_cont
+        self.loss_cont = build_loss(loss_cont)
+        self.loss_cont.num_classes = self.num_classes
+        if with_cont:
+            self.fc_cont = self._linear_relu(in_channels=self.cls_last_dim, **cont_predictor_cfg)
+        self.init_weights()
+
+    @staticmethod
+    def _linear_relu(num_linear, in_channels, feat_channels, return_relu=False):
+        """contrastive_head.py:252-263 (note: ``return_relu`` only shifts where the ReLUs stop)."""
+        layers = []
+        num_relu = num_linear if return_relu else num_linear - 1
+        for i in range(num_linear):
+            layers.append(nn.Linear(in_channels if i == 0 else feat_channels, feat_channels))
+            if i < num_relu - 1:
+                layers.append(nn.ReLU(inplace=True))
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x, x_cls, x_reg = self._trunk(x)
+        self.cls_feats = x_cls
+        return (self.fc_cls(x_cls) if self.with_cls else None,
+                self.fc_reg(x_reg) if self.with_reg else None,
+                self.fc_cont(x) if self.with_cont else None)
+
+    def loss(self, cls_score, bbox_pred, cont_feats, rois, labels, label_weights, bbox_targets, bbox_weights,
+             bbox_absolute_targets=None, reduction_override=None, **kwargs):
+        """contrastive_head.py:60-138."""
+        avg = max(torch.sum(label_weights > 0).float().item(), 1.) if cls_score is not None else None
+        losses = self._cls_reg_losses(cls_score.float() if cls_score is not None else None,
+                                      bbox_pred.float() if bbox_pred is not None else None, labels,
+                                      label_weights, bbox_targets, bbox_weights, avg, reduction_override)
+        labels = labels.contiguous().view(-1, 1)
+        if cont_feats is not None and cont_feats.numel() > 0:
+            # The reference adds the key only when #foreground > min_samples (a host-side branch on device
+            # data, :123-129); the kernel applies the same rule on the device and returns 0 otherwise, so
+            # the key is always present and every rank logs the same set of variables.
+            losses['loss_cont'] = self.loss_cont(cont_feats.float(), labels)
+        self.roi_targets = (labels, label_weights, bbox_targets, bbox_weights)
+        return losses
+
+
+class BaseRoIHead(nn.Module):
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__()
+        assert mask_head is None and shared_head is None, 'bbox-only detector'
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_roi_extractor = build_roi_extractor(bbox_roi_extractor)
+        self.bbox_head = build_head(bbox_head)
+        self.bbox_assigner = self.bbox_sampler = None
+        if self.train_cfg:
+            self.bbox_assigner = build_assigner(self.train_cfg.assigner)
+            self.bbox_sampler = build_sampler(self.train_cfg.sampler, context=self)
+
+    with_bbox, with_mask, with_shared_head = True, False, False
+
+
+@HEADS.register_module()
+class StandardRoIHead(BaseRoIHead):
+    """standard_roi_head.py:11-200 (bbox branch)."""
+
+    def _assign_and_sample(self, x, n, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore):
+        out = []
+        for i in range(n):
+            ar = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
+            out.append(self.bbox_sampler.sample(ar, proposal_list[i], gt_bboxes[i], gt_labels[i]))
+        return out
+
+    def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
+                      gt_masks=None, **kwargs):
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None] * num_imgs
+        if 'num_views' not in kwargs:
+            sampling_results = self._assign_and_sample(x, num_imgs, proposal_list, gt_bboxes, gt_labels,
+                                                       gt_bboxes_ignore)
+        else:   # assign/sample on the first view only, replicate the lists (contrastive_roi_head.py:84-97)
+            first = self._assign_and_sample(x, kwargs['batch_size'], proposal_list, gt_bboxes, gt_labels,
+                                            gt_bboxes_ignore)
+            sampling_results = []
+            for _ in range(kwargs['num_views']):
+                sampling_results.extend(first)
+        bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas, **kwargs)
+        return dict(bbox_results['loss_bbox'])
+
+    def _bbox_forward(self, x, rois):
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=feats)
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas, **kwargs):
+        rois = bbox2roi([r.bboxes for r in sampling_results])
+        res = self._bbox_forward(x, rois)
+        targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], rois, *targets))
+        return res
+
+
+@HEADS.register_module()
+class ContrastiveRoIHead(StandardRoIHead):
+    """contrastive_roi_head.py:10-157."""
+
+    def _bbox_forward(self, x, rois):
+        feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred, cont_feats = self.bbox_head(feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, cont_feats=cont_feats, bbox_feats=feats)
+
+    def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
+                            gt_instance_inds=None, **kwargs):
+        rois = bbox2roi([r.bboxes for r in sampling_results])
+        res = self._bbox_forward(x, rois)
+        if 'random_proposal_list' in kwargs:
+            rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
+            res2 = self._bbox_forward(x, rois2)
+            res['cont_feats'] = torch.cat([res['cont_feats'], res2['cont_feats']], dim=0)
+        targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
+                                                           self.train_cfg)
+        self.bbox_targets = targets
+        res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], res['cont_feats'], rois,
+                                                 *targets, **kwargs))
+        return res

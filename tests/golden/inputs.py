@@ -26,3 +26,70 @@ def supcon_inputs(seed, n_fg_per_img=100, n_rand=17, few_fg=False, n_img=2, per_
 
 def checksum(*arrays):
     return np.float64(sum(float(np.asarray(a, dtype=np.float64).sum()) for a in arrays))
+
+
+# ---------------------------------------------------------------------------------------------- model-level
+import zlib  # noqa: E402
+
+
+def named_weights(shapes):
+    """Deterministic weights keyed by parameter NAME (so the reference model and ours, which share mmdet's
+    state_dict layout, get identical values regardless of construction order).  shapes: {name: shape}."""
+    out = {}
+    for name, shape in shapes.items():
+        rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+        shape = tuple(shape)
+        if name.endswith('num_batches_tracked'):
+            v = np.zeros(shape, np.int64)
+        elif name.endswith('running_var'):
+            v = (0.5 + rs.rand(*shape)).astype(np.float32)
+        elif name.endswith('running_mean'):
+            v = (0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif len(shape) == 1 and name.endswith('weight'):       # BN gamma
+            v = (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif name.endswith('bias'):
+            v = (0.01 * rs.standard_normal(shape)).astype(np.float32)
+        else:                                                    # conv / linear weight: He-scaled normal
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            v = (rs.standard_normal(shape) * np.sqrt(2.0 / fan_in) * 0.7).astype(np.float32)
+        out[name] = v
+    return out
+
+
+def lowpass_image(rs, h, w, k=8):
+    """uint8 [h,w,3] box-filtered uniform noise (non-degenerate histograms / saliency)."""
+    x = rs.randint(0, 256, (h + k, w + k, 3)).astype(np.float64)
+    c = np.cumsum(np.cumsum(x, 0), 1)
+    c = np.pad(c, ((1, 0), (1, 0), (0, 0)))
+    s = c[k:k + h, k:k + w] - c[:h, k:k + w] - c[k:k + h, :w] + c[:h, :w]
+    s = s / (k * k)
+    s = (s - s.min()) / (s.max() - s.min() + 1e-9) * 255.0
+    return s.astype(np.uint8)
+
+
+def synthetic_boxes(rs, n, h, w, wmin=24, wmax=400):
+    bw = rs.uniform(wmin, min(wmax, w // 2), n)
+    bh = rs.uniform(wmin, min(wmax, h // 2), n)
+    x1 = rs.uniform(0, w - bw)
+    y1 = rs.uniform(0, h - bh)
+    return np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+
+
+def model_batch(seed, n_img, h, w, n_gt=12, n_cls=8):
+    """A train_step input in the collated format of the OA-DG pipeline: normalised float
+    images for both views, gt lists, OA-Mix box lists."""
+    rs = np.random.RandomState(seed)
+    mean = np.array([123.675, 116.28, 103.53], np.float32)
+    std = np.array([58.395, 57.12, 57.375], np.float32)
+    img, img2, gtb, gtl, mlb, oab = [], [], [], [], [], []
+    for _ in range(n_img):
+        a = lowpass_image(rs, h, w).astype(np.float32)
+        b = np.clip(a * rs.uniform(0.7, 1.2) + rs.uniform(-20, 20) + rs.standard_normal(a.shape) * 6, 0, 255)
+        img.append(((a - mean) / std).transpose(2, 0, 1).astype(np.float32))
+        img2.append(((b.astype(np.float32) - mean) / std).transpose(2, 0, 1).astype(np.float32))
+        gtb.append(synthetic_boxes(rs, n_gt, h, w, 16, min(200, w // 3)))
+        gtl.append(rs.randint(0, n_cls, n_gt).astype(np.int64))
+        mlb.append(np.round(synthetic_boxes(rs, rs.randint(1, 3), h, w, 8, 60)).astype(np.int64))
+        oab.append(np.round(synthetic_boxes(rs, rs.randint(1, 4), h, w, 8, 60)).astype(np.int64))
+    return dict(img=np.stack(img), img2=np.stack(img2), gt_bboxes=gtb, gt_labels=gtl, multilevel_boxes=mlb,
+                oamix_boxes=oab)

@@ -1,0 +1,123 @@
+"""Generate tests/golden/model_*.npz: the REFERENCE detector (every line executed is reference code except
+mmcv.ops.RoIAlign / batched_nms, which are oracle/roi_align.py and oracle/nms.py) run for one train_step on
+seeded inputs with name-seeded weights.  Run here only:  python tests/golden/make_golden_model.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import refload  # noqa: E402
+from inputs import model_batch, named_weights  # noqa: E402
+from oracle import nms as ONMS  # noqa: E402
+from oracle import roi_align as ORA  # noqa: E402
+
+
+class OracleRoIAlign(nn.Module):
+    def __init__(self, output_size, spatial_scale=1.0, sampling_ratio=0, pool_mode='avg', aligned=True,
+                 use_torchvision=False):
+        super().__init__()
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.spatial_scale, self.sampling_ratio, self.aligned = spatial_scale, sampling_ratio, aligned
+        assert pool_mode == 'avg'
+
+    def forward(self, x, rois):
+        return ORA.roi_align(x, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+
+
+def build_reference_detector():
+    refload.install(ops=dict(RoIAlign=OracleRoIAlign, batched_nms=ONMS.batched_nms, nms=ONMS.nms))
+    for m in ['mmdet.core.bbox.assigners.max_iou_assigner', 'mmdet.core.bbox.samplers.random_sampler',
+              'mmdet.core.bbox.coder.delta_xywh_bbox_coder', 'mmdet.core.bbox.iou_calculators.iou2d_calculator',
+              'mmdet.core.anchor.anchor_generator', 'mmdet.models.losses.oadg.cross_entropy_loss_plus',
+              'mmdet.models.losses.oadg.smooth_l1_loss_plus', 'mmdet.models.losses.oadg.contrastive_loss_plus',
+              'mmdet.models.backbones.resnet', 'mmdet.models.necks.fpn', 'mmdet.models.dense_heads.rpn_head',
+              'mmdet.models.roi_heads.roi_extractors.single_level_roi_extractor',
+              'mmdet.models.roi_heads.bbox_heads.contrastive_head',
+              'mmdet.models.roi_heads.contrastive_roi_head', 'mmdet.models.detectors.faster_rcnn']:
+        refload.ref(m)
+    os.environ['OADG_CONFIG_ROOT'] = refload.REF
+    import oadg_amd
+    cfg = oadg_amd.Config.fromfile(
+        os.path.join(refload.REF, 'configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'),
+        import_custom_modules=False)
+    model_cfg = refload.to_cfg(cfg.to_dict()['model'])
+    model_cfg['backbone']['init_cfg'] = None
+    det = refload.ref('mmdet.models.builder', 'build_detector')(model_cfg)
+    return det
+
+
+def load_named(model):
+    sd = model.state_dict()
+    w = named_weights({k: v.shape for k, v in sd.items()})
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()})
+
+
+def to_batch(b):
+    return dict(img=torch.tensor(b['img']), img2=torch.tensor(b['img2']),
+                gt_bboxes=[torch.tensor(x) for x in b['gt_bboxes']],
+                gt_bboxes2=[torch.tensor(x) for x in b['gt_bboxes']],
+                gt_labels=[torch.tensor(x) for x in b['gt_labels']],
+                multilevel_boxes=[torch.tensor(x) for x in b['multilevel_boxes']],
+                oamix_boxes=[torch.tensor(x) for x in b['oamix_boxes']],
+                img_metas=[dict(img_shape=b['img'].shape[2:] + (3,), pad_shape=b['img'].shape[2:] + (3,),
+                                ori_shape=b['img'].shape[2:] + (3,), scale_factor=1.0, flip=False)
+                           for _ in range(b['img'].shape[0])])
+
+
+def grad_report(model):
+    rep = {}
+    groups = {}
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        top = '.'.join(n.split('.')[:2])
+        groups.setdefault(top, 0.0)
+        groups[top] += float(p.grad.double().pow(2).sum())
+    for k, v in groups.items():
+        rep['gn_' + k] = np.float64(np.sqrt(v))
+    for n in ['roi_head.bbox_head.fc_cls.weight', 'roi_head.bbox_head.fc_cont.2.weight',
+              'rpn_head.rpn_cls.weight', 'neck.fpn_convs.0.conv.bias', 'backbone.layer4.2.conv3.weight']:
+        p = dict(model.named_parameters())[n]
+        rep['g_' + n] = p.grad.detach().flatten()[:4096].numpy().copy()
+    return rep
+
+
+def main(h=256, w=512, n_img=2, seed=0):
+    det = build_reference_detector()
+    load_named(det)
+    det.train()
+    integrate = refload.ref('mmdet.models.detectors.base', 'integrate_data')
+    batch = model_batch(seed, n_img, h, w)
+    data = to_batch(batch)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    t0 = time.time()
+    data = integrate(data, det.train_cfg)
+    losses = det(**data)
+    loss, log_vars = det._parse_losses(losses)
+    loss.backward()
+    print('reference step', time.time() - t0, 's', log_vars)
+    out = dict(h=np.int64(h), w=np.int64(w), n_img=np.int64(n_img), seed=np.int64(seed))
+    for k, v in log_vars.items():
+        out['lv_' + k] = np.float64(v)
+    out.update(grad_report(det))
+    # intermediate pins: sampled RoIs and labels (indices exact), random proposals
+    tg = det.roi_head.bbox_targets
+    out['roi_labels'] = tg[0].numpy().copy()
+    out['roi_bbox_targets_sum'] = np.float64(tg[2].double().sum())
+    out['n_params'] = np.int64(sum(p.numel() for p in det.parameters()))
+    out['n_trainable'] = np.int64(sum(p.numel() for p in det.parameters() if p.requires_grad))
+    np.savez_compressed(os.path.join(HERE, f'model_step_{h}x{w}.npz'), **out)
+    print('wrote', f'model_step_{h}x{w}.npz', {k: v for k, v in out.items() if k.startswith('lv_') or k.startswith('n_')})
+
+
+if __name__ == '__main__':
+    main()

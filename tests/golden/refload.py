@@ -305,6 +305,10 @@ class _LazyPkg(types.ModuleType):
             raise AttributeError(name)
         full = self.__name__ + '.' + name
         d = self.__path__[0]
+        if (self.__name__, name) in _OVERRIDES:
+            val = getattr(importlib.import_module(_OVERRIDES[(self.__name__, name)]), name)
+            self.__dict__[name] = val
+            return val
         if os.path.isdir(os.path.join(d, name)) or os.path.isfile(os.path.join(d, name + '.py')):
             return importlib.import_module(full)
         owner = _OVERRIDES.get((self.__name__, name)) or self._index().get(name)
@@ -344,6 +348,7 @@ class _LazyPkg(types.ModuleType):
 
 # names defined in more than one reference file: which one the real package exports
 _OVERRIDES = {
+    ('mmdet.models.losses', 'accuracy'): 'mmdet.models.losses.accuracy',
     ('mmdet.core', 'bbox_overlaps'): 'mmdet.core.bbox.iou_calculators.iou2d_calculator',
     ('mmdet.core.bbox', 'bbox_overlaps'): 'mmdet.core.bbox.iou_calculators.iou2d_calculator',
     ('mmdet.models.losses', 'cross_entropy'): 'mmdet.models.losses.oadg.cross_entropy_loss_plus',
@@ -391,8 +396,12 @@ def install(cv2_module=None, ops=None):
     sys.modules['cv2'] = cv2_module if cv2_module is not None else types.ModuleType('cv2')
     install_mmdet_shells()
     # heavy/irrelevant leaves imported at module import time by files on the path
-    vis = _mod('mmdet.utils.visualize')
-    vis.__getattr__ = lambda n: (lambda *a, **k: None)
+    class _NoOps(types.ModuleType):
+        def __getattr__(self, n):
+            if n.startswith('__'):
+                raise AttributeError(n)
+            return lambda *a, **k: None
+    sys.modules['mmdet.utils.visualize'] = _NoOps('mmdet.utils.visualize')
     _mod('mmdet.core.visualization', imshow_det_bboxes=None, __path__=[])
     _mod('mmdet.core.mask.structures', BitmapMasks=type('BitmapMasks', (), {}),
          PolygonMasks=type('PolygonMasks', (), {}))

@@ -1,0 +1,112 @@
+"""Whole-detector parity against tests/golden/model_step_256x512.npz, which was produced by running the
+REFERENCE FasterRCNN+ContrastiveRoIHead train step (tests/golden/make_golden_model.py).
+
+* CPU (not gpu): our host logic (anchors, assign, sample, targets, random proposals, list plumbing, module
+  layout / state_dict names) with the four HIP entry points swapped for the oracle -> must reproduce the
+  reference's losses, sampled labels and gradient norms essentially exactly.
+* GPU: the product path (HIP losses / RoIAlign / NMS, torch fp32 convs) on the same inputs.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import model_batch, named_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
+
+
+def build_and_load(device='cpu'):
+    from oadg_amd import Config, build_detector
+    det = build_detector(Config.fromfile(CFG).model)
+    w = named_weights({k: v.shape for k, v in det.state_dict().items()})
+    det.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()})
+    return det.to(device).train()
+
+
+def make_data(g, device='cpu'):
+    b = model_batch(int(g['seed']), int(g['n_img']), int(g['h']), int(g['w']))
+    shape = b['img'].shape[2:] + (3,)
+    t = lambda x: torch.tensor(x, device=device)  # noqa: E731
+    return dict(img=t(b['img']), img2=t(b['img2']), gt_bboxes=[t(x) for x in b['gt_bboxes']],
+                gt_bboxes2=[t(x) for x in b['gt_bboxes']], gt_labels=[t(x) for x in b['gt_labels']],
+                multilevel_boxes=[torch.tensor(x) for x in b['multilevel_boxes']],
+                oamix_boxes=[torch.tensor(x) for x in b['oamix_boxes']],
+                img_metas=[dict(img_shape=shape, pad_shape=shape, ori_shape=shape, scale_factor=1.0, flip=False)
+                           for _ in range(b['img'].shape[0])])
+
+
+def grad_groups(det):
+    groups = {}
+    for n, p in det.named_parameters():
+        if p.grad is not None:
+            top = '.'.join(n.split('.')[:2])
+            groups[top] = groups.get(top, 0.0) + float(p.grad.double().pow(2).sum())
+    return {k: np.sqrt(v) for k, v in groups.items()}
+
+
+def test_state_dict_layout_and_param_counts(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
+    det = build_and_load()
+    assert sum(p.numel() for p in det.parameters()) == int(g['n_params'])
+    assert sum(p.numel() for p in det.parameters() if p.requires_grad) == int(g['n_trainable']) == 41486904
+    keys = set(det.state_dict())
+    for k in ['backbone.layer2.0.conv1.weight', 'backbone.layer1.0.downsample.1.running_var',
+              'neck.lateral_convs.0.conv.weight', 'neck.fpn_convs.3.conv.bias', 'rpn_head.rpn_conv.weight',
+              'rpn_head.rpn_cls.bias', 'roi_head.bbox_head.shared_fcs.0.weight',
+              'roi_head.bbox_head.fc_cont.0.weight', 'roi_head.bbox_head.fc_cont.2.bias',
+              'roi_head.bbox_head.fc_cls.weight', 'roi_head.bbox_head.fc_reg.bias']:
+        assert k in keys, k
+
+
+def test_host_logic_reproduces_reference_step(golden_dir):
+    from oracle_backend import oracle_ops
+    g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
+    det = build_and_load()
+    data = make_data(g)
+    torch.manual_seed(int(g['seed']))
+    np.random.seed(int(g['seed']))
+    with oracle_ops():
+        out = det.train_step(data, None)
+        out['loss'].backward()
+    for k, v in out['log_vars'].items():
+        ref = float(g['lv_' + k])
+        assert abs(v - ref) <= 1e-6 * abs(ref), (k, v, ref)
+    assert np.array_equal(det.roi_head.bbox_targets[0].numpy(), g['roi_labels'])
+    for k, v in grad_groups(det).items():
+        ref = float(g['gn_' + k])
+        assert abs(v - ref) <= 1e-5 * ref, (k, v, ref)
+    params = dict(det.named_parameters())
+    for k in g.files:
+        if k.startswith('g_'):
+            mine = params[k[2:]].grad.flatten()[:4096].numpy()
+            assert np.abs(mine - g[k]).max() <= 1e-5 * np.abs(g[k]).max() + 1e-9, k
+
+
+@pytest.mark.gpu
+def test_product_step_matches_reference_on_gpu(dev, golden_dir):
+    """fp32 on the MI355X.  Convolutions come from a different library (MIOpen vs the CPU's oneDNN), and the
+    step contains discrete decisions (top-k, NMS, IoU thresholds, sampling), so agreement is asserted at
+    5e-3 for the loss terms and 2e-2 for the gradient norms rather than at 1e-4; the 1e-4 bar is held by
+    the per-kernel tests, which feed identical inputs to both sides."""
+    g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
+    torch.backends.cudnn.allow_tf32 = False
+    det = build_and_load(dev)
+    data = make_data(g, dev)
+    torch.manual_seed(int(g['seed']))
+    np.random.seed(int(g['seed']))
+    out = det.train_step(data, None)
+    out['loss'].backward()
+    torch.cuda.synchronize()
+    print({k: (v, float(g['lv_' + k])) for k, v in out['log_vars'].items()})
+    for k, v in out['log_vars'].items():
+        ref = float(g['lv_' + k])
+        tol = 5e-3 if k != 'acc' else 2e-2
+        assert abs(v - ref) <= tol * abs(ref), (k, v, ref)
+    same = (det.roi_head.bbox_targets[0].cpu().numpy() == g['roi_labels']).mean()
+    assert same >= 0.99, same
+    for k, v in grad_groups(det).items():
+        ref = float(g['gn_' + k])
+        assert abs(v - ref) <= 2e-2 * ref, (k, v, ref)
