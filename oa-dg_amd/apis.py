@@ -1,0 +1,143 @@
+"""Training wiring (mmdet/apis/train.py:19-212, tools/train.py:92-207): seeds, optimizer, LR schedule,
+data-parallel wrap, iteration loop.  One process per GPU; gradients are all-reduced by torch DDP over RCCL
+(``backend='nccl'`` is RCCL on ROCm) in buckets that overlap the backward pass."""
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .detectors import integrate_data
+
+
+def get_dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_dist(launcher='pytorch', backend='nccl', **kwargs):
+    """tools/train.py:119-132 / mmcv init_dist('pytorch'): env:// rendezvous, one GPU per process."""
+    if launcher not in ('pytorch',):
+        raise NotImplementedError(f'launcher {launcher}')
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if torch.cuda.is_available() and backend == 'nccl':
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group(backend=backend, **kwargs)
+
+
+def init_random_seed(seed=None, device='cuda'):
+    """apis/train.py:19-49: rank 0's seed is broadcast so every rank shares it."""
+    if seed is not None:
+        return seed
+    rank, world = get_dist_info()
+    seed = np.random.randint(2 ** 31)
+    if world == 1:
+        return seed
+    t = torch.tensor(seed if rank == 0 else 0, dtype=torch.int32, device=device)
+    dist.broadcast(t, src=0)
+    return t.item()
+
+
+def set_random_seed(seed, deterministic=False):
+    """apis/train.py:52-68."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    if deterministic:
+        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.benchmark = False
+
+
+def build_optimizer(model, cfg):
+    cfg = dict(cfg)
+    t = cfg.pop('type')
+    cfg.pop('paramwise_cfg', None)
+    params = [p for p in model.parameters() if p.requires_grad]
+    if t != 'SGD':
+        raise NotImplementedError(f'optimizer {t} (the named configs use SGD)')
+    return torch.optim.SGD(params, **cfg)
+
+
+class StepLrSchedule:
+    """mmcv StepLrUpdaterHook + linear warmup (…_cityscapes.py: step=[1], warmup 500 it, ratio 1e-3)."""
+
+    def __init__(self, optimizer, policy='step', step=(8, 11), gamma=0.1, warmup=None, warmup_iters=0,
+                 warmup_ratio=0.1, by_epoch=True, **kwargs):
+        assert policy == 'step'
+        self.opt, self.steps, self.gamma = optimizer, [step] if isinstance(step, int) else list(step), gamma
+        self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
+        self.base = [g['lr'] for g in optimizer.param_groups]
+
+    def set(self, epoch, it):
+        exp = sum(1 for s in self.steps if epoch >= s)
+        for g, b in zip(self.opt.param_groups, self.base):
+            lr = b * self.gamma ** exp
+            if self.warmup == 'linear' and it < self.warmup_iters:
+                k = (1 - it / self.warmup_iters) * (1 - self.warmup_ratio)
+                lr = lr * (1 - k)
+            g['lr'] = lr
+
+
+class TrainEngine:
+    """model.train_step + backward + optimizer step for one process/GPU (the runner's hot loop,
+    SURVEY.md 3.1): OptimizerHook semantics = zero_grad, loss.backward(), (no grad clip), step."""
+
+    def __init__(self, model, optimizer, distributed=False, amp_dtype=None, bucket_cap_mb=50,
+                 find_unused_parameters=False):
+        self.module = model
+        self.optimizer = optimizer
+        self.amp_dtype = amp_dtype
+        self.ddp = None
+        if distributed:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            dev = next(model.parameters()).device
+            self.ddp = DDP(model, device_ids=[dev.index] if dev.type == 'cuda' else None,
+                           broadcast_buffers=False, find_unused_parameters=find_unused_parameters,
+                           bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+    def forward_losses(self, data):
+        data = integrate_data(data, self.module.train_cfg)
+        fwd = self.ddp if self.ddp is not None else self.module
+        if self.amp_dtype is not None:
+            with torch.autocast('cuda', dtype=self.amp_dtype):
+                losses = fwd(**data)
+        else:
+            losses = fwd(**data)
+        return self.module._parse_losses(losses), len(data['img_metas'])
+
+    def step(self, data):
+        self.optimizer.zero_grad(set_to_none=True)
+        (loss, log_vars), n = self.forward_losses(data)
+        loss.backward()
+        self.optimizer.step()
+        return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
+
+
+def train_detector(model, data_iter, cfg, distributed=False, max_iters=None, logger=print, amp_dtype=None):
+    """apis/train.py:71-212 reduced to the hot loop: build optimizer + schedule, iterate, log every
+    cfg.log_config.interval iterations."""
+    optimizer = build_optimizer(model, cfg.optimizer)
+    sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
+    engine = TrainEngine(model, optimizer, distributed, amp_dtype,
+                         find_unused_parameters=cfg.get('find_unused_parameters', False))
+    interval = cfg.get('log_config', {}).get('interval', 50)
+    rank, _ = get_dist_info()
+    t0 = time.time()
+    for it, data in enumerate(data_iter):
+        if max_iters is not None and it >= max_iters:
+            break
+        sched.set(0, it)
+        out = engine.step(data)
+        if rank == 0 and (it + 1) % interval == 0:
+            lv = {k: (float(v) if not isinstance(v, float) else v) for k, v in out['log_vars'].items()}
+            logger(f'iter {it + 1} lr {optimizer.param_groups[0]["lr"]:.5f} '
+                   f'{(time.time() - t0) / (it + 1):.3f}s/it ' + ' '.join(f'{k}: {v:.4f}' for k, v in lv.items()))
+    return engine
