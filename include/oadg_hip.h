@@ -88,6 +88,67 @@ int oadg_nms_batched(const float* boxes, const int* counts, int n_images, int Mm
                      int max_keep, void* workspace, size_t workspace_bytes, int* keep, int* keep_cnt,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * OA-Mix (object-aware augmentation) device ops.  The host class `OAMix` (oa-dg_amd/pipelines/oa_mix.py,
+ * registered under the reference's PIPELINES name) replays the reference's np.random stream and enqueues these.
+ * Images are uint8 [H, W, 3] (the reference's BGR bytes); masks are never H x W x 3 floats: a blurred box mask
+ * is the outer product My[y] * Mx[x] of two float32 profiles.
+ *   _box_profiles  replaces OAMix._get_mask                 mmdet/datasets/pipelines/oa_mix.py:74-93
+ *                  qbox [n,4] = box // spatial_ratio as int32 (x1,y1,x2,y2); sigma [n,2] = (sx, sy), <= 0: no blur
+ *   _fg_union      max over the fg masks + its uint8(x*255) image   bbox_augmentation.py:257-264
+ *   _saliency      replaces cv2.saliency.StaticSaliencySpectralResidual + mean   oa_mix.py:104-111
+ *                  boxes [n,4] int32 crop corners; score -1 when a side < min_side
+ *   _hist/_luts    per-channel histogram; luts[0] = PIL.ImageOps.autocontrast, luts[1] = .equalize   augmix.py:64-69
+ *   _bbox_step     one gt box of a bboxes_only_* op: warp the whole image (minv_host = inverted 2x3, row-major),
+ *                  blend it in through the box's blurred mask inside rect (rx0,ry0,rw,rh)   bbox_augmentation.py:31-71
+ *   _compose       one depth step of the multi-level chain: up to 2 disjoint random boxes + the outside, each with
+ *                  its own op; optionally acc (=|+=) acc_w * float(dst)   oa_mix.py:221-236
+ *   _final         object_aware_mixing + clip + uint8 + (Normalize, Pad) -> out_u8 and/or NHWC out_norm
+ *                  (out_dtype 0 fp32 / 1 bf16, padded to Hp x Wp with zeros)   oa_mix.py:281-309, transforms.py:618-629,699-701
+ *   _normalize     Normalize + Pad of an un-augmented view
+ */
+enum {
+    OADG_OP_COPY = 0,
+    OADG_OP_LUT_AUTOCONTRAST = 1,
+    OADG_OP_LUT_EQUALIZE = 2,
+    OADG_OP_POSTERIZE = 3,   /* param = bit mask */
+    OADG_OP_SOLARIZE = 4,    /* param = threshold */
+    OADG_OP_IMAGE = 5,       /* image = uint8 [H,W,3] holding the op's full result (bboxes_only_* ops) */
+    OADG_OP_BG_WARP = 6,     /* bg_only_* : minv = inverted affine */
+    OADG_OP_WARP_NEG = 7     /* 'invert' of augmix.all: -warpAffine (uint8 wrap) */
+};
+typedef struct {
+    int kind;
+    int param;
+    const void* image;
+    double minv[6];
+} oadg_region_op;
+typedef struct {
+    int fg_index;   /* >= 0: blurred fg mask number; -1: sharp rectangle */
+    int rect[4];    /* x1,y1,x2,y2 (exclusive) when fg_index < 0 */
+    float m_oa;
+} oadg_mix_target;
+
+int oadg_oamix_box_profiles(const int* qbox, const double* sigma, int n, int H, int W, int ratio, float* My,
+                            float* Mx, void* stream);
+int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, float* union_f,
+                        uint8_t* union_u8, void* stream);
+int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
+                        double* scores, void* stream);
+int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream);
+int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream);
+int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, int rx0, int ry0, int rw, int rh,
+                         const float* My_row, const float* Mx_row, uint8_t* scratch, void* stream);
+int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
+                       const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,
+                       const uint8_t* union_u8, float* acc, float acc_w, int acc_mode, void* stream);
+int oadg_oamix_final(const uint8_t* img, const float* acc, int H, int W, const oadg_mix_target* targets,
+                     int n_targets, const float* My, const float* Mx, double m_beta, const float* mean_host,
+                     const float* stdinv_host, int to_rgb, uint8_t* out_u8, void* out_norm, int out_dtype,
+                     int Hp, int Wp, void* stream);
+int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_host, const float* stdinv_host,
+                         int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

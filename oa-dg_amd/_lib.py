@@ -5,13 +5,21 @@ library and raises on any non-zero return code.  A missing library is a hard err
 """
 import ctypes
 import os
-from ctypes import (POINTER, c_char_p, c_float, c_int, c_int64, c_long, c_size_t, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'liboadg_hip.so')
 _lib = None
 
-vp, ci, cf, cl, cs = c_void_p, c_int, c_float, c_long, c_size_t
+vp, ci, cf, cl, cs, cd = c_void_p, c_int, c_float, c_long, c_size_t, c_double
+
+
+class RegionOp(Structure):
+    """oadg_region_op (include/oadg_hip.h)"""
+    _fields_ = [('kind', c_int), ('param', c_int), ('image', c_void_p), ('minv', c_double * 6)]
+
+
+OP_COPY, OP_LUT_AUTOCONTRAST, OP_LUT_EQUALIZE, OP_POSTERIZE, OP_SOLARIZE, OP_IMAGE, OP_BG_WARP, OP_WARP_NEG = range(8)
 
 # name -> (restype, argtypes); must list every symbol include/oadg_hip.h declares
 SIGNATURES = {
@@ -28,6 +36,16 @@ SIGNATURES = {
                                 vp, ci, ci, ci, ci, ci, vp, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
+    'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
+    'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp]),
+    'oadg_oamix_hist': (ci, [vp, cl, vp, vp]),
+    'oadg_oamix_luts': (ci, [vp, vp, vp]),
+    'oadg_oamix_bbox_step': (ci, [vp, ci, ci, POINTER(cd), ci, ci, ci, ci, vp, vp, vp, vp]),
+    'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
+    'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
+                              ci, vp]),
+    'oadg_oamix_normalize': (ci, [vp, ci, ci, POINTER(cf), POINTER(cf), ci, vp, ci, ci, ci, vp]),
 }
 
 
@@ -59,6 +77,7 @@ def check(rc, what):
 
 
 def ptr(t):
+    """device pointer of a tensor (or of anything exposing data_ptr()); None -> NULL"""
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 

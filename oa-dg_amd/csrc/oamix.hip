@@ -1,0 +1,778 @@
+// OA-Mix on the device: box-mask profiles, spectral-residual saliency, histogram LUT colour ops, fixed-point
+// affine warps blended through analytic blurred masks, region-wise multi-level composition, object-aware
+// mixing fused with normalisation.  gfx950 only.
+//
+// Replaces, behind the C ABI in include/oadg_hip.h (the Python class `OAMix` of oa-dg_amd/pipelines/oa_mix.py
+// replays the reference's RNG stream on the host and enqueues these kernels):
+//   mmdet/datasets/pipelines/oa_mix.py:74-93     _get_mask               -> oadg_oamix_box_profiles
+//   mmdet/datasets/pipelines/oa_mix.py:95-120    get_fg_regions          -> oadg_oamix_saliency (+ profiles)
+//   mmdet/datasets/pipelines/augmix.py:64-78,103 autocontrast/equalize/posterize/solarize (Pillow)
+//                                                                       -> oadg_oamix_hist/_luts/_compose
+//   mmdet/datasets/pipelines/augmix.py:83-188    rotate/shear/translate (cv2.warpAffine)
+//   mmdet/datasets/pipelines/bbox_augmentation.py:31-88    bbox-only ops -> oadg_oamix_bbox_step
+//   mmdet/datasets/pipelines/bbox_augmentation.py:240-272  bg-only ops   -> oadg_oamix_compose (kind BG_WARP)
+//   mmdet/datasets/pipelines/oa_mix.py:221-236   multi-level chain       -> oadg_oamix_compose
+//   mmdet/datasets/pipelines/oa_mix.py:281-309   object_aware_mixing     -> oadg_oamix_final
+//   mmdet/datasets/pipelines/transforms.py:618-629,699-701 Pad/Normalize -> oadg_oamix_final/_normalize
+//
+// Every byte-producing kernel performs the oracle's arithmetic operation for operation (float32 / float64
+// IEEE ops without contraction, OpenCV's 10+5-bit fixed-point coordinates and 15-bit integer bilinear
+// weights), so outputs are compared bit-for-bit.  All kernels are HBM-streaming or box-local; masks are
+// never materialised as H x W x 3 float images (25 MB each in the reference): a blurred box mask is the
+// outer product My[y] * Mx[x] of two 1-D profiles.
+#include "common.h"
+#include "oadg_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ double exp_det(double x) {
+    // oracle/cvleaves.py exp_det: same constants, same order, +,-,* only
+    const double LOG2E = 1.4426950408889634;
+    const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double k = rint(x * LOG2E);
+    const double r = (x - k * LN2_HI) - k * LN2_LO;
+    double f[14];
+    f[0] = 1.0;
+#pragma unroll
+    for (int n = 1; n < 14; ++n) f[n] = f[n - 1] / (double)n;
+    double p = f[13];
+#pragma unroll
+    for (int n = 12; n >= 0; --n) p = p * r + f[n];
+    return ldexp(p, (int)k);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i >= n ? p - i : i;
+}
+
+__device__ __forceinline__ long sat_int(double v) {
+    v = rint(v);
+    v = fmin(fmax(v, -2147483648.0), 2147483647.0);
+    return (long)v;
+}
+
+struct Warp {
+    double m[6];
+};
+
+// OpenCV WarpAffineInvoker coordinates in 1/32 px for destination pixel (x, y)
+__device__ __forceinline__ void warp_xy(const Warp& w, int x, int y, long& X, long& Y) {
+    const long adelta = sat_int(w.m[0] * (double)x * 1024.0);
+    const long bdelta = sat_int(w.m[3] * (double)x * 1024.0);
+    const long X0 = sat_int((w.m[1] * (double)y + w.m[2]) * 1024.0) + 16;
+    const long Y0 = sat_int((w.m[4] * (double)y + w.m[5]) * 1024.0) + 16;
+    X = (X0 + adelta) >> 5;
+    Y = (Y0 + bdelta) >> 5;
+}
+
+struct Tap {
+    int o00, o01, o10, o11;   // pixel offsets (y*W + x), -1 = outside (reads as 0)
+    int w00, w01, w10, w11;   // 15-bit integer weights
+};
+
+__device__ __forceinline__ Tap make_tap(long X, long Y, int H, int W) {
+    long sx = X >> 5, sy = Y >> 5;
+    sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+    sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+    const int fx = (int)(X & 31), fy = (int)(Y & 31);
+    Tap t;
+    t.w00 = (32 - fx) * (32 - fy) * 32;
+    t.w01 = fx * (32 - fy) * 32;
+    t.w10 = (32 - fx) * fy * 32;
+    t.w11 = fx * fy * 32;
+    const bool x0 = sx >= 0 && sx < W, x1 = sx + 1 >= 0 && sx + 1 < W;
+    const bool y0 = sy >= 0 && sy < H, y1 = sy + 1 >= 0 && sy + 1 < H;
+    t.o00 = (y0 && x0) ? (int)(sy * W + sx) : -1;
+    t.o01 = (y0 && x1) ? (int)(sy * W + sx + 1) : -1;
+    t.o10 = (y1 && x0) ? (int)((sy + 1) * W + sx) : -1;
+    t.o11 = (y1 && x1) ? (int)((sy + 1) * W + sx + 1) : -1;
+    return t;
+}
+
+__device__ __forceinline__ int tap_fetch(const Tap& t, const uint8_t* img, int stride, int c) {
+    const int v00 = t.o00 >= 0 ? img[(size_t)t.o00 * stride + c] : 0;
+    const int v01 = t.o01 >= 0 ? img[(size_t)t.o01 * stride + c] : 0;
+    const int v10 = t.o10 >= 0 ? img[(size_t)t.o10 * stride + c] : 0;
+    const int v11 = t.o11 >= 0 ? img[(size_t)t.o11 * stride + c] : 0;
+    int r = (v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11 + (1 << 14)) >> 15;
+    return r < 0 ? 0 : (r > 255 ? 255 : r);
+}
+
+// ------------------------------------------------------------------------------------------------ profiles
+constexpr int PROF_MAXQ = 2048;   // quarter-resolution length
+constexpr int PROF_MAXK = 4096;   // Gaussian taps
+
+// grid (n_boxes, 2): axis 0 -> My (length H), axis 1 -> Mx (length W)
+__global__ __launch_bounds__(256) void box_profiles_kernel(const int* __restrict__ qbox,
+                                                          const double* __restrict__ sigma, int H, int W,
+                                                          int ratio, float* __restrict__ My,
+                                                          float* __restrict__ Mx) {
+    __shared__ float a[PROF_MAXQ];
+    __shared__ float bl[PROF_MAXQ];
+    __shared__ float kf[PROF_MAXK];
+    __shared__ double s_inv;
+    const int b = blockIdx.x, axis = blockIdx.y, tid = threadIdx.x;
+    const int L = axis == 0 ? H : W;
+    const int Lq = L / ratio;
+    const int lo = axis == 0 ? qbox[4 * b + 1] : qbox[4 * b + 0];
+    const int hi = axis == 0 ? qbox[4 * b + 3] : qbox[4 * b + 2];
+    const double sg = axis == 0 ? sigma[2 * b + 1] : sigma[2 * b + 0];
+    for (int i = tid; i < Lq; i += 256) a[i] = (i >= lo && i < hi) ? 1.0f : 0.0f;
+    __syncthreads();
+    if (sg > 0.0) {
+        const int n = ((int)rint(sg * 4.0 * 2.0 + 1.0)) | 1;
+        const int r = (n - 1) / 2;
+        const double scale2x = -0.5 / (sg * sg);
+        for (int i = tid; i < n; i += 256) {
+            const double x = (double)i - (double)(n - 1) * 0.5;
+            kf[i] = (float)exp_det(scale2x * x * x);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += (double)kf[i];
+            s_inv = 1.0 / s;
+        }
+        __syncthreads();
+        const double inv = s_inv;
+        for (int i = tid; i < n; i += 256) kf[i] = (float)((double)kf[i] * inv);
+        __syncthreads();
+        for (int i = tid; i < Lq; i += 256) {
+            float acc = kf[r] * a[i];
+            for (int j = 1; j <= r; ++j) {
+                const float pair = a[reflect101(i + j, Lq)] + a[reflect101(i - j, Lq)];
+                acc = acc + kf[r + j] * pair;
+            }
+            bl[i] = acc;
+        }
+    } else {
+        for (int i = tid; i < Lq; i += 256) bl[i] = a[i];
+    }
+    __syncthreads();
+    float* out = axis == 0 ? My + (size_t)b * H : Mx + (size_t)b * W;
+    const double scale = 1.0 / ((double)L / (double)Lq);
+    for (int d = tid; d < L; d += 256) {
+        double f = ((double)d + 0.5) * scale - 0.5;
+        long s = (long)floor(f);
+        float ff = (float)(f - (double)s);
+        if (s < 0) { ff = 0.f; s = 0; }
+        if (s >= Lq - 1) { ff = 0.f; s = Lq - 1; }
+        const long s1 = s + 1 < Lq ? s + 1 : Lq - 1;
+        const float a0 = 1.0f - ff;
+        out[d] = bl[s] * a0 + bl[s1] * ff;
+    }
+}
+
+__global__ void fg_union_kernel(const float* __restrict__ My, const float* __restrict__ Mx, int n, int H,
+                                int W, float* __restrict__ uf, uint8_t* __restrict__ u8) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)H * W) return;
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    float m = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float v = My[(size_t)i * H + y] * Mx[(size_t)i * W + x];
+        m = i == 0 ? v : fmaxf(m, v);
+    }
+    uf[p] = m;
+    u8[p] = (uint8_t)(m * 255.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ histogram / LUTs
+__global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ img, long npix,
+                                                   int* __restrict__ hist) {
+    __shared__ int h[768];
+    for (int i = threadIdx.x; i < 768; i += 256) h[i] = 0;
+    __syncthreads();
+    const long ngroups = npix / 4;   // 4 pixels = 12 bytes = 3 aligned dwords
+    const unsigned* w = reinterpret_cast<const unsigned*>(img);
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (long)gridDim.x * 256) {
+        const unsigned a = w[3 * g], b = w[3 * g + 1], c = w[3 * g + 2];
+        atomicAdd(&h[0 * 256 + (a & 255)], 1);         atomicAdd(&h[1 * 256 + ((a >> 8) & 255)], 1);
+        atomicAdd(&h[2 * 256 + ((a >> 16) & 255)], 1); atomicAdd(&h[0 * 256 + (a >> 24)], 1);
+        atomicAdd(&h[1 * 256 + (b & 255)], 1);         atomicAdd(&h[2 * 256 + ((b >> 8) & 255)], 1);
+        atomicAdd(&h[0 * 256 + ((b >> 16) & 255)], 1); atomicAdd(&h[1 * 256 + (b >> 24)], 1);
+        atomicAdd(&h[2 * 256 + (c & 255)], 1);         atomicAdd(&h[0 * 256 + ((c >> 8) & 255)], 1);
+        atomicAdd(&h[1 * 256 + ((c >> 16) & 255)], 1); atomicAdd(&h[2 * 256 + (c >> 24)], 1);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {   // tail pixels
+        for (long p = ngroups * 4; p < npix; ++p) atomicAdd(&h[threadIdx.x * 256 + img[p * 3 + threadIdx.x]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 768; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// one block, thread = intensity; luts[0] = ImageOps.autocontrast, luts[1] = ImageOps.equalize
+__global__ __launch_bounds__(256) void luts_kernel(const int* __restrict__ hist, uint8_t* __restrict__ luts) {
+    __shared__ int h[256];
+    __shared__ long pre[256];
+    __shared__ int s_lo, s_hi, s_nz, s_last;
+    const int ix = threadIdx.x;
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+        h[ix] = hist[c * 256 + ix];
+        __syncthreads();
+        if (ix == 0) {
+            int lo = 0, hi = 255, nz = 0, last = 0;
+            for (lo = 0; lo < 256; ++lo) if (h[lo]) break;
+            for (hi = 255; hi >= 0; --hi) if (h[hi]) break;
+            long run = 0;
+            for (int i = 0; i < 256; ++i) { pre[i] = run; run += h[i]; if (h[i]) { ++nz; last = h[i]; } }
+            if (lo > 255) lo = 255;      // empty image: Python's loop leaves lo = 255, hi = 0
+            if (hi < 0) hi = 0;
+            s_lo = lo; s_hi = hi; s_nz = nz; s_last = last;
+        }
+        __syncthreads();
+        int ac = ix;
+        if (s_hi > s_lo) {
+            const double scale = 255.0 / (double)(s_hi - s_lo);
+            const double offset = -(double)s_lo * scale;
+            const double v = (double)ix * scale + offset;
+            int q = (int)v;   // Python int(): truncation toward zero
+            ac = q < 0 ? 0 : (q > 255 ? 255 : q);
+        }
+        luts[(0 * 3 + c) * 256 + ix] = (uint8_t)ac;
+        int eq = ix;
+        if (s_nz > 1) {
+            const long total = pre[255] + h[255];
+            const long step = (total - s_last) / 255;
+            if (step) {
+                const long q = (step / 2 + pre[ix]) / step;
+                eq = q > 255 ? 255 : (int)q;
+            }
+        }
+        luts[(1 * 3 + c) * 256 + ix] = (uint8_t)eq;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bbox-only step
+// phase 1: blended rect -> scratch ; phase 2: scratch -> image.  rect = support of the blurred mask.
+__global__ void bbox_blend_kernel(const uint8_t* __restrict__ img, int H, int W, Warp wp, int rx0, int ry0,
+                                  int rw, int rh, const float* __restrict__ My, const float* __restrict__ Mx,
+                                  uint8_t* __restrict__ scratch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rw * rh) return;
+    const int yy = i / rw, xx = i - yy * rw;
+    const int x = rx0 + xx, y = ry0 + yy;
+    long X, Y;
+    warp_xy(wp, x, y, X, Y);
+    const Tap t = make_tap(X, Y, H, W);
+    const float b = My[y] * Mx[x];
+    const float m = 1.0f - b;
+    const float om = 1.0f - m;
+    const size_t p = ((size_t)y * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float wv = (float)tap_fetch(t, img, 3, c);
+        const float v = (float)img[p + c] * m + wv * om;
+        scratch[(size_t)i * 3 + c] = (uint8_t)v;
+    }
+}
+
+__global__ void rect_copy_kernel(uint8_t* __restrict__ img, int W, int rx0, int ry0, int rw, int rh,
+                                 const uint8_t* __restrict__ scratch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rw * rh) return;
+    const int yy = i / rw, xx = i - yy * rw;
+    const size_t p = ((size_t)(ry0 + yy) * W + rx0 + xx) * 3;
+    img[p] = scratch[(size_t)i * 3];
+    img[p + 1] = scratch[(size_t)i * 3 + 1];
+    img[p + 2] = scratch[(size_t)i * 3 + 2];
+}
+
+// ------------------------------------------------------------------------------------------------ compose
+struct ComposeArgs {
+    oadg_region_op op[3];     // [0],[1]: random boxes, [2]: outside
+    int rect[2][4];           // x1,y1,x2,y2 (exclusive) of the random boxes
+    int n_rects;
+};
+
+__device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const uint8_t* src, int H, int W,
+                                                int x, int y, const uint8_t* lut_s, const float* uf,
+                                                const uint8_t* u8, uint8_t out[3]) {
+    const size_t p = ((size_t)y * W + x) * 3;
+    switch (op.kind) {
+        case OADG_OP_LUT_AUTOCONTRAST:
+        case OADG_OP_LUT_EQUALIZE: {
+            const uint8_t* l = lut_s + (op.kind == OADG_OP_LUT_EQUALIZE ? 768 : 0);
+            out[0] = l[src[p]]; out[1] = l[256 + src[p + 1]]; out[2] = l[512 + src[p + 2]];
+            break;
+        }
+        case OADG_OP_POSTERIZE:
+            for (int c = 0; c < 3; ++c) out[c] = src[p + c] & (uint8_t)op.param;
+            break;
+        case OADG_OP_SOLARIZE:
+            for (int c = 0; c < 3; ++c) { const int v = src[p + c]; out[c] = (uint8_t)(v < op.param ? v : 255 - v); }
+            break;
+        case OADG_OP_IMAGE: {
+            const uint8_t* im = (const uint8_t*)op.image;
+            out[0] = im[p]; out[1] = im[p + 1]; out[2] = im[p + 2];
+            break;
+        }
+        case OADG_OP_BG_WARP: {
+            Warp wp;
+            for (int i = 0; i < 6; ++i) wp.m[i] = op.minv[i];
+            long X, Y;
+            warp_xy(wp, x, y, X, Y);
+            const Tap t = make_tap(X, Y, H, W);
+            const double wm = (double)tap_fetch(t, u8, 1, 0) / 255.0;
+            const double keep = fmax((double)uf[(size_t)y * W + x], wm);
+            const double ok = 1.0 - keep;
+            for (int c = 0; c < 3; ++c) {
+                const double v = keep * (double)src[p + c] + ok * (double)tap_fetch(t, src, 3, c);
+                out[c] = (uint8_t)v;
+            }
+            break;
+        }
+        case OADG_OP_WARP_NEG: {
+            Warp wp;
+            for (int i = 0; i < 6; ++i) wp.m[i] = op.minv[i];
+            long X, Y;
+            warp_xy(wp, x, y, X, Y);
+            const Tap t = make_tap(X, Y, H, W);
+            for (int c = 0; c < 3; ++c) out[c] = (uint8_t)(0 - tap_fetch(t, src, 3, c));
+            break;
+        }
+        default:
+            out[0] = src[p]; out[1] = src[p + 1]; out[2] = src[p + 2];
+    }
+}
+
+__global__ __launch_bounds__(256) void compose_kernel(const uint8_t* __restrict__ src,
+                                                      uint8_t* __restrict__ dst, int H, int W,
+                                                      ComposeArgs a, const uint8_t* __restrict__ luts,
+                                                      const float* __restrict__ uf,
+                                                      const uint8_t* __restrict__ u8,
+                                                      float* __restrict__ acc, float acc_w, int acc_mode) {
+    __shared__ uint8_t lut_s[2 * 768];
+    if (luts)
+        for (int i = threadIdx.x; i < 2 * 768; i += 256) lut_s[i] = luts[i];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < (long)H * W; p += (long)gridDim.x * 256) {
+        const int y = (int)(p / W), x = (int)(p - (long)y * W);
+        int r = 2;
+        for (int k = 0; k < a.n_rects; ++k)
+            if (x >= a.rect[k][0] && x < a.rect[k][2] && y >= a.rect[k][1] && y < a.rect[k][3]) r = k;
+        uint8_t o[3];
+        apply_region_op(a.op[r], src, H, W, x, y, lut_s, uf, u8, o);
+        dst[p * 3] = o[0]; dst[p * 3 + 1] = o[1]; dst[p * 3 + 2] = o[2];
+        if (acc_mode) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = acc_w * (float)o[c];
+                acc[p * 3 + c] = acc_mode == 1 ? t : acc[p * 3 + c] + t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final mix
+struct NormArgs {
+    float mean[3], stdinv[3];
+    int to_rgb;
+};
+
+template <typename T>
+__device__ __forceinline__ void store_norm(T* out, size_t idx, float v);
+template <>
+__device__ __forceinline__ void store_norm<float>(float* out, size_t idx, float v) { out[idx] = v; }
+template <>
+__device__ __forceinline__ void store_norm<unsigned short>(unsigned short* out, size_t idx, float v) {
+    out[idx] = f32_to_bf16(v);
+}
+
+template <typename T>
+__device__ __forceinline__ void write_norm(T* out, int Wp, int x, int y, const uint8_t px[3], const NormArgs& n) {
+    // mmcv.imnormalize: BGR->RGB swap, then (x - mean) * (1/std) in float32; NHWC, padded right/bottom with 0
+    const size_t base = ((size_t)y * Wp + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sc = n.to_rgb ? 2 - c : c;
+        store_norm<T>(out, base + c, ((float)px[sc] - n.mean[c]) * n.stdinv[c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void final_mix_kernel(const uint8_t* __restrict__ img,
+                                                        const float* __restrict__ acc, int H, int W,
+                                                        const oadg_mix_target* __restrict__ tg, int n_tg,
+                                                        const float* __restrict__ My,
+                                                        const float* __restrict__ Mx, double m_beta,
+                                                        NormArgs nrm, uint8_t* __restrict__ out_u8,
+                                                        T* __restrict__ out_norm, int Hp, int Wp) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)Hp * Wp) return;
+    const int y = (int)(p / Wp), x = (int)(p - (long)y * Wp);
+    if (y >= H || x >= W) {   // padding
+        if (out_norm) for (int c = 0; c < 3; ++c) store_norm<T>(out_norm, (size_t)p * 3 + c, 0.f);
+        return;
+    }
+    const size_t q = ((size_t)y * W + x) * 3;
+    float im[3], ag[3], orig[3] = {0.f, 0.f, 0.f}, aug[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { im[c] = (float)img[q + c]; ag[c] = acc[q + c]; }
+    float mask_sum = 0.f, mask_max = 0.f;
+    for (int t = 0; t < n_tg; ++t) {
+        const oadg_mix_target g = tg[t];
+        float mask;
+        if (g.fg_index >= 0) mask = My[(size_t)g.fg_index * H + y] * Mx[(size_t)g.fg_index * W + x];
+        else mask = (x >= g.rect[0] && x < g.rect[2] && y >= g.rect[1] && y < g.rect[3]) ? 1.0f : 0.0f;
+        mask_sum = mask_sum + mask;
+        mask_max = t == 0 ? mask : fmaxf(mask_max, mask);
+        const float overlap = mask_sum - mask_max;
+        const float wgt = mask - overlap * 0.5f;
+        const float a = 1.0f - g.m_oa;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            orig[c] = orig[c] + (a * im[c]) * wgt;
+            aug[c] = aug[c] + (g.m_oa * ag[c]) * wgt;
+        }
+        mask_sum = mask_max;
+    }
+    const float rest = 1.0f - mask_sum;
+    const float mf = (float)m_beta;
+    uint8_t px[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float o = orig[c] + aug[c];
+        o = (float)((double)o + ((1.0 - m_beta) * (double)img[q + c]) * (double)rest);
+        o = o + (mf * ag[c]) * rest;
+        o = fminf(fmaxf(o, 0.f), 255.f);
+        px[c] = (uint8_t)o;
+    }
+    if (out_u8) { out_u8[q] = px[0]; out_u8[q + 1] = px[1]; out_u8[q + 2] = px[2]; }
+    if (out_norm) write_norm<T>(out_norm, Wp, x, y, px, nrm);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                        NormArgs nrm, T* __restrict__ out, int Hp, int Wp) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (long)Hp * Wp) return;
+    const int y = (int)(p / Wp), x = (int)(p - (long)y * Wp);
+    if (y >= H || x >= W) {
+        for (int c = 0; c < 3; ++c) store_norm<T>(out, (size_t)p * 3 + c, 0.f);
+        return;
+    }
+    const size_t q = ((size_t)y * W + x) * 3;
+    const uint8_t px[3] = {img[q], img[q + 1], img[q + 2]};
+    write_norm<T>(out, Wp, x, y, px, nrm);
+}
+
+// ------------------------------------------------------------------------------------------------ saliency
+// StaticSaliencySpectralResidual on one box crop per block: gray -> 64x64 -> FFT2 -> log-amplitude minus its
+// 3x3 mean -> inverse FFT -> |.| -> 5x5 Gaussian (sigma 8) -> square -> /max -> bilinear to the crop size ->
+// mean of uint8(map * 255).  All of it in LDS (64x64 complex fp64 = 64 KiB).
+constexpr int SN = 64;
+
+__device__ void fft64_rows_or_cols(double* re, double* im, bool cols, bool inverse) {
+    // 64 independent 64-point radix-2 DIT FFTs; thread t < 64 owns line t (stride 1 or 64)
+    const int t = threadIdx.x;
+    if (t < SN) {
+        const int stride = cols ? SN : 1, base = cols ? t : t * SN;
+        // bit reversal
+        for (int i = 0; i < SN; ++i) {
+            int j = 0;
+            for (int b = 0; b < 6; ++b) j |= ((i >> b) & 1) << (5 - b);
+            if (j > i) {
+                double a = re[base + i * stride]; re[base + i * stride] = re[base + j * stride]; re[base + j * stride] = a;
+                a = im[base + i * stride]; im[base + i * stride] = im[base + j * stride]; im[base + j * stride] = a;
+            }
+        }
+        for (int len = 2; len <= SN; len <<= 1) {
+            const double ang = (inverse ? 2.0 : -2.0) * 3.14159265358979323846 / (double)len;
+            for (int s = 0; s < SN; s += len) {
+                for (int k = 0; k < len / 2; ++k) {
+                    double wr, wi;
+                    sincos(ang * (double)k, &wi, &wr);
+                    const int i0 = base + (s + k) * stride, i1 = base + (s + k + len / 2) * stride;
+                    const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
+                    re[i1] = re[i0] - xr; im[i1] = im[i0] - xi;
+                    re[i0] = re[i0] + xr; im[i0] = im[i0] + xi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void lin_axis(int d, int n_src, int n_dst, int& s0, int& s1, double& f) {
+    const double scale = (double)n_src / (double)n_dst;
+    double ff = ((double)d + 0.5) * scale - 0.5;
+    long s = (long)floor(ff);
+    ff = ff - (double)s;
+    if (s < 0) { ff = 0.0; s = 0; }
+    if (s >= n_src - 1) { ff = 0.0; s = n_src - 1; }
+    s0 = (int)s; s1 = s + 1 < n_src ? (int)s + 1 : n_src - 1; f = ff;
+}
+
+__global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                       const int* __restrict__ boxes, int min_side,
+                                                       double* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* re = reinterpret_cast<double*>(smem);            // [64*64]
+    double* im = re + SN * SN;                                // [64*64]
+    float* sal = reinterpret_cast<float*>(im + SN * SN);      // [64*64]
+    __shared__ double red[16];
+    __shared__ double s_max;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int x1 = boxes[4 * b], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
+    const int w = x2 - x1, h = y2 - y1;
+    if (w < min_side || h < min_side) {
+        if (tid == 0) scores[b] = -1.0;
+        return;
+    }
+    // gray (cv::cvtColor BGR2GRAY fixed point) + bilinear to 64x64, rounded to uint8
+    for (int i = tid; i < SN * SN; i += 256) {
+        const int dy = i / SN, dx = i - dy * SN;
+        int ya, yb, xa, xb; double fy, fx;
+        lin_axis(dy, h, SN, ya, yb, fy);
+        lin_axis(dx, w, SN, xa, xb, fx);
+        auto gray = [&](int yy, int xx) -> double {
+            const uint8_t* p = img + ((size_t)(y1 + yy) * W + (x1 + xx)) * 3;
+            return (double)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+        };
+        const double top = gray(ya, xa) * (1.0 - fx) + gray(ya, xb) * fx;
+        const double bot = gray(yb, xa) * (1.0 - fx) + gray(yb, xb) * fx;
+        double v = floor(top * (1.0 - fy) + bot * fy + 0.5);
+        v = fmin(fmax(v, 0.0), 255.0);
+        re[i] = v; im[i] = 0.0;
+    }
+    __syncthreads();
+    fft64_rows_or_cols(re, im, false, false);
+    fft64_rows_or_cols(re, im, true, false);
+    // log amplitude in `sal`-free storage: keep angle in im, log-magnitude in re
+    for (int i = tid; i < SN * SN; i += 256) {
+        const double mag = hypot(re[i], im[i]);
+        const double ang = atan2(im[i], re[i]);
+        re[i] = log(mag);
+        im[i] = ang;
+    }
+    __syncthreads();
+    // residual = exp(L - boxblur3(L)) ; needs L intact while reading neighbours -> stage result in registers
+    double resid[16];
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid + k * 256;
+        const int y = i / SN, x = i - y * SN;
+        double s = 0.0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) s += re[reflect101(y + dy, SN) * SN + reflect101(x + dx, SN)];
+        resid[k] = exp(re[i] - s / 9.0);
+    }
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid + k * 256;
+        double sn, cs;
+        sincos(im[i], &sn, &cs);
+        re[i] = resid[k] * cs;
+        im[i] = resid[k] * sn;
+    }
+    __syncthreads();
+    fft64_rows_or_cols(re, im, false, true);
+    fft64_rows_or_cols(re, im, true, true);
+    for (int i = tid; i < SN * SN; i += 256) re[i] = hypot(re[i], im[i]);
+    __syncthreads();
+    // 5x5 Gaussian sigma 8 (separable, reflect101): horizontal into im, vertical back into re
+    double g[5];
+    {
+        double s = 0.0;
+        for (int i = 0; i < 5; ++i) { g[i] = exp(-0.5 * (double)((i - 2) * (i - 2)) / 64.0); s += g[i]; }
+        for (int i = 0; i < 5; ++i) g[i] /= s;
+    }
+    for (int i = tid; i < SN * SN; i += 256) {
+        const int y = i / SN, x = i - y * SN;
+        double s = 0.0;
+        for (int k = 0; k < 5; ++k) s += g[k] * re[y * SN + reflect101(x + k - 2, SN)];
+        im[i] = s;
+    }
+    __syncthreads();
+    double lmax = 0.0;
+    for (int i = tid; i < SN * SN; i += 256) {
+        const int y = i / SN, x = i - y * SN;
+        double s = 0.0;
+        for (int k = 0; k < 5; ++k) s += g[k] * im[reflect101(y + k - 2, SN) * SN + x];
+        s = s * s;
+        re[i] = s;
+        lmax = fmax(lmax, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    if (tid == 0) s_max = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
+    for (int i = tid; i < SN * SN; i += 256) sal[i] = (float)(re[i] / s_max);
+    __syncthreads();
+    // bilinear (float32, horizontal then vertical) to w x h; score = mean(uint8(v * 255))
+    double acc = 0.0;
+    for (int i = tid; i < w * h; i += 256) {
+        const int dy = i / w, dx = i - dy * w;
+        int ya, yb, xa, xb; double fyd, fxd;
+        lin_axis(dy, SN, h, ya, yb, fyd);
+        lin_axis(dx, SN, w, xa, xb, fxd);
+        const float fx = (float)fxd, fy = (float)fyd;
+        const float ax0 = 1.0f - fx, ay0 = 1.0f - fy;
+        const float r0 = sal[ya * SN + xa] * ax0 + sal[ya * SN + xb] * fx;
+        const float r1 = sal[yb * SN + xa] * ax0 + sal[yb * SN + xb] * fx;
+        const float v = r0 * ay0 + r1 * fy;
+        acc += (double)(uint8_t)(v * 255.0f);
+    }
+    const double tot = block_sum_d(acc, red);
+    if (tid == 0) scores[b] = tot / (double)((long)w * h);
+}
+
+int grid1d(long n, int block) { return (int)((n + block - 1) / block); }
+
+}  // namespace
+
+extern "C" {
+
+int oadg_oamix_box_profiles(const int* qbox, const double* sigma, int n, int H, int W, int ratio, float* My,
+                            float* Mx, void* stream) {
+    if (n == 0) return OADG_OK;
+    if (!qbox || !sigma || !My || !Mx || n < 0 || H < 1 || W < 1 || ratio < 1) return OADG_EARG;
+    if (H / ratio > PROF_MAXQ || W / ratio > PROF_MAXQ) return OADG_EARG;
+    hipLaunchKernelGGL(box_profiles_kernel, dim3(n, 2), dim3(256), 0, (hipStream_t)stream, qbox, sigma, H, W,
+                       ratio, My, Mx);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, float* union_f,
+                        uint8_t* union_u8, void* stream) {
+    if (!union_f || !union_u8 || n < 0 || (n > 0 && (!My || !Mx))) return OADG_EARG;
+    hipLaunchKernelGGL(fg_union_kernel, dim3(grid1d((long)H * W, 256)), dim3(256), 0, (hipStream_t)stream, My,
+                       Mx, n, H, W, union_f, union_u8);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
+                        double* scores, void* stream) {
+    if (n == 0) return OADG_OK;
+    if (!img || !boxes || !scores || n < 0) return OADG_EARG;
+    const size_t lds = (size_t)SN * SN * (8 + 8 + 4);
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS must be opted into once (idempotent)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)saliency_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(saliency_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, img, H, W, boxes,
+                       min_side, scores);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream) {
+    if (!img || !hist || npix < 0) return OADG_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(hist, 0, 768 * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    int g = grid1d(npix / 4 + 1, 256 * 16);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(hist_kernel, dim3(g), dim3(256), 0, st, img, npix, hist);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream) {
+    if (!hist || !luts) return OADG_EARG;
+    hipLaunchKernelGGL(luts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hist, luts);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, int rx0, int ry0, int rw, int rh,
+                         const float* My_row, const float* Mx_row, uint8_t* scratch, void* stream) {
+    if (!img || !minv_host || !My_row || !Mx_row || !scratch) return OADG_EARG;
+    if (rw <= 0 || rh <= 0) return OADG_OK;
+    if (rx0 < 0 || ry0 < 0 || rx0 + rw > W || ry0 + rh > H) return OADG_EARG;
+    Warp wp;
+    for (int i = 0; i < 6; ++i) wp.m[i] = minv_host[i];
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid1d((long)rw * rh, 256);
+    hipLaunchKernelGGL(bbox_blend_kernel, dim3(g), dim3(256), 0, st, (const uint8_t*)img, H, W, wp, rx0, ry0, rw,
+                       rh, My_row, Mx_row, scratch);
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rect_copy_kernel, dim3(g), dim3(256), 0, st, img, W, rx0, ry0, rw, rh,
+                       (const uint8_t*)scratch);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
+                       const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,
+                       const uint8_t* union_u8, float* acc, float acc_w, int acc_mode, void* stream) {
+    if (!src || !dst || !ops_host || n_rects < 0 || n_rects > 2 || (n_rects && !rects_host)) return OADG_EARG;
+    if (acc_mode && !acc) return OADG_EARG;
+    ComposeArgs a;
+    a.n_rects = n_rects;
+    for (int k = 0; k < 3; ++k) {
+        a.op[k] = ops_host[k];
+        const int kd = a.op[k].kind;
+        if ((kd == OADG_OP_LUT_AUTOCONTRAST || kd == OADG_OP_LUT_EQUALIZE) && !luts) return OADG_EARG;
+        if (kd == OADG_OP_IMAGE && !a.op[k].image) return OADG_EARG;
+        if (kd == OADG_OP_BG_WARP && (!union_f || !union_u8)) return OADG_EARG;
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 4; ++j) a.rect[k][j] = (k < n_rects) ? rects_host[4 * k + j] : 0;
+    int g = grid1d((long)H * W, 256);
+    if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(compose_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, a, luts,
+                       union_f, union_u8, acc, acc_w, acc_mode);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+static int fill_norm(NormArgs& n, const float* mean_host, const float* stdinv_host, int to_rgb) {
+    if (!mean_host || !stdinv_host) return OADG_EARG;
+    for (int c = 0; c < 3; ++c) { n.mean[c] = mean_host[c]; n.stdinv[c] = stdinv_host[c]; }
+    n.to_rgb = to_rgb;
+    return OADG_OK;
+}
+
+int oadg_oamix_final(const uint8_t* img, const float* acc, int H, int W, const oadg_mix_target* targets,
+                     int n_targets, const float* My, const float* Mx, double m_beta, const float* mean_host,
+                     const float* stdinv_host, int to_rgb, uint8_t* out_u8, void* out_norm, int out_dtype,
+                     int Hp, int Wp, void* stream) {
+    if (!img || !acc || n_targets < 0 || (n_targets && !targets) || Hp < H || Wp < W) return OADG_EARG;
+    if (!out_u8 && !out_norm) return OADG_EARG;
+    NormArgs nrm = {};
+    if (out_norm && fill_norm(nrm, mean_host, stdinv_host, to_rgb)) return OADG_EARG;
+    const int g = grid1d((long)Hp * Wp, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == 1)
+        hipLaunchKernelGGL((final_mix_kernel<unsigned short>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (unsigned short*)out_norm, Hp, Wp);
+    else
+        hipLaunchKernelGGL((final_mix_kernel<float>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (float*)out_norm, Hp, Wp);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_host, const float* stdinv_host,
+                         int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream) {
+    if (!img || !out || Hp < H || Wp < W) return OADG_EARG;
+    NormArgs nrm;
+    if (fill_norm(nrm, mean_host, stdinv_host, to_rgb)) return OADG_EARG;
+    const int g = grid1d((long)Hp * Wp, 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == 1)
+        hipLaunchKernelGGL((normalize_kernel<unsigned short>), dim3(g), dim3(256), 0, st, img, H, W, nrm,
+                           (unsigned short*)out, Hp, Wp);
+    else
+        hipLaunchKernelGGL((normalize_kernel<float>), dim3(g), dim3(256), 0, st, img, H, W, nrm, (float*)out, Hp,
+                           Wp);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+}  // extern "C"

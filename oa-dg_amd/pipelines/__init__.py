@@ -1,0 +1,4 @@
+"""Data-path transforms under the reference's PIPELINES names (mmdet/datasets/pipelines)."""
+from .oa_mix import OAMix  # noqa: F401
+from .device_pipeline import (Collect, Compose, DefaultFormatBundle, DevicePipeline, Normalize, Pad,  # noqa: F401
+                              SyntheticCityscapes)

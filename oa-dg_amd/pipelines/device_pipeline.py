@@ -1,0 +1,182 @@
+"""The part of the reference's train pipeline that follows image loading, executed on the device for a whole
+batch: OAMix -> Normalize -> Pad -> DefaultFormatBundle -> Collect (+ mmcv collate), SURVEY.md 3.2 / 8a a13.
+
+``Normalize`` / ``Pad`` / ``DefaultFormatBundle`` / ``Collect`` are registered so the reference's pipeline lists
+parse unchanged; they only carry their configuration.  ``DevicePipeline`` reads that configuration and produces
+the collated batch ``train_step`` consumes, with Normalize+Pad fused into the OA-Mix output kernel
+(transforms.py:618-629,699-701; formating.py:217-255,289-357): images leave the pipeline as normalised NHWC
+tensors (logical [N,3,H,W], channels_last), never as host arrays.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+from ..registry import DATASETS, PIPELINES, build_from_cfg
+from .oa_mix import OAMix, _ImageState
+
+
+@PIPELINES.register_module()
+class Normalize:
+    def __init__(self, mean, std, to_rgb=True):
+        self.mean = np.array(mean, dtype=np.float32)
+        self.std = np.array(std, dtype=np.float32)
+        self.to_rgb = to_rgb
+
+    def as_args(self):
+        # mmcv.imnormalize: (x - mean) * (1 / std) after the BGR->RGB swap
+        return dict(mean=[float(v) for v in self.mean],
+                    stdinv=[float(np.float32(1.0 / np.float64(s))) for s in self.std], to_rgb=self.to_rgb)
+
+
+@PIPELINES.register_module()
+class Pad:
+    def __init__(self, size=None, size_divisor=None, pad_val=0):
+        assert size is not None or size_divisor is not None
+        self.size, self.size_divisor, self.pad_val = size, size_divisor, pad_val
+
+    def padded(self, h, w):
+        if self.size is not None:
+            return int(self.size[0]), int(self.size[1])
+        d = self.size_divisor
+        return int(np.ceil(h / d)) * d, int(np.ceil(w / d)) * d
+
+
+@PIPELINES.register_module()
+class DefaultFormatBundle:
+    def __init__(self, img_to_float=True, pad_val=dict(img=0, masks=0, seg=255)):
+        self.img_to_float = img_to_float
+
+
+@PIPELINES.register_module()
+class Collect:
+    def __init__(self, keys, meta_keys=('filename', 'ori_filename', 'ori_shape', 'img_shape', 'pad_shape',
+                                        'scale_factor', 'flip', 'flip_direction', 'img_norm_cfg')):
+        self.keys, self.meta_keys = keys, meta_keys
+
+
+class Compose:
+    """mmdet/datasets/pipelines/compose.py: build each transform from the PIPELINES registry."""
+
+    def __init__(self, transforms):
+        self.transforms = [build_from_cfg(t, PIPELINES) if isinstance(t, dict) else t for t in transforms]
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+            if data is None:
+                return None
+        return data
+
+
+class DevicePipeline:
+    """Batched device execution of [OAMix,] Normalize, Pad, DefaultFormatBundle, Collect."""
+
+    def __init__(self, pipeline_cfg, dtype=torch.float32):
+        ts = Compose(pipeline_cfg).transforms
+        self.oamix = next((t for t in ts if isinstance(t, OAMix)), None)
+        self.norm = next((t for t in ts if isinstance(t, Normalize)), None)
+        self.pad = next((t for t in ts if isinstance(t, Pad)), None)
+        collect = next((t for t in ts if isinstance(t, Collect)), None)
+        self.keys = list(collect.keys) if collect else ['img', 'gt_bboxes', 'gt_labels']
+        assert self.norm is not None, 'the pipeline needs a Normalize step'
+        self.dtype = dtype
+
+    def __call__(self, imgs_u8, gt_bboxes, gt_labels):
+        """imgs_u8: uint8 [N,H,W,3] cuda tensor (BGR bytes); gt_bboxes: list of float32 [n_i,4] numpy arrays;
+        gt_labels: list of int64 numpy arrays.  Returns the collated dict for ``train_step``."""
+        L = _lib.lib()
+        N, H, W = imgs_u8.shape[:3]
+        dev = imgs_u8.device
+        Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
+        na = self.norm.as_args()
+        mean = (ctypes.c_float * 3)(*na['mean'])
+        stdinv = (ctypes.c_float * 3)(*na['stdinv'])
+        dt = 1 if self.dtype == torch.bfloat16 else 0
+        mk = lambda: torch.empty((N, 3, Hp, Wp), dtype=self.dtype, device=dev,  # noqa: E731
+                                 memory_format=torch.channels_last)
+        out = dict()
+        img = mk()
+        for i in range(N):   # physical NHWC slice i is contiguous
+            check(L.oadg_oamix_normalize(ptr(imgs_u8[i]), H, W, mean, stdinv, int(na['to_rgb']),
+                                         ctypes.c_void_p(img.data_ptr() + i * img.stride(0) * img.element_size()),
+                                         dt, Hp, Wp, stream_ptr()), 'oadg_oamix_normalize')
+        out['img'] = img
+        shape, pshape = (H, W, 3), (Hp, Wp, 3)
+        out['img_metas'] = [dict(img_shape=shape, pad_shape=pshape, ori_shape=shape, scale_factor=1.0, flip=False)
+                            for _ in range(N)]
+        out['gt_bboxes'] = [torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(dev) for b in gt_bboxes]
+        out['gt_labels'] = [torch.from_numpy(np.ascontiguousarray(l, dtype=np.int64)).to(dev) for l in gt_labels]
+        if self.oamix is not None and self.oamix.num_views > 1:
+            assert self.oamix.num_views == 2 and self.oamix.keep_orig
+            om = self.oamix
+            # saliency / mask profiles of every image are enqueued first, so the scores of image i are on the
+            # host long before its object-aware mixing step needs them
+            states = [_ImageState(imgs_u8[i].contiguous(), gt_bboxes[i], om.spatial_ratio, om.sigma_ratio)
+                      for i in range(N)]
+            img2 = mk()
+            ml, oa = [], []
+            for i, st in enumerate(states):
+                om._history = {}
+                view = ctypes.c_void_p(img2.data_ptr() + i * img2.stride(0) * img2.element_size())
+                om.oamix(st, out_u8=None, out_norm=_PtrView(view, self.dtype), norm=na, pad_shape=(Hp, Wp))
+                ml.append(torch.from_numpy(np.asarray(om._history['random_box_list'])))
+                oa.append(torch.from_numpy(np.stack(om._history['oa_random_box_list'], axis=0)))
+            out['img2'] = img2
+            out['gt_bboxes2'] = [b.clone() for b in out['gt_bboxes']]
+            out['multilevel_boxes'] = ml
+            out['oamix_boxes'] = oa
+        return {k: v for k, v in out.items() if k in self.keys or k == 'img_metas'}
+
+
+class _PtrView:
+    """a (device pointer, dtype) pair quacking enough like a tensor for ptr()/dtype checks"""
+
+    def __init__(self, p, dtype):
+        self._p, self.dtype = p, dtype
+
+    def data_ptr(self):
+        return self._p.value
+
+
+@DATASETS.register_module()
+class SyntheticCityscapes:
+    """Cityscapes-shaped synthetic samples: uint8 low-pass noise images resident in HBM, ~20
+    boxes per image with sides U(24,400) clipped to the image, labels U{0..7}.  Seeded per (seed, index)."""
+
+    def __init__(self, img_shape=(1024, 2048), num_boxes=20, num_classes=8, length=2975, pipeline=None,
+                 box_size=(24, 400), seed=0, device='cuda'):
+        self.img_shape, self.num_boxes, self.num_classes = tuple(img_shape), num_boxes, num_classes
+        self.length, self.box_size, self.seed, self.device = length, box_size, seed, device
+        self.pipeline_cfg = pipeline
+
+    def __len__(self):
+        return self.length
+
+    def boxes(self, idx):
+        rs = np.random.RandomState((self.seed * 1000003 + idx) & 0x7fffffff)
+        H, W = self.img_shape
+        n = self.num_boxes
+        bw = rs.uniform(self.box_size[0], min(self.box_size[1], W), n)
+        bh = rs.uniform(self.box_size[0], min(self.box_size[1], H), n)
+        x1 = rs.uniform(0, W - bw)
+        y1 = rs.uniform(0, H - bh)
+        b = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        return b, rs.randint(0, self.num_classes, n).astype(np.int64)
+
+    def image(self, idx, k=8):
+        """uint8 [H,W,3]: uniform noise, k x k box filter, stretched to 0..255 (on the device)."""
+        H, W = self.img_shape
+        g = torch.Generator(device=self.device).manual_seed((self.seed * 1000003 + idx) & 0x7fffffff)
+        x = torch.rand((1, 3, H + k - 1, W + k - 1), device=self.device, generator=g)
+        x = torch.nn.functional.avg_pool2d(x, k, stride=1)
+        lo, hi = x.amin(), x.amax()
+        x = ((x - lo) / (hi - lo + 1e-9) * 255.0).clamp(0, 255).to(torch.uint8)
+        return x[0].permute(1, 2, 0).contiguous()
+
+    def batch(self, indices):
+        imgs = torch.stack([self.image(i) for i in indices])
+        bl = [self.boxes(i) for i in indices]
+        return imgs, [b for b, _ in bl], [l for _, l in bl]

@@ -1,0 +1,397 @@
+"""OA-Mix on the MI355X under the reference's PIPELINES name ``OAMix``.
+
+Mirrors mmdet/datasets/pipelines/oa_mix.py:32-312 (and the leaf/wrapper functions of augmix.py:32-212,
+bbox_augmentation.py:31-118,240-302 it dispatches to): same constructor, same ``__call__(results) -> results``
+contract, same keys written (``img2``, ``gt_bboxes2``, ``oamix_boxes``, ``multilevel_boxes``, ``img_fields``,
+``custom_field``), and the same consumption of the GLOBAL ``np.random`` stream, draw for draw.
+
+What differs is where the pixels are touched: the host only draws random numbers and fills small launch
+descriptors; every image byte is produced by the HIP kernels of csrc/oamix.hip through the C ABI.  The n_gt
+full-resolution float masks of the reference (25 MB each) are replaced by two 1-D profiles per box.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import (OP_BG_WARP, OP_IMAGE, OP_LUT_AUTOCONTRAST, OP_LUT_EQUALIZE, OP_POSTERIZE, OP_SOLARIZE,
+                    OP_WARP_NEG, RegionOp, check, ptr, stream_ptr)
+from ..core.bbox import bbox_overlaps_np
+from ..registry import PIPELINES
+
+AUG_LISTS = {   # oa_mix.py:15-29
+    'augmix': ['autocontrast', 'equalize', 'posterize', 'solarize', 'bboxes_only_rotate',
+               'bboxes_only_shear_xy', 'bboxes_only_translate_xy', 'bg_only_rotate', 'bg_only_shear_xy',
+               'bg_only_translate_xy'],
+    'augmix.all': ['autocontrast', 'equalize', 'posterize', 'solarize', 'invert', 'color', 'contrast',
+                   'brightness', 'sharpness', 'bboxes_only_rotate', 'bboxes_only_shear_xy',
+                   'bboxes_only_translate_xy', 'bg_only_rotate', 'bg_only_shear_xy', 'bg_only_translate_xy'],
+}
+MIX_TARGET_DTYPE = np.dtype([('fg_index', '<i4'), ('rect', '<i4', (4,)), ('m_oa', '<f4')])   # oadg_mix_target
+
+
+def sample_level(n):            # augmix.py:60-61
+    return np.random.uniform(low=0.1, high=n)
+
+
+def int_parameter(level, maxval):   # augmix.py:32-43
+    return int(level * maxval / 10)
+
+
+def float_parameter(level, maxval):  # augmix.py:46-57
+    return float(level) * maxval / 10.
+
+
+def invert_affine(M):
+    """cv2.warpAffine inverts the forward matrix in double precision before sampling (imgwarp.cpp)."""
+    m = [float(v) for v in np.asarray(M, dtype=np.float64).reshape(-1)]
+    D = m[0] * m[4] - m[1] * m[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[4] * D, m[0] * D
+    m[0] = A11
+    m[1] *= -D
+    m[3] *= -D
+    m[4] = A22
+    b1 = -m[0] * m[2] - m[1] * m[5]
+    b2 = -m[3] * m[2] - m[4] * m[5]
+    m[2], m[5] = b1, b2
+    return m
+
+
+def rotation_matrix(center, angle, scale=1.0):
+    """cv2.getRotationMatrix2D (centre is a Point2f)."""
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
+    a = angle * math.pi / 180.0
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy],
+                     [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
+
+
+def geo_matrix(kind, severity, img_size, center=None, size_for_level=None):
+    """The affine matrix one geometric leaf draws (augmix.py:83-188), in the dtype cv2 receives it."""
+    if kind == 'rotate':
+        deg = int_parameter(sample_level(severity), 30)
+        if np.random.uniform() > 0.5:
+            deg = -deg
+        c = center if center is not None else (img_size[0] / 2, img_size[1] / 2)
+        return rotation_matrix(c, deg)
+    if kind in ('shear_x', 'shear_y'):
+        lvl = float_parameter(sample_level(severity), 0.3)
+        if np.random.uniform() > 0.5:
+            lvl = -lvl
+        if kind == 'shear_x':
+            tx = 0 if center is None else -lvl * center[1]
+            return np.float32([[1, -lvl, -tx], [0, 1, 0]])
+        ty = 0 if center is None else -lvl * center[0]
+        return np.float32([[1, 0, 0], [-lvl, 1, -ty]])
+    ax = 0 if kind == 'translate_x' else 1
+    maxval = img_size[ax] if size_for_level is None else size_for_level[ax]
+    lvl = int_parameter(sample_level(severity), maxval / 3)
+    if np.random.random() > 0.5:
+        lvl = -lvl
+    return np.float32([[1, 0, -lvl], [0, 1, 0]]) if ax == 0 else np.float32([[1, 0, 0], [0, 1, -lvl]])
+
+
+class _ImageState:
+    """Device-side state of one image: profiles of the fg masks, their union, saliency scores (async)."""
+
+    def __init__(self, img, gt_bboxes, spatial_ratio, sigma_ratio):
+        L = _lib.lib()
+        self.img = img                                     # uint8 [H,W,3] on the device
+        self.H, self.W = int(img.shape[0]), int(img.shape[1])
+        self.gt = np.asarray(gt_bboxes, dtype=np.float32).reshape(-1, 4)
+        n = self.n = self.gt.shape[0]
+        dev = img.device
+        H, W = self.H, self.W
+        # --- blurred-mask profiles (oa_mix.py:74-93) -------------------------------------------------
+        qbox = np.zeros((n, 4), np.int32)
+        sigma = np.zeros((n, 2), np.float64)
+        self.support = []                                   # conservative rect where the mask can be non-zero
+        for i, gt in enumerate(self.gt):
+            x1, y1, x2, y2 = np.array(gt // spatial_ratio, dtype=np.int32)
+            qbox[i] = (x1, y1, x2, y2)
+            sx = (x2 - x1) * sigma_ratio / 3 * 2
+            sy = (y2 - y1) * sigma_ratio / 3 * 2
+            blur = not (sx <= 0 or sy <= 0)
+            sigma[i] = (sx, sy) if blur else (0.0, 0.0)
+            self.support.append(self._support(int(x1), int(y1), int(x2), int(y2), float(sx), float(sy), blur,
+                                              spatial_ratio))
+        assert (qbox >= 0).all(), 'gt boxes must have non-negative coordinates'
+        self.My = torch.empty((max(n, 1), H), dtype=torch.float32, device=dev)
+        self.Mx = torch.empty((max(n, 1), W), dtype=torch.float32, device=dev)
+        self.union_f = torch.empty((H, W), dtype=torch.float32, device=dev)
+        self.union_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        if n:
+            self._qbox = torch.from_numpy(qbox).to(dev)
+            self._sigma = torch.from_numpy(sigma).to(dev)
+            check(L.oadg_oamix_box_profiles(ptr(self._qbox), ptr(self._sigma), n, H, W, spatial_ratio,
+                                            ptr(self.My), ptr(self.Mx), stream_ptr()), 'oadg_oamix_box_profiles')
+        check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
+                                    stream_ptr()), 'oadg_oamix_fg_union')
+        # --- saliency scores (oa_mix.py:98-111): launched now, read when object-aware mixing needs them -----
+        self._scores = None
+        if n:
+            ib = np.array(self.gt, dtype=np.int32)
+            self._ibox = torch.from_numpy(ib).to(dev)
+            self._scores_dev = torch.empty((n,), dtype=torch.float64, device=dev)
+            check(L.oadg_oamix_saliency(ptr(img), H, W, ptr(self._ibox), n, spatial_ratio,
+                                        ptr(self._scores_dev), stream_ptr()), 'oadg_oamix_saliency')
+            self._scores_host = torch.empty((n,), dtype=torch.float64, pin_memory=True)
+            self._scores_host.copy_(self._scores_dev, non_blocking=True)
+            self._scores_evt = torch.cuda.Event()
+            self._scores_evt.record()
+
+    def _support(self, x1, y1, x2, y2, sx, sy, blur, ratio):
+        H, W = self.H, self.W
+        if x2 <= x1 or y2 <= y1:
+            return None                                     # empty at reduced resolution: mask is all zero
+        rx = ((int(np.rint(sx * 4 * 2 + 1)) | 1) - 1) // 2 if blur else 0
+        ry = ((int(np.rint(sy * 4 * 2 + 1)) | 1) - 1) // 2 if blur else 0
+        xa = max(0, ratio * (x1 - rx) - 2 * ratio)
+        xb = min(W, ratio * (x2 + rx) + 2 * ratio)
+        ya = max(0, ratio * (y1 - ry) - 2 * ratio)
+        yb = min(H, ratio * (y2 + ry) + 2 * ratio)
+        return (xa, ya, xb - xa, yb - ya)
+
+    def scores(self):
+        """fg_score_list of get_fg_regions: -1 for boxes thinner than spatial_ratio, else the saliency mean."""
+        if self._scores is None:
+            if self.n == 0:
+                self._scores = []
+            else:
+                self._scores_evt.synchronize()
+                self._scores = [float(s) if s >= 0 else -1 for s in self._scores_host.tolist()]
+        return self._scores
+
+
+@PIPELINES.register_module()
+class OAMix:
+
+    def __init__(self, version='augmix', num_views=2, keep_orig=True, severity=10, mixture_width=3,
+                 mixture_depth=-1, random_box_scale=(0.01, 0.1), random_box_ratio=(3, 1 / 3),
+                 oa_random_box_scale=(0.005, 0.1), oa_random_box_ratio=(3, 1 / 3), num_bboxes=(3, 5),
+                 spatial_ratio=4, sigma_ratio=0.3, **kwargs):
+        if version not in AUG_LISTS:
+            raise NotImplementedError(version)
+        self.version, self.aug_list = version, AUG_LISTS[version]
+        self.num_views, self.keep_orig, self.severity = num_views, keep_orig, severity
+        self.aug_prob_coeff, self.mixture_width, self.mixture_depth = 1.0, mixture_width, mixture_depth
+        self.random_box_scale, self.random_box_ratio = random_box_scale, random_box_ratio
+        self.oa_random_box_scale, self.oa_random_box_ratio = oa_random_box_scale, oa_random_box_ratio
+        self.score_thresh = 10
+        self.spatial_ratio, self.sigma_ratio = spatial_ratio, sigma_ratio
+        self._history = {}
+        self.kwargs = kwargs            # unknown kwargs are swallowed like the reference (oa_mix.py:72)
+        self._bufs = {}
+        self.trace = None               # set to [] to record the op sequence (tests)
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _buffers(self, st):
+        key = (st.H, st.W, str(st.img.device))
+        b = self._bufs.get(key)
+        if b is None:
+            dev, H, W = st.img.device, st.H, st.W
+            u8 = lambda: torch.empty((H, W, 3), dtype=torch.uint8, device=dev)  # noqa: E731
+            b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()], scratch=u8(),
+                     acc=torch.empty((H, W, 3), dtype=torch.float32, device=dev),
+                     hist=torch.empty((768,), dtype=torch.int32, device=dev),
+                     luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev))
+            self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------------------------------ regions
+    def _random_regions(self, H, W, scale, ratio, num_bboxes, return_score=False, fg_boxes=None,
+                        fg_scores=None, max_iters=50, eps=1e-6):
+        """get_random_regions (oa_mix.py:122-184) without the H x W x 3 masks."""
+        boxes, scores = [], []
+        target = np.random.randint(*num_bboxes) if isinstance(num_bboxes, tuple) else num_bboxes
+        for _ in range(max_iters):
+            if len(boxes) >= target:
+                break
+            x1, y1 = np.random.randint(0, W), np.random.randint(0, H)
+            _scale = np.random.uniform(*scale) * H * W
+            _ratio = np.random.uniform(*ratio)
+            bw, bh = int(np.sqrt(_scale / _ratio)), int(np.sqrt(_scale * _ratio))
+            if x1 + bw > W or y1 + bh > H:
+                continue
+            box = np.array([[x1, y1, min(x1 + bw, W), min(y1 + bh, H)]])
+            if np.sum(bbox_overlaps_np(box, np.asarray(boxes).reshape(-1, 4))) > eps:
+                continue
+            if return_score:
+                ious = bbox_overlaps_np(box, fg_boxes)
+                final = float('inf')
+                if np.sum(ious) > eps:
+                    for iou, fb, fs in zip(ious[0], fg_boxes, fg_scores):
+                        if iou == 0.0 or fb[2] - fb[0] < 1 or fb[3] - fb[1] < 1:
+                            continue
+                        if fs < final:
+                            final = fs
+                scores.append(final)
+            boxes += list(box)
+        return (boxes, scores) if return_score else boxes
+
+    # ------------------------------------------------------------------------------------------ one op
+    def _ensure_luts(self, st, src, step):
+        if step.get('luts_for') is not src:
+            L = _lib.lib()
+            b = self._buffers(st)
+            check(L.oadg_oamix_hist(ptr(src), st.H * st.W, ptr(b['hist']), stream_ptr()), 'oadg_oamix_hist')
+            check(L.oadg_oamix_luts(ptr(b['hist']), ptr(b['luts']), stream_ptr()), 'oadg_oamix_luts')
+            step['luts_for'] = src
+
+    def _aug(self, st, src, step):
+        """aug (oa_mix.py:264-279): draw the op, draw its parameters, return the region-op descriptor."""
+        name = self.aug_list[np.random.choice(len(self.aug_list))]
+        if self.trace is not None:
+            self.trace.append(name)
+        op = RegionOp()
+        H, W = st.H, st.W
+        if name in ('autocontrast', 'equalize'):
+            self._ensure_luts(st, src, step)
+            op.kind = OP_LUT_AUTOCONTRAST if name == 'autocontrast' else OP_LUT_EQUALIZE
+        elif name == 'posterize':
+            bits = 4 - int_parameter(sample_level(self.severity), 4)
+            op.kind, op.param = OP_POSTERIZE, (~(2 ** (8 - bits) - 1)) & 0xFF
+        elif name == 'solarize':
+            op.kind, op.param = OP_SOLARIZE, 256 - int_parameter(sample_level(self.severity), 256)
+        elif name == 'invert':
+            tx = 1 if np.random.random() > 0.5 else -1
+            ty = 1 if np.random.random() > 0.5 else -1
+            op.kind = OP_WARP_NEG
+            op.minv[:] = invert_affine(np.float32([[1, 0, tx], [0, 1, ty]]))
+        elif name in ('color', 'contrast', 'brightness', 'sharpness'):
+            raise NotImplementedError(f'{name}: the ImageEnhance ops of version="augmix.all" are not built yet')
+        else:
+            scope, kind = name.split('_only_')
+            if kind.endswith('_xy'):
+                kind = kind[:-2] + ('x' if np.random.rand() < 0.5 else 'y')
+            if scope == 'bg':
+                op.kind = OP_BG_WARP
+                op.minv[:] = invert_affine(geo_matrix(kind, self.severity, (W, H)))
+            else:
+                op.kind = OP_IMAGE
+                op.image = self._bboxes_only(st, src, kind, step).data_ptr()
+        return op
+
+    def _bboxes_only(self, st, src, kind, step):
+        """_apply_bboxes_only_augmentation (bbox_augmentation.py:74-88): the gt boxes, in order, each warp the
+        whole current image about their centre and blend it in through their blurred mask."""
+        L = _lib.lib()
+        b = self._buffers(st)
+        T = b['tmp'][step['n_tmp']]
+        step['n_tmp'] += 1
+        T.copy_(src)
+        H, W = st.H, st.W
+        for i, box in enumerate(st.gt):
+            x1, y1, x2, y2 = int(box[0]), int(box[1]), int(box[2]), int(box[3])
+            if (x2 - x1) < 1 or (y2 - y1) < 1:
+                continue                                     # returns before any draw (:45-47)
+            center = ((x1 + x2) / 2., (y1 + y2) / 2.)
+            M = geo_matrix(kind, self.severity, (W, H), center, (x2 - x1 + 1, y2 - y1 + 1))
+            sup = st.support[i]
+            if sup is None or sup[2] <= 0 or sup[3] <= 0:
+                continue                                     # mask identically zero: image unchanged
+            minv = (ctypes.c_double * 6)(*invert_affine(M))
+            check(L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
+                                         ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
+                                         ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
+                                         stream_ptr()), 'oadg_oamix_bbox_step')
+        return T
+
+    # ------------------------------------------------------------------------------------------ one view
+    def oamix(self, st, out_u8=None, out_norm=None, norm=None, pad_shape=None):
+        """oamix (oa_mix.py:207-243) for one image state; writes the uint8 view and/or its normalised tensor."""
+        L = _lib.lib()
+        H, W = st.H, st.W
+        b = self._buffers(st)
+        ws = np.float32(np.random.dirichlet([self.aug_prob_coeff] * self.mixture_width))
+        rboxes = self._random_regions(H, W, self.random_box_scale, self.random_box_ratio, (1, 3))
+        self._history['random_box_list'] = np.stack(rboxes, axis=0)
+        assert len(rboxes) <= 2
+        rects = (ctypes.c_int * 8)(*[int(v) for bx in rboxes for v in bx], *([0] * (8 - 4 * len(rboxes))))
+        for i in range(self.mixture_width):
+            depth = self.mixture_depth if self.mixture_depth > 0 else np.random.randint(1, 4)
+            cur = st.img
+            for d in range(depth):
+                step = dict(n_tmp=0, luts_for=None)
+                ops = (RegionOp * 3)()
+                for k in range(len(rboxes)):
+                    ops[k] = self._aug(st, cur, step)
+                ops[2] = self._aug(st, cur, step)
+                dst = b['ping'][d & 1]
+                last = d == depth - 1
+                check(L.oadg_oamix_compose(ptr(cur), ptr(dst), H, W, ops, rects, len(rboxes), ptr(b['luts']),
+                                           ptr(st.union_f), ptr(st.union_u8), ptr(b['acc']), float(ws[i]),
+                                           (1 if i == 0 else 2) if last else 0, stream_ptr()),
+                      'oadg_oamix_compose')
+                cur = dst
+        # get_regions_for_object_aware_mixing (oa_mix.py:245-262)
+        scores = st.scores()
+        targets = []
+        for idx, score in enumerate(scores):
+            if score <= self.score_thresh:
+                targets.append((idx, (0, 0, 0, 0), score))
+        rb, rs = self._random_regions(H, W, self.oa_random_box_scale, self.oa_random_box_ratio,
+                                      num_bboxes=min(max(len(targets), 1), 5), return_score=True,
+                                      fg_boxes=st.gt, fg_scores=scores)
+        self._history['oa_random_box_list'] = rb
+        for bx, sc in zip(rb, rs):
+            targets.append((-1, tuple(int(v) for v in bx), sc))
+        # object_aware_mixing (oa_mix.py:281-309)
+        m = np.random.beta(self.aug_prob_coeff, self.aug_prob_coeff)
+        tg = np.zeros((len(targets),), MIX_TARGET_DTYPE)
+        for t, (idx, rect, score) in enumerate(targets):
+            hi = 0.5 if score <= self.score_thresh else 1.0
+            tg[t] = (idx, rect, np.float32(np.random.uniform(0.0, hi)))
+        tg_dev = torch.from_numpy(tg.view(np.uint8).reshape(-1)).to(st.img.device) if len(targets) else None
+        mean = stdinv = None
+        to_rgb, dt, Hp, Wp = 0, 0, H, W
+        if out_norm is not None:
+            mean = (ctypes.c_float * 3)(*norm['mean'])
+            stdinv = (ctypes.c_float * 3)(*norm['stdinv'])
+            to_rgb = int(norm['to_rgb'])
+            dt = 1 if out_norm.dtype == torch.bfloat16 else 0
+            Hp, Wp = pad_shape
+        check(L.oadg_oamix_final(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(st.My),
+                                 ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp,
+                                 Wp, stream_ptr()), 'oadg_oamix_final')
+        return out_u8
+
+    # ------------------------------------------------------------------------------------------ dict API
+    def __call__(self, results, *args, **kwargs):
+        """oa_mix.py:187-204.  ``results['img']`` may be a uint8 HWC numpy array (uploaded, the new view is
+        returned as numpy) or a uint8 HWC cuda tensor (everything stays on the device)."""
+        img = results['img']
+        as_numpy = isinstance(img, np.ndarray)
+        dimg = torch.from_numpy(np.ascontiguousarray(img)).cuda() if as_numpy else img.contiguous()
+        if dimg.dtype != torch.uint8 or dimg.dim() != 3 or dimg.shape[2] != 3 or not dimg.is_cuda:
+            raise TypeError('OAMix expects a uint8 HxWx3 image (numpy or cuda tensor)')
+        gts = results['gt_bboxes']
+        gts = gts.detach().cpu().numpy() if isinstance(gts, torch.Tensor) else np.asarray(gts)
+        state = None
+        results['custom_field'] = []
+        for i in range(1, self.num_views + 1):
+            if i == 1:
+                self._history = {}
+                if not self.keep_orig:
+                    state = state or _ImageState(dimg, gts, self.spatial_ratio, self.sigma_ratio)
+                    out = self.oamix(state, out_u8=torch.empty_like(dimg))
+                    results['img'] = out.cpu().numpy() if as_numpy else out
+                results['img_fields'] = ['img']
+            else:
+                state = state or _ImageState(dimg, gts, self.spatial_ratio, self.sigma_ratio)
+                out = self.oamix(state, out_u8=torch.empty_like(dimg))
+                results[f'img{i}'] = out.cpu().numpy() if as_numpy else out
+                results['img_fields'] += [f'img{i}']
+                results[f'gt_bboxes{i}'] = results['gt_bboxes'].copy() if as_numpy or isinstance(
+                    results['gt_bboxes'], np.ndarray) else results['gt_bboxes'].clone()
+                results['oamix_boxes'] = np.stack(self._history['oa_random_box_list'], axis=0)
+                results['custom_field'] += [f'img{i}', f'gt_bboxes{i}', 'oamix_boxes']
+                results['multilevel_boxes'] = self._history['random_box_list']
+                results['custom_field'] += ['multilevel_boxes']
+        return results
+
+    def __repr__(self):
+        return self.__class__.__name__

@@ -112,18 +112,37 @@ def get_rotation_matrix_2d(center, angle, scale):
 
 
 # ------------------------------------------------------------------------------------------- blur / resize
+_LOG2E = 1.4426950408889634
+_LN2_HI = 6.93147180369123816490e-01
+_LN2_LO = 1.90821492927058770002e-10
+_INV_FACT = [1.0]
+for _n in range(1, 14):
+    _INV_FACT.append(_INV_FACT[-1] / _n)
+
+
+def exp_det(x):
+    """exp(x) for x <= 0 from IEEE +,-,* only (no libm): identical bits on the host and in the HIP kernel
+    (same constants, same operation order, no fused multiply-add).  |error| < 1 ulp of double."""
+    x = np.asarray(x, np.float64)
+    k = np.rint(x * _LOG2E)
+    r = (x - k * _LN2_HI) - k * _LN2_LO
+    p = np.full_like(r, _INV_FACT[13])
+    for n in range(12, -1, -1):
+        p = p * r + _INV_FACT[n]
+    return np.ldexp(p, k.astype(np.int64))
+
+
 def gaussian_kernel_f32(sigma):
     """getGaussianKernel(ksize = round(sigma*8+1)|1, sigma, CV_32F)."""
     n = int(np.rint(sigma * 4 * 2 + 1)) | 1
     scale2x = -0.5 / (sigma * sigma)
-    cf = np.empty(n, np.float32)
+    x = np.arange(n, dtype=np.float64) - (n - 1) * 0.5
+    cf = exp_det(scale2x * x * x).astype(np.float32)      # std::exp in OpenCV; see exp_det
     s = 0.0
-    for i in range(n):
-        x = i - (n - 1) * 0.5
-        cf[i] = np.float32(math.exp(scale2x * x * x))
-        s += float(cf[i])
+    for c in cf:                                           # sequential double sum, as getGaussianKernel
+        s += float(c)
     inv = 1.0 / s
-    return np.array([np.float32(float(c) * inv) for c in cf], np.float32)
+    return (cf.astype(np.float64) * inv).astype(np.float32)
 
 
 def _reflect101(i, n):
