@@ -1,0 +1,195 @@
+"""bench.py - training images/sec of the OA-DG hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one batch of synthetic Cityscapes-shaped input that is already
+resident in HBM: OA-Mix (view 2 of every image) + Normalize/Pad on the device -> Faster R-CNN R50-FPN forward
+(both views) -> RPN/RoI losses incl. OA-Loss -> backward -> (DDP all-reduce) -> SGD step.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  "roofline"     - the dominant hand-written kernel of the step, timed live with HIP events on its stream
+  "cpu_baseline" - the CPU oracle (kind "port") timed on this box's host cores on a bounded sample (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
+METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56):
+    """SURVEY.md 8d RoIAlign row, backward: read 49*C grad elements + read-modify-write of the unique fp32
+    input footprint (ceil(w_l)+1)(ceil(h_l)+1)*C on the RoI's level."""
+    w = (rois[:, 3] - rois[:, 1]).clamp(min=0)
+    h = (rois[:, 4] - rois[:, 2]).clamp(min=0)
+    lvl = torch.floor(torch.log2(torch.sqrt(w * h) / finest_scale + 1e-6)).clamp(0, len(strides) - 1).long()
+    s = torch.tensor(strides, device=rois.device, dtype=torch.float32)[lvl]
+    foot = (torch.ceil(w / s) + 1) * (torch.ceil(h / s) + 1)
+    return float((49 * C * elem + 2 * 4 * C * foot).sum().item())
+
+
+def cpu_baseline(cfg, seconds_budget=30.0):
+    """The CPU port of the step (our host logic + oracle/ ops + the OA-Mix oracle) on ONE quarter-resolution
+    image (512x1024): a bounded sample of the same workload.  value is scaled by the pixel ratio (1/4)."""
+    from oadg_amd import build_detector
+    from oadg_amd.apis import build_optimizer
+    from oadg_amd.detectors import integrate_data
+    from oracle import oamix as OO
+    from oracle.backend import oracle_ops
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from inputs import lowpass_image, synthetic_boxes
+    threads = torch.get_num_threads()
+    H, W = 512, 1024
+    rs = np.random.RandomState(0)
+    img = lowpass_image(rs, H, W)
+    gts = synthetic_boxes(rs, 20, H, W, 12, 200)
+    labels = rs.randint(0, 8, 20).astype(np.int64)
+    det = build_detector(cfg.model)
+    det.init_weights()
+    det.train()
+    opt = build_optimizer(det, cfg.optimizer)
+    mean = np.array([123.675, 116.28, 103.53], np.float32)
+    stdinv = (1.0 / np.array([58.395, 57.12, 57.375], np.float64)).astype(np.float32)
+    norm = lambda u8: torch.from_numpy(np.ascontiguousarray(  # noqa: E731
+        ((u8[..., ::-1].astype(np.float32) - mean) * stdinv).transpose(2, 0, 1)))[None]
+    np.random.seed(0)
+    torch.manual_seed(0)
+    t0 = time.time()
+    r = OO.OAMixOracle(version='augmix')(dict(img=img.copy(), gt_bboxes=gts.copy()))
+    t_mix = time.time() - t0
+    shape = (H, W, 3)
+    data = dict(img=norm(img), img2=norm(r['img2']), gt_bboxes=[torch.from_numpy(gts)],
+                gt_bboxes2=[torch.from_numpy(gts.copy())], gt_labels=[torch.from_numpy(labels)],
+                multilevel_boxes=[torch.from_numpy(np.asarray(r['multilevel_boxes']))],
+                oamix_boxes=[torch.from_numpy(np.asarray(r['oamix_boxes']))],
+                img_metas=[dict(img_shape=shape, pad_shape=shape, ori_shape=shape, scale_factor=1.0, flip=False)])
+    with oracle_ops():
+        out = det.train_step(data, None)
+        opt.zero_grad()
+        out['loss'].backward()
+        opt.step()
+    t_all = time.time() - t0
+    return dict(value=round((1.0 / t_all) * (H * W) / (1024.0 * 2048.0), 5), unit='images/s', cores=threads,
+                kind='port',
+                sample=f'1 image at {H}x{W} (1/4 of the pixels; value scaled by 1/4): OA-Mix oracle {t_mix:.1f}s + '
+                       f'detector step with oracle ops {t_all - t_mix:.1f}s, torch {threads} threads, '
+                       f'nproc={os.cpu_count()}')
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    distributed = world > 1
+    import oadg_amd
+    from oadg_amd import Config, build_detector, hip_ops
+    from oadg_amd.apis import TrainEngine, build_optimizer, init_dist, set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    if distributed:
+        init_dist('pytorch', backend='nccl')
+    rank = dist.get_rank() if distributed else 0
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    dev = torch.device('cuda', torch.cuda.current_device())
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    cfg = Config.fromfile(CFG)
+    amp = torch.bfloat16 if a.dtype == 'bf16' else None
+    set_random_seed(0)                       # identical initial weights on every rank
+    det = build_detector(cfg.model)
+    det.init_weights()
+    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    det.log_vars_on_host = False             # log_vars stay on the device (read at a log interval in training)
+    engine = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=distributed, amp_dtype=amp)
+    set_random_seed(1 + rank)                # per-rank data / augmentation streams
+    ds = SyntheticCityscapes(img_shape=(a.height, a.width), num_boxes=20, num_classes=8, seed=rank, device=dev)
+    pipe = DevicePipeline(cfg.data.train.pipeline, dtype=amp or torch.float32)
+    nb = min(a.steps + a.warmup, 6)
+    batches = [ds.batch(range(i * a.batch, (i + 1) * a.batch)) for i in range(nb)]   # resident in HBM
+    torch.cuda.synchronize()
+
+    def step(i):
+        imgs, boxes, labels = batches[i % nb]
+        return engine.step(pipe(imgs, boxes, labels))
+
+    for i in range(a.warmup):
+        out = step(i)
+    hip_ops.TIMERS = {'roi_align_bwd': []}
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    pairs = hip_ops.TIMERS['roi_align_bwd']
+    hip_ops.TIMERS = None
+    loss = float(out['loss'])
+    assert np.isfinite(loss), 'training diverged'
+    if rank != 0:
+        return
+    # ---- roofline of the dominant hand-written kernel (RoIAlign backward: atomic scatter into the fp32
+    #      pyramid gradient), HIP-event durations from the timed region
+    ms = [s.elapsed_time(e) for s, e in pairs]
+    K = 2 * a.batch * 512
+    rois = det.roi_head._last_rois if hasattr(det.roi_head, '_last_rois') else None
+    elem = 2 if amp is not None else 4
+    # per-launch algorithmic bytes: average of the two launches per step (sampled RoIs, random-proposal RoIs)
+    if rois is not None:
+        total_bytes = sum(roi_algorithmic_bytes(r, [4, 8, 16, 32], 256, elem) for r in rois)
+        per_launch = total_bytes / max(len(rois), 1)
+    else:
+        per_launch = K * 49 * 256 * elem
+    avg_ms = sum(ms) / max(len(ms), 1)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    res = {
+        'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
+        'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+        'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '
+                               f'{a.batch} img/GPU x 2 views, {a.height}x{a.width}, 20 boxes/img, SGD step',
+                   'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'final_loss': round(loss, 4)},
+        'roofline': {'kernel': 'roi_align_bwd_kernel', 'bound': 'hbm', 'achieved': round(achieved, 2),
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+                     'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
+                     'algorithmic_bytes_per_launch': int(per_launch)},
+    }
+    if a.gpus == 1 and not a.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(cfg)
+    else:
+        res['cpu_baseline'] = None
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

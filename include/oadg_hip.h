@@ -149,6 +149,14 @@ int oadg_oamix_final(const uint8_t* img, const float* acc, int H, int W, const o
 int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_host, const float* stdinv_host,
                          int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
+ *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58
+ * state624/left/next are the generator's engine words (in/out); out [k] int64.
+ */
+int oadg_host_randperm_prefix(uint64_t* state624, int* left, uint64_t* next, int64_t n, int64_t k,
+                              int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,8 +132,18 @@ class MaxIoUAssigner:
                 ig = self.iou_calculator(bboxes, gt_bboxes_ignore, mode='iof').max(dim=1)[0]
             else:
                 ig = self.iou_calculator(gt_bboxes_ignore, bboxes, mode='iof').max(dim=0)[0]
-            overlaps[:, ig > self.ignore_iof_thr] = -1
+            overlaps = overlaps.masked_fill((ig > self.ignore_iof_thr)[None, :], -1)
         return self.assign_wrt_overlaps(overlaps, gt_labels)
+
+    def assign_masked(self, bboxes, valid, gt_bboxes, gt_labels=None):
+        """assign() on the rows of ``bboxes`` flagged ``valid`` ([n] bool), without compacting them: invalid
+        rows get gt_ind -1 and take no part in the per-gt maxima, exactly as if they had been filtered out."""
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)
+        if overlaps.numel():
+            overlaps = overlaps.masked_fill(~valid[None, :], -1)
+        res = self.assign_wrt_overlaps(overlaps, gt_labels)
+        res.gt_inds = res.gt_inds.masked_fill(~valid, -1)
+        return res
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
         num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
@@ -147,9 +157,10 @@ class MaxIoUAssigner:
         max_overlaps, argmax_overlaps = overlaps.max(dim=0)
         gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
         if isinstance(self.neg_iou_thr, float):
-            gt_inds[(max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr)] = 0
+            gt_inds = gt_inds.masked_fill((max_overlaps >= 0) & (max_overlaps < self.neg_iou_thr), 0)
         elif isinstance(self.neg_iou_thr, tuple):
-            gt_inds[(max_overlaps >= self.neg_iou_thr[0]) & (max_overlaps < self.neg_iou_thr[1])] = 0
+            gt_inds = gt_inds.masked_fill((max_overlaps >= self.neg_iou_thr[0]) &
+                                          (max_overlaps < self.neg_iou_thr[1]), 0)
         pos = max_overlaps >= self.pos_iou_thr
         gt_inds = torch.where(pos, argmax_overlaps + 1, gt_inds)
         if self.match_low_quality:
@@ -208,7 +219,7 @@ class RandomSampler:
     def random_choice(gallery, num):
         assert len(gallery) >= num
         # CPU generator, then moved: the draw depends only on gallery.numel() (random_sampler.py:58)
-        perm = torch.randperm(gallery.numel())[:num].to(device=gallery.device)
+        perm = randperm_prefix(gallery.numel(), num).to(device=gallery.device)
         return gallery[perm]
 
     def _sample(self, mask, num_expected):
@@ -237,6 +248,68 @@ class RandomSampler:
             num_neg = min(num_neg, int(self.neg_pos_ub * max(1, pos_inds.numel())))
         neg_inds = self._sample(assign_result.gt_inds == 0, num_neg).unique()
         return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)
+
+
+def _pinned_to(t_cpu, device):
+    """async H2D of a small host tensor (pinned staging; never blocks the host on the stream)."""
+    if device.type != 'cuda':
+        return t_cpu.to(device)
+    return t_cpu.pin_memory().to(device, non_blocking=True)
+
+
+def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):
+    """RandomSampler.sample for a list of images with ONE device->host read.
+
+    Equivalent, image by image and in image order, to ``sampler.sample(...)`` (base_sampler.py:38-103,
+    random_sampler.py:32-82): the same candidates, the same ``torch.randperm(n)`` draws from the global CPU
+    generator (first positives, then negatives), the same sorted index lists.  The reference discovers the
+    candidate counts through ``nonzero`` (one synchronisation per call); here the counts of all images are
+    read at once, the permutations are drawn on the host and the chosen candidates are located on the
+    device through their rank among the candidates."""
+    n_img = len(assign_results)
+    prepared = []
+    for i in range(n_img):
+        ar, bboxes, gtb = assign_results[i], bboxes_list[i], gt_bboxes_list[i]
+        if len(bboxes.shape) < 2:
+            bboxes = bboxes[None, :]
+        bboxes = bboxes[:, :4]
+        gt_flags = bboxes.new_zeros((bboxes.shape[0],), dtype=torch.uint8)
+        if sampler.add_gt_as_proposals and len(gtb) > 0:
+            if gt_labels_list is None or gt_labels_list[i] is None:
+                raise ValueError('gt_labels must be given when add_gt_as_proposals is True')
+            bboxes = torch.cat([gtb, bboxes], dim=0)
+            ar.add_gt_(gt_labels_list[i])
+            gt_flags = torch.cat([bboxes.new_ones(gtb.shape[0], dtype=torch.uint8), gt_flags])
+        pos_mask, neg_mask = ar.gt_inds > 0, ar.gt_inds == 0
+        prepared.append((ar, bboxes, gt_flags, pos_mask, neg_mask))
+    if n_img == 0:
+        return []
+    dev = prepared[0][1].device
+    counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared]).tolist()   # the one read
+    num_pos_exp = int(sampler.num * sampler.pos_fraction)
+    results = []
+    for i, ((ar, bboxes, gt_flags, pos_mask, neg_mask), (n_pos, n_neg)) in enumerate(zip(prepared, counts)):
+        def choose(mask, n_cand, n_exp):
+            if n_cand <= n_exp:
+                k = n_cand
+                sel = mask
+            else:
+                k = n_exp
+                perm = _pinned_to(randperm_prefix(n_cand, n_exp), dev)       # random_sampler.py:58
+                flags = torch.zeros(mask.numel() + 1, dtype=torch.bool, device=dev)
+                flags[perm] = True
+                rank = torch.cumsum(mask, 0) - 1
+                sel = mask & flags[rank.clamp(min=0)]
+            if k == 0:
+                return torch.zeros((0,), dtype=torch.long, device=dev), 0
+            return torch.nonzero_static(sel, size=k).squeeze(1), k
+        pos_inds, k_pos = choose(pos_mask, n_pos, num_pos_exp)
+        n_neg_exp = sampler.num - k_pos
+        if sampler.neg_pos_ub >= 0:
+            n_neg_exp = min(n_neg_exp, int(sampler.neg_pos_ub * max(1, k_pos)))
+        neg_inds, _ = choose(neg_mask, n_neg, n_neg_exp)
+        results.append(SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes_list[i], ar, gt_flags))
+    return results
 
 
 # ----------------------------------------------------------------------------------------------- coder
@@ -323,3 +396,31 @@ def bbox2roi(bbox_list):
         else:
             rois.append(b.new_zeros((0, 5)))
     return torch.cat(rois, 0)
+
+
+def randperm_prefix(n, k):
+    """``torch.randperm(n)[:k]`` on the global CPU generator - same values, same generator state afterwards -
+    through the O(k) replay in csrc/host_rng.hip (ATen's shuffle touches all n entries: ~10-70 ms at the
+    RPN's n ~ 520k candidates, per image)."""
+    import ctypes
+    from .. import _lib
+    if n < 4096:
+        return torch.randperm(n)[:k]
+    L = _lib.lib()
+    st = torch.get_rng_state()
+    a = st.numpy()
+    assert a.size == 5056, 'unexpected CPU generator state layout'
+    left = ctypes.c_int(int(a[8:12].view(np.int32)[0]))
+    nxt = ctypes.c_uint64(int(a[16:24].view(np.uint64)[0]))
+    state = a[24:24 + 624 * 8].view(np.uint64).copy()
+    k = min(k, n)
+    out = np.empty(k, np.int64)
+    rc = L.oadg_host_randperm_prefix(state.ctypes.data, ctypes.byref(left), ctypes.byref(nxt), n, k,
+                                     out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError('oadg_host_randperm_prefix failed')
+    a[24:24 + 624 * 8] = state.view(np.uint8)
+    a[8:12] = np.array([left.value], np.int32).view(np.uint8)
+    a[16:24] = np.array([nxt.value], np.uint64).view(np.uint8)
+    torch.set_rng_state(st)
+    return torch.from_numpy(out)

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from . import hip_ops
 from .core import anchor_inside_flags, images_to_levels, multi_apply, unmap
+from .core.bbox import sample_many
 from .layers import Conv2d, normal_init
 from .registry import (HEADS, build_assigner, build_bbox_coder, build_loss, build_prior_generator,
                        build_sampler)
@@ -53,21 +54,30 @@ class AnchorHead(nn.Module):
         """anchor_head.py:171-199."""
         multi_level_anchors = self.prior_generator.grid_priors(featmap_sizes, device=device)
         anchor_list = [multi_level_anchors for _ in range(len(img_metas))]
+        # valid_flags only depend on shapes: when the padded image covers every feature-map cell, every anchor
+        # is valid and the boolean filtering of the reference (a device->host synchronisation) is a no-op
+        self._all_anchors_valid = all(
+            min(int(-(-m['pad_shape'][0] // s[1])), fs[0]) == fs[0] and
+            min(int(-(-m['pad_shape'][1] // s[0])), fs[1]) == fs[1]
+            for m in img_metas for fs, s in zip(featmap_sizes, self.prior_generator.strides))
         valid_flag_list = [self.prior_generator.valid_flags(featmap_sizes, m['pad_shape'], device)
                            for m in img_metas]
         return anchor_list, valid_flag_list
 
     def _get_targets_single(self, flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore, gt_labels,
-                            img_meta, label_channels=1, unmap_outputs=True):
+                            img_meta, sampling_result=None, label_channels=1, unmap_outputs=True):
         """anchor_head.py:201-297."""
-        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
-                                           self.train_cfg.allowed_border)
-        if not inside_flags.any():
-            return (None,) * 7
-        anchors = flat_anchors[inside_flags, :]
-        assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore,
-                                             None if self.sampling else gt_labels)
-        sampling_result = self.sampler.sample(assign_result, anchors, gt_bboxes)
+        if sampling_result is None:     # reference order of operations: filter, assign, sample (synchronising)
+            inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                               self.train_cfg.allowed_border)
+            if not inside_flags.any():
+                return (None,) * 7
+            anchors = flat_anchors[inside_flags, :]
+            assign_result = self.assigner.assign(anchors, gt_bboxes, gt_bboxes_ignore,
+                                                 None if self.sampling else gt_labels)
+            sampling_result = self.sampler.sample(assign_result, anchors, gt_bboxes)
+        else:                           # all anchors valid, already assigned + sampled for the whole batch
+            inside_flags, anchors = None, flat_anchors
         n = anchors.shape[0]
         bbox_targets = torch.zeros_like(anchors)
         bbox_weights = torch.zeros_like(anchors)
@@ -88,7 +98,7 @@ class AnchorHead(nn.Module):
             label_weights[pos_inds] = 1.0 if self.train_cfg.pos_weight <= 0 else self.train_cfg.pos_weight
         if len(neg_inds) > 0:
             label_weights[neg_inds] = 1.0
-        if unmap_outputs:
+        if unmap_outputs and inside_flags is not None:
             total = flat_anchors.size(0)
             labels = unmap(labels, total, inside_flags, fill=self.num_classes)
             label_weights = unmap(label_weights, total, inside_flags)
@@ -108,8 +118,16 @@ class AnchorHead(nn.Module):
             gt_bboxes_ignore_list = [None] * num_imgs
         if gt_labels_list is None:
             gt_labels_list = [None] * num_imgs
+        fast = (getattr(self, '_all_anchors_valid', False) and self.train_cfg.allowed_border < 0 and
+                all(g is None for g in gt_bboxes_ignore_list) and hasattr(self.sampler, 'random_choice'))
+        if fast:   # one host read for the whole batch instead of ~6 per image
+            ars = [self.assigner.assign(concat_anchors[i], gt_bboxes_list[i], None,
+                                        None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]
+            srs = sample_many(self.sampler, ars, concat_anchors, gt_bboxes_list)
+        else:
+            srs = [None] * num_imgs
         results = multi_apply(self._get_targets_single, concat_anchors, concat_flags, gt_bboxes_list,
-                              gt_bboxes_ignore_list, gt_labels_list, img_metas,
+                              gt_bboxes_ignore_list, gt_labels_list, img_metas, srs,
                               label_channels=label_channels, unmap_outputs=unmap_outputs)
         all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, pos_l, neg_l, _ = results[:7]
         if any(l is None for l in all_labels):
@@ -158,18 +176,19 @@ class AnchorHead(nn.Module):
         return multi_apply(self.forward_single, feats)
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
-                      proposal_cfg=None, num_proposal_imgs=None, **kwargs):
+                      proposal_cfg=None, num_proposal_imgs=None, padded_proposals=False, **kwargs):
         """base_dense_head.py:302-342.  ``num_proposal_imgs`` limits proposal generation to the first images
         (the contrastive RoI head only consumes the view-1 lists, contrastive_roi_head.py:85-95)."""
         outs = self(x)
-        if gt_labels is None:
-            losses = self.loss(*outs, gt_bboxes, None, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
-        else:
-            losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        # proposals are enqueued before the loss so that the RoI head's host read (candidate counts) only
+        # waits for the NMS, while the device is still busy with the RPN loss kernels
+        proposal_list = None
+        if proposal_cfg is not None:
+            proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
+                                            num_imgs=num_proposal_imgs, padded=padded_proposals)
+        losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
         if proposal_cfg is None:
             return losses
-        proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
-                                        num_imgs=num_proposal_imgs)
         return losses, proposal_list
 
 
@@ -203,7 +222,8 @@ class RPNHead(AnchorHead):
         return dict(loss_rpn_cls=losses['loss_cls'], loss_rpn_bbox=losses['loss_bbox'])
 
     @torch.no_grad()
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, num_imgs=None, **kwargs):
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, num_imgs=None, padded=False,
+                   **kwargs):
         """base_dense_head.py:31-106 + rpn_head.py:103-235, batched over images.
 
         Per image and level: stable descending sort, top nms_pre, decode against the anchors, drop
@@ -260,9 +280,20 @@ class RPNHead(AnchorHead):
         boxes_sorted = torch.gather(props + offs[..., None], 1, order[..., None].expand(-1, -1, 4))
         counts = valid.sum(dim=1).int()
         keep, keep_cnt = hip_ops.nms_sorted_batched(boxes_sorted, counts, thr, cfg.max_per_img)
-        cnt = keep_cnt.tolist()                      # one host read for the whole batch
-        out = []
-        for i in range(n_img):
-            sel = order[i, keep[i, :cnt[i]].long()]
-            out.append(torch.cat([props[i, sel], scores[i, sel, None]], dim=1))
-        return out
+        P = min(cfg.max_per_img, M) if cfg.max_per_img > 0 else M
+        if not padded:
+            cnt = keep_cnt.tolist()                  # one host read for the whole batch
+            out = []
+            for i in range(n_img):
+                sel = order[i, keep[i, :cnt[i]].long()]
+                out.append(torch.cat([props[i, sel], scores[i, sel, None]], dim=1))
+            return out
+        # fixed-size lists without any host read: rows past the kept count are zero boxes with score -1
+        kidx = keep[:, :P].long().clamp(0, M - 1)
+        sel = torch.gather(order, 1, kidx)
+        live = torch.arange(P, device=device)[None, :] < keep_cnt[:, None]
+        pb = torch.gather(props, 1, sel[..., None].expand(-1, -1, 4))
+        ps = torch.gather(scores, 1, sel)
+        dets = torch.cat([torch.where(live[..., None], pb, pb.new_zeros(())),
+                          torch.where(live, ps, ps.new_full((), -1.0))[..., None]], dim=2)
+        return list(dets.unbind(0))

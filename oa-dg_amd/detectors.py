@@ -152,12 +152,16 @@ class TwoStageDetector(BaseDetector):
             n_prop = kwargs['batch_size'] if 'num_views' in kwargs else None
             rpn_losses, proposal_list = self.rpn_head.forward_train(
                 x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
-                proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop)
+                proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop, padded_proposals=True)
             losses.update(rpn_losses)
         else:
             proposal_list = proposals
         if 'random_proposal_cfg' in self.train_cfg.keys():
+            host_gts = [m.get('gt_bboxes_np') for m in img_metas]
+            if all(g is not None for g in host_gts):
+                kwargs['img_metas_host'] = host_gts
             kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
+            kwargs.pop('img_metas_host', None)
         losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
                                                   gt_bboxes_ignore, gt_masks, **kwargs))
         return losses
@@ -173,7 +177,11 @@ class TwoStageDetector(BaseDetector):
         assert cfg['bbox_from'] == 'oagrb', 'oagrb is required'
         assert 'multilevel_bboxes' in kwargs or 'oamix_boxes' in kwargs, 'boxes are required'
         device = img.device
-        gts = [g.detach().cpu().numpy() for g in gt_bboxes]   # one host copy of the gts per step
+        metas = kwargs.get('img_metas_host')
+        if metas is not None:     # the data pipeline kept the host copies of the gt boxes: no device read
+            gts = [np.asarray(g, dtype=np.float32) for g in metas]
+        else:
+            gts = [g.detach().cpu().numpy() for g in gt_bboxes]
         out = []
         for b in kwargs.get('multilevel_boxes', []):
             b = b.to(torch.float32).cpu().numpy()

@@ -12,6 +12,22 @@ from . import _lib
 from ._lib import check, ptr, require_cuda, stream_ptr
 
 
+# kernel name -> list of (start, end) torch.cuda.Event pairs recorded around that C-ABI call on the current
+# stream; filled only while bench.py sets TIMERS to a dict (live HIP-event timing of the timed region)
+TIMERS = None
+
+
+def _timed(name, fn, *args):
+    if TIMERS is None or name not in TIMERS:
+        return fn(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = fn(*args)
+    b.record()
+    TIMERS[name].append((a, b))
+    return rc
+
+
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 8), dtype=torch.uint8, device=device)
 
@@ -134,9 +150,9 @@ class _RoIAlignFPN(torch.autograd.Function):
         out = torch.empty((K, C, PH, PW), dtype=dt, device=rois.device,
                           memory_format=torch.channels_last)
         P, Hs, Ws, Ss = _pyramid_args(feats, scales)
-        check(L.oadg_roi_align_fwd(P, Hs, Ws, Ss, len(feats), N, C, 0 if dt == torch.float32 else 1,
-                                   float(finest_scale), ptr(rois), K, PH, PW, int(sampling_ratio),
-                                   int(bool(aligned)), ptr(out), stream_ptr()), 'oadg_roi_align_fwd')
+        check(_timed('roi_align_fwd', L.oadg_roi_align_fwd, P, Hs, Ws, Ss, len(feats), N, C,
+                     0 if dt == torch.float32 else 1, float(finest_scale), ptr(rois), K, PH, PW,
+                     int(sampling_ratio), int(bool(aligned)), ptr(out), stream_ptr()), 'oadg_roi_align_fwd')
         ctx.save_for_backward(rois)
         ctx.meta = ([tuple(f.shape) for f in feats], dt, tuple(scales), float(finest_scale),
                     int(sampling_ratio), int(bool(aligned)), (PH, PW))
@@ -154,9 +170,9 @@ class _RoIAlignFPN(torch.autograd.Function):
                              memory_format=torch.channels_last).zero_() for s in shapes]
         N, C = shapes[0][:2]
         P, Hs, Ws, Ss = _pyramid_args(grads, scales)
-        check(L.oadg_roi_align_bwd(P, Hs, Ws, Ss, len(grads), N, C, 0 if dt == torch.float32 else 1,
-                                   finest_scale, ptr(rois), rois.shape[0], PH, PW, sampling_ratio,
-                                   aligned, ptr(gout), stream_ptr()), 'oadg_roi_align_bwd')
+        check(_timed('roi_align_bwd', L.oadg_roi_align_bwd, P, Hs, Ws, Ss, len(grads), N, C,
+                     0 if dt == torch.float32 else 1, finest_scale, ptr(rois), rois.shape[0], PH, PW,
+                     sampling_ratio, aligned, ptr(gout), stream_ptr()), 'oadg_roi_align_bwd')
         grads = [g if dt == torch.float32 else g.to(dt) for g in grads]
         return (None, None, None, None, None, None, *grads)
 

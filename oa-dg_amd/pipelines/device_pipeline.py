@@ -105,10 +105,15 @@ class DevicePipeline:
                                          dt, Hp, Wp, stream_ptr()), 'oadg_oamix_normalize')
         out['img'] = img
         shape, pshape = (H, W, 3), (Hp, Wp, 3)
-        out['img_metas'] = [dict(img_shape=shape, pad_shape=pshape, ori_shape=shape, scale_factor=1.0, flip=False)
-                            for _ in range(N)]
-        out['gt_bboxes'] = [torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(dev) for b in gt_bboxes]
-        out['gt_labels'] = [torch.from_numpy(np.ascontiguousarray(l, dtype=np.int64)).to(dev) for l in gt_labels]
+        # the host copies of the gt boxes travel in img_metas: the random-proposal generator and OA-Mix need
+        # them on the host, and reading them back from the device would stall the stream
+        out['img_metas'] = [dict(img_shape=shape, pad_shape=pshape, ori_shape=shape, scale_factor=1.0, flip=False,
+                                 gt_bboxes_np=np.ascontiguousarray(gt_bboxes[i], dtype=np.float32))
+                            for i in range(N)]
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).pin_memory().to(  # noqa: E731
+            dev, non_blocking=True)
+        out['gt_bboxes'] = [up(b, np.float32) for b in gt_bboxes]
+        out['gt_labels'] = [up(l, np.int64) for l in gt_labels]
         if self.oamix is not None and self.oamix.num_views > 1:
             assert self.oamix.num_views == 2 and self.oamix.keep_orig
             om = self.oamix

@@ -94,6 +94,11 @@ def geo_matrix(kind, severity, img_size, center=None, size_for_level=None):
     return np.float32([[1, 0, -lvl], [0, 1, 0]]) if ax == 0 else np.float32([[1, 0, 0], [0, 1, -lvl]])
 
 
+def _upload(arr, device):
+    """small host array -> device without blocking the host on the stream (pinned staging)."""
+    return torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(device, non_blocking=True)
+
+
 class _ImageState:
     """Device-side state of one image: profiles of the fg masks, their union, saliency scores (async)."""
 
@@ -124,8 +129,8 @@ class _ImageState:
         self.union_f = torch.empty((H, W), dtype=torch.float32, device=dev)
         self.union_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
         if n:
-            self._qbox = torch.from_numpy(qbox).to(dev)
-            self._sigma = torch.from_numpy(sigma).to(dev)
+            self._qbox = _upload(qbox, dev)
+            self._sigma = _upload(sigma, dev)
             check(L.oadg_oamix_box_profiles(ptr(self._qbox), ptr(self._sigma), n, H, W, spatial_ratio,
                                             ptr(self.My), ptr(self.Mx), stream_ptr()), 'oadg_oamix_box_profiles')
         check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
@@ -134,7 +139,7 @@ class _ImageState:
         self._scores = None
         if n:
             ib = np.array(self.gt, dtype=np.int32)
-            self._ibox = torch.from_numpy(ib).to(dev)
+            self._ibox = _upload(ib, dev)
             self._scores_dev = torch.empty((n,), dtype=torch.float64, device=dev)
             check(L.oadg_oamix_saliency(ptr(img), H, W, ptr(self._ibox), n, spatial_ratio,
                                         ptr(self._scores_dev), stream_ptr()), 'oadg_oamix_saliency')
@@ -345,7 +350,7 @@ class OAMix:
         for t, (idx, rect, score) in enumerate(targets):
             hi = 0.5 if score <= self.score_thresh else 1.0
             tg[t] = (idx, rect, np.float32(np.random.uniform(0.0, hi)))
-        tg_dev = torch.from_numpy(tg.view(np.uint8).reshape(-1)).to(st.img.device) if len(targets) else None
+        tg_dev = _upload(tg.view(np.uint8).reshape(-1), st.img.device) if len(targets) else None
         mean = stdinv = None
         to_rgb, dt, Hp, Wp = 0, 0, H, W
         if out_norm is not None:

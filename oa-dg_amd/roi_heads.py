@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from . import hip_ops
 from .core import bbox2roi, multi_apply
+from .core.bbox import sample_many
 from .layers import normal_init, xavier_init
 from .losses import accuracy
 from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_bbox_coder, build_head,
@@ -128,13 +129,27 @@ class BBoxHead(nn.Module):
 
     # -- loss ------------------------------------------------------------------------------------------
     def _cls_reg_losses(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
-                        avg_factor, reduction_override=None):
+                        avg_factor, reduction_override=None, pos_rows=None):
         losses = dict()
         if cls_score is not None and cls_score.numel() > 0:
             losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
                                                reduction_override=reduction_override)
             losses['acc'] = accuracy(cls_score, labels)
-        if bbox_pred is not None:
+        if bbox_pred is not None and pos_rows is not None:
+            # positives are the leading rows of every image block: their indices are known on the host
+            if pos_rows.numel() > 0:
+                from .core.bbox import _pinned_to
+                pr = _pinned_to(pos_rows, bbox_pred.device)
+                if self.reg_class_agnostic:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), 4)[pr]
+                else:
+                    pos_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pr, labels[pr]]
+                losses['loss_bbox'] = self.loss_bbox(pos_pred, bbox_targets[pr], bbox_weights[pr],
+                                                     avg_factor=bbox_targets.size(0),
+                                                     reduction_override=reduction_override)
+            else:
+                losses['loss_bbox'] = bbox_pred[:0].sum()
+        elif bbox_pred is not None:
             bg = self.num_classes
             pos = (labels >= 0) & (labels < bg)
             if pos.any():
@@ -150,11 +165,16 @@ class BBoxHead(nn.Module):
         return losses
 
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
-             reduction_override=None, **kwargs):
-        """bbox_head.py:397-...: avg_factor = #(label_weights > 0) (one host read, as the reference)."""
-        avg = max(torch.sum(label_weights > 0).float().item(), 1.) if cls_score is not None else None
-        return self._cls_reg_losses(cls_score.float(), bbox_pred.float(), labels, label_weights, bbox_targets,
-                                    bbox_weights, avg, reduction_override)
+             reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):
+        """bbox_head.py:397-...: avg_factor = #(label_weights > 0)."""
+        avg = None
+        if cls_score is not None:
+            avg = max(float(num_sampled), 1.) if num_sampled is not None else \
+                max(torch.sum(label_weights > 0).float().item(), 1.)
+        return self._cls_reg_losses(cls_score.float() if cls_score is not None else None,
+                                    bbox_pred.float() if bbox_pred is not None else None, labels,
+                                    label_weights, bbox_targets, bbox_weights, avg, reduction_override,
+                                    pos_rows=pos_rows)
 
 
 class ConvFCBBoxHead(BBoxHead):
@@ -254,12 +274,17 @@ class Shared2FCContrastiveHead(ConvFCBBoxHead):
                 self.fc_cont(x) if self.with_cont else None)
 
     def loss(self, cls_score, bbox_pred, cont_feats, rois, labels, label_weights, bbox_targets, bbox_weights,
-             bbox_absolute_targets=None, reduction_override=None, **kwargs):
-        """contrastive_head.py:60-138."""
-        avg = max(torch.sum(label_weights > 0).float().item(), 1.) if cls_score is not None else None
+             bbox_absolute_targets=None, reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):
+        """contrastive_head.py:60-138.  ``num_sampled`` / ``pos_rows`` (host-side facts about the sampling
+        results) replace the reference's two device reads: every sampled row has label weight 1."""
+        avg = None
+        if cls_score is not None:
+            avg = max(float(num_sampled), 1.) if num_sampled is not None else \
+                max(torch.sum(label_weights > 0).float().item(), 1.)
         losses = self._cls_reg_losses(cls_score.float() if cls_score is not None else None,
                                       bbox_pred.float() if bbox_pred is not None else None, labels,
-                                      label_weights, bbox_targets, bbox_weights, avg, reduction_override)
+                                      label_weights, bbox_targets, bbox_weights, avg, reduction_override,
+                                      pos_rows=pos_rows)
         labels = labels.contiguous().view(-1, 1)
         if cont_feats is not None and cont_feats.numel() > 0:
             # The reference adds the key only when #foreground > min_samples (a host-side branch on device
@@ -292,11 +317,32 @@ class StandardRoIHead(BaseRoIHead):
     """standard_roi_head.py:11-200 (bbox branch)."""
 
     def _assign_and_sample(self, x, n, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore):
+        """Per image: MaxIoU assign + RandomSampler (standard_roi_head.py:88-101).  Proposal lists may be
+        padded to a fixed length with score -1 rows (RPNHead.get_bboxes(padded=True)); those rows are never
+        candidates.  All images share one host read of the candidate counts."""
+        if all(g is None for g in gt_bboxes_ignore[:n]) and hasattr(self.bbox_sampler, 'random_choice') and \
+                hasattr(self.bbox_assigner, 'assign_masked'):
+            ars = []
+            for i in range(n):
+                p = proposal_list[i]
+                valid = p[:, 4] >= 0 if p.size(1) == 5 else torch.ones_like(p[:, 0], dtype=torch.bool)
+                ars.append(self.bbox_assigner.assign_masked(p[:, :4], valid, gt_bboxes[i], gt_labels[i]))
+            return sample_many(self.bbox_sampler, ars, proposal_list[:n], gt_bboxes[:n], gt_labels[:n])
         out = []
         for i in range(n):
             ar = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
             out.append(self.bbox_sampler.sample(ar, proposal_list[i], gt_bboxes[i], gt_labels[i]))
         return out
+
+    @staticmethod
+    def _host_counts(sampling_results):
+        """(#sampled rows, flat row indices of the positives) from shapes only - no device read."""
+        total, rows = 0, []
+        for r in sampling_results:
+            npos, nneg = r.pos_inds.numel(), r.neg_inds.numel()
+            rows.append(torch.arange(total, total + npos))
+            total += npos + nneg
+        return total, (torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long))
 
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
                       gt_masks=None, **kwargs):
@@ -324,7 +370,9 @@ class StandardRoIHead(BaseRoIHead):
         rois = bbox2roi([r.bboxes for r in sampling_results])
         res = self._bbox_forward(x, rois)
         targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
-        res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], rois, *targets))
+        num_sampled, pos_rows = self._host_counts(sampling_results)
+        res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], rois, *targets,
+                                                 num_sampled=num_sampled, pos_rows=pos_rows))
         return res
 
 
@@ -341,13 +389,17 @@ class ContrastiveRoIHead(StandardRoIHead):
                             gt_instance_inds=None, **kwargs):
         rois = bbox2roi([r.bboxes for r in sampling_results])
         res = self._bbox_forward(x, rois)
+        self._last_rois = [rois.detach()]
         if 'random_proposal_list' in kwargs:
             rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
             res2 = self._bbox_forward(x, rois2)
             res['cont_feats'] = torch.cat([res['cont_feats'], res2['cont_feats']], dim=0)
+            self._last_rois.append(rois2.detach())
         targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
                                                            self.train_cfg)
         self.bbox_targets = targets
+        num_sampled, pos_rows = self._host_counts(sampling_results)
         res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], res['cont_feats'], rois,
-                                                 *targets, **kwargs))
+                                                 *targets, num_sampled=num_sampled, pos_rows=pos_rows,
+                                                 **kwargs))
         return res

@@ -62,7 +62,7 @@ def test_state_dict_layout_and_param_counts(golden_dir):
 
 
 def test_host_logic_reproduces_reference_step(golden_dir):
-    from oracle_backend import oracle_ops
+    from oracle.backend import oracle_ops
     g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
     det = build_and_load()
     data = make_data(g)
