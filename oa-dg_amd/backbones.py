@@ -3,7 +3,7 @@ mmdet/models/utils/res_layer.py).  Frozen stem + stage 1, BN always in eval mode
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
-from .layers import Conv2d, build_norm_layer, constant_init, kaiming_init
+from .layers import Conv2d, build_norm_layer, constant_init, conv_bn, kaiming_init
 from .registry import BACKBONES
 
 
@@ -27,11 +27,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = self.relu(conv_bn(x, self.conv1, self.bn1))
+        out = self.relu(conv_bn(out, self.conv2, self.bn2))
+        out = conv_bn(out, self.conv3, self.bn3)
         if self.downsample is not None:
-            identity = self.downsample(x)
+            identity = conv_bn(x, self.downsample[0], self.downsample[1])
         out += identity
         return self.relu(out)
 
@@ -109,7 +109,7 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.relu(conv_bn(x, self.conv1, self.bn1)))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

@@ -141,6 +141,12 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const flo
     }
 }
 
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const unsigned short* p) { return bf16_to_f32(*p); }
+
+// Backward: scatter g/count to the four corners of every sample (atomic fp32 adds into the level's gradient
+// map).  Lane l owns channels l, l+64, l+128, l+192 of a 256-channel group, so each wave-wide atomic covers
+// 256 contiguous bytes (two cache lines) of one pixel instead of 64 words strided over 1 KiB.
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const float* __restrict__ rois,
                                                             int K, int PH, int PW, int sampling_ratio,
@@ -154,8 +160,13 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const flo
     float* base = p.dfeat[g.lvl] + (size_t)g.batch * H * W * C;
     for (int bin = wave; bin < PH * PW; bin += 4) {
         const int ph = bin / PW, pw = bin - ph * PW;
-        for (int c0 = lane * 4; c0 < C; c0 += 256) {
-            const f32x4 gv = load4(gout + ((size_t)k * PH * PW + bin) * C + c0) / g.count;
+        for (int cb = 0; cb < C; cb += 256) {
+            float gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = cb + lane + 64 * j;
+                gv[j] = c < C ? load1(gout + ((size_t)k * PH * PW + bin) * C + c) / g.count : 0.f;
+            }
             for (int iy = 0; iy < g.grid_h; ++iy) {
                 const float y = g.start_h + ph * g.bin_h + (iy + 0.5f) * g.bin_h / (float)g.grid_h;
                 for (int ix = 0; ix < g.grid_w; ++ix) {
@@ -164,10 +175,12 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const flo
                     if (!s.in) continue;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        unsafeAtomicAdd(base + (size_t)s.o1 * C + c0 + j, gv[j] * s.w1);
-                        unsafeAtomicAdd(base + (size_t)s.o2 * C + c0 + j, gv[j] * s.w2);
-                        unsafeAtomicAdd(base + (size_t)s.o3 * C + c0 + j, gv[j] * s.w3);
-                        unsafeAtomicAdd(base + (size_t)s.o4 * C + c0 + j, gv[j] * s.w4);
+                        const int c = cb + lane + 64 * j;
+                        if (c >= C) continue;
+                        unsafeAtomicAdd(base + (size_t)s.o1 * C + c, gv[j] * s.w1);
+                        unsafeAtomicAdd(base + (size_t)s.o2 * C + c, gv[j] * s.w2);
+                        unsafeAtomicAdd(base + (size_t)s.o3 * C + c, gv[j] * s.w3);
+                        unsafeAtomicAdd(base + (size_t)s.o4 * C + c, gv[j] * s.w4);
                     }
                 }
             }

@@ -32,6 +32,35 @@ class Conv2d(nn.Conv2d):
         return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
 
 
+# Frozen-statistics BatchNorm (norm_eval=True: every BN of the detector, resnet.py:648-657) is a per-channel
+# affine map, so it is folded into the preceding convolution: y = conv(x, W * s) + t with
+# s = gamma / sqrt(var + eps), t = beta - mean * s.  The activation-sized BN forward/backward passes (and the
+# two extra reads of dy and x that autograd's batch_norm backward needs for d(gamma), d(beta)) disappear;
+# d(gamma) and d(beta) come out of the weight-sized products and the convolution's bias gradient.
+FOLD_EVAL_BN = True
+
+
+def conv_bn(x, conv, bn):
+    """bn(conv(x)) for a BatchNorm in eval mode, folded; falls back to the two-step form otherwise."""
+    if not FOLD_EVAL_BN or bn.training or conv.bias is not None:
+        return bn(conv(x))
+    frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)
+    key = None
+    if frozen:   # constant until the parameters/buffers are overwritten: fold once
+        key = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+               bn.running_var._version, conv.weight.device, conv.weight.data_ptr())
+        cached = getattr(conv, '_folded', None)
+        if cached is not None and cached[0] == key:
+            return conv2d(x, cached[1], cached[2], conv.stride, conv.padding, conv.dilation)
+    scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+    w = conv.weight * scale.view(-1, 1, 1, 1)
+    b = bn.bias - bn.running_mean * scale
+    if frozen:
+        w, b = w.detach(), b.detach()
+        conv._folded = (key, w, b)
+    return conv2d(x, w, b, conv.stride, conv.padding, conv.dilation)
+
+
 def build_norm_layer(cfg, num_features, postfix=''):
     """mmcv.cnn.build_norm_layer for BN: returns (name, layer); ``requires_grad`` from the cfg."""
     cfg = dict(cfg)
