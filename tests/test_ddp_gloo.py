@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (one process per device, gradient all-reduce by DDP,
+packed log-var all-reduce) - SURVEY.md 8e.  The HIP entry points are swapped for the oracle (no GPU here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(3)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import oadg_amd  # noqa: F401
+    from oadg_amd import Config, build_detector
+    from oadg_amd.apis import TrainEngine, build_optimizer, set_random_seed
+    from oracle.backend import oracle_ops
+    from inputs import model_batch
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
+    set_random_seed(0)
+    det = build_detector(cfg.model)
+    det.init_weights()
+    det.train()
+    eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=True)
+    b = model_batch(10 + rank, 1, 192, 320, n_gt=6)          # different data on each rank
+    shape = b['img'].shape[2:] + (3,)
+    t = torch.tensor
+    data = dict(img=t(b['img']), img2=t(b['img2']), gt_bboxes=[t(x) for x in b['gt_bboxes']],
+                gt_bboxes2=[t(x) for x in b['gt_bboxes']], gt_labels=[t(x) for x in b['gt_labels']],
+                multilevel_boxes=[t(x) for x in b['multilevel_boxes']], oamix_boxes=[t(x) for x in b['oamix_boxes']],
+                img_metas=[dict(img_shape=shape, pad_shape=shape, ori_shape=shape, scale_factor=1.0, flip=False)])
+    set_random_seed(1 + rank)
+    w0 = det.roi_head.bbox_head.fc_cls.weight.detach().clone()
+    with oracle_ops():
+        out = eng.step(data)
+    p = torch.cat([q_.detach().flatten()[:64] for q_ in det.parameters() if q_.requires_grad])
+    g = det.roi_head.bbox_head.fc_cls.weight.grad.detach().flatten()[:256].clone()
+    lv = out['log_vars']
+    q.put((rank, p.numpy(), g.numpy(), dict(lv), float(out['loss']),
+           bool((det.roi_head.bbox_head.fc_cls.weight.detach() != w0).any())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_data_parallel_step():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=540) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p0, g0, lv0, l0, ch0), (_, p1, g1, lv1, l1, ch1) = res
+    assert ch0 and ch1, 'the optimizer step changed nothing'
+    assert np.array_equal(g0, g1), 'gradients were not all-reduced to the same mean'
+    assert np.array_equal(p0, p1), 'parameters diverged across ranks'
+    assert l0 != l1, 'ranks saw different data, their local losses must differ'
+    assert lv0.keys() == lv1.keys()
+    for k in lv0:                      # log vars are the cross-rank means (base.py:270-275)
+        assert abs(lv0[k] - lv1[k]) <= 1e-6 * max(1.0, abs(lv0[k])), k
+    assert abs(lv0['loss'] - 0.5 * (l0 + l1)) <= 1e-5 * abs(lv0['loss'])

@@ -1,0 +1,155 @@
+#!/usr/bin/env python
+"""Train a detector: the reference's entry point (tools/train.py:22-207) for the MI355X build.
+
+    python tools/train.py CONFIG [--work-dir D] [--resume-from F] [--auto-resume] [--no-validate]
+                          [--gpus N | --gpu-ids I ...] [--seed S] [--deterministic]
+                          [--cfg-options k=v ...] [--launcher none|pytorch|slurm|mpi] [--local_rank R]
+                          [--debug_mode] [--max-iters N]
+
+CONFIG may be one of this repo's configs (configs/oadg/*.py) or an unmodified reference config (its
+``/ws/external/...`` bases are resolved against the tree the config lives in, or $OADG_CONFIG_ROOT).
+Datasets other than ``SyntheticCityscapes`` are out of scope of this build: a reference
+config's dataset section is replaced by the synthetic Cityscapes-shaped source while its pipeline (OAMix,
+Normalize, Pad, Collect keys) is honoured.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class DictAction(argparse.Action):
+    """key=value pairs -> dict (mmcv.DictAction): ints/floats/bools/lists/tuples are parsed."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        opts = {}
+        for kv in values:
+            k, v = kv.split('=', maxsplit=1)
+            opts[k] = v
+        setattr(namespace, self.dest, opts)
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description='Train a detector')
+    p.add_argument('config', help='train config file path')
+    p.add_argument('--work-dir', help='the dir to save logs and models')
+    p.add_argument('--resume-from', help='the checkpoint file to resume from')
+    p.add_argument('--auto-resume', action='store_true', help='resume from the latest checkpoint automatically')
+    p.add_argument('--no-validate', action='store_true', help='accepted for compatibility (evaluation is out of scope)')
+    g = p.add_mutually_exclusive_group()
+    g.add_argument('--gpus', type=int, help='number of gpus to use (only applicable to non-distributed training)')
+    g.add_argument('--gpu-ids', type=int, nargs='+', help='ids of gpus to use (non-distributed training)')
+    p.add_argument('--seed', type=int, default=None, help='random seed')
+    p.add_argument('--deterministic', action='store_true')
+    p.add_argument('--options', nargs='+', action=DictAction, help='deprecated alias of --cfg-options')
+    p.add_argument('--cfg-options', nargs='+', action=DictAction, help='override config entries, key=value')
+    p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none')
+    p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--debug_mode', action='store_true')
+    p.add_argument('--max-iters', type=int, default=None, help='stop after this many iterations (smoke runs)')
+    p.add_argument('--amp', default='bf16', choices=['bf16', 'none'])
+    a = p.parse_args()
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['LOCAL_RANK'] = str(a.local_rank)
+    if a.options and a.cfg_options:
+        raise ValueError('--options and --cfg-options cannot be both specified')
+    if a.options:
+        a.cfg_options = a.options
+    return a
+
+
+def latest_checkpoint(work_dir):
+    """mmdet/utils/misc.py:7-38 find_latest_checkpoint."""
+    if not work_dir or not os.path.isdir(work_dir):
+        return None
+    if os.path.exists(os.path.join(work_dir, 'latest.pth')):
+        return os.path.join(work_dir, 'latest.pth')
+    cks = [f for f in os.listdir(work_dir) if f.endswith('.pth')]
+    return os.path.join(work_dir, max(cks, key=lambda f: os.path.getmtime(os.path.join(work_dir, f)))) if cks else None
+
+
+def main():
+    a = parse_args()
+    import oadg_amd
+    from oadg_amd import Config, build_detector
+    from oadg_amd.apis import (TrainEngine, StepLrSchedule, build_optimizer, get_dist_info, init_dist,
+                               init_random_seed, set_random_seed)
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    cfg = Config.fromfile(a.config)
+    if a.cfg_options:
+        cfg.merge_from_dict(a.cfg_options)
+    work_dir = a.work_dir or cfg.get('work_dir') or os.path.join('./work_dirs',
+                                                                 os.path.splitext(os.path.basename(a.config))[0])
+    distributed = a.launcher != 'none'
+    if distributed:
+        init_dist(a.launcher, **cfg.get('dist_params', dict(backend='nccl')))
+    rank, world = get_dist_info()
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
+    dev = torch.device('cuda', torch.cuda.current_device())
+    os.makedirs(work_dir, exist_ok=True)
+    seed = init_random_seed(a.seed, device=dev)
+    set_random_seed(seed, deterministic=a.deterministic)
+    model = build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    model.init_weights()
+    model = model.to(dev).to(memory_format=torch.channels_last).train()
+    resume = a.resume_from or (latest_checkpoint(work_dir) if a.auto_resume else None) or cfg.get('resume_from')
+    start_iter = 0
+    optimizer = build_optimizer(model, cfg.optimizer)
+    load_from = cfg.get('load_from')
+    if resume:
+        ck = torch.load(resume, map_location=dev)
+        model.load_state_dict(ck['state_dict'])
+        if 'optimizer' in ck:
+            optimizer.load_state_dict(ck['optimizer'])
+        start_iter = ck.get('meta', {}).get('iter', 0)
+    elif load_from and os.path.exists(str(load_from)):
+        ck = torch.load(load_from, map_location=dev)   # mmdet checkpoints: {'state_dict': ...}; same key names
+        missing, unexpected = model.load_state_dict(ck.get('state_dict', ck), strict=False)
+        if rank == 0:
+            print(f'loaded {load_from}: {len(missing)} missing / {len(unexpected)} unexpected keys')
+    amp = torch.bfloat16 if a.amp == 'bf16' else None
+    engine = TrainEngine(model, optimizer, distributed=distributed, amp_dtype=amp,
+                         find_unused_parameters=cfg.get('find_unused_parameters', False))
+    sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
+    dcfg = cfg.data.train
+    while 'dataset' in dcfg and dcfg.get('type') in ('RepeatDataset',):
+        dcfg = dcfg.dataset
+    ds_args = {k: v for k, v in dcfg.items() if k in ('img_shape', 'num_boxes', 'num_classes', 'length', 'box_size')}
+    ds = SyntheticCityscapes(seed=seed + rank, device=dev, **ds_args)
+    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32)
+    bs = cfg.data.get('samples_per_gpu', 2)
+    epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
+    iters_per_epoch = len(ds) // (bs * world)
+    interval = cfg.get('log_config', {}).get('interval', 50)
+    it, t0 = start_iter, time.time()
+    for epoch in range(epochs):
+        for k in range(iters_per_epoch):
+            if a.max_iters is not None and it >= a.max_iters:
+                break
+            sched.set(epoch, it)
+            base = (epoch * iters_per_epoch + k) * bs * world + rank * bs
+            imgs, boxes, labels = ds.batch([(base + j) % len(ds) for j in range(bs)])
+            out = engine.step(pipe(imgs, boxes, labels))
+            it += 1
+            if rank == 0 and it % interval == 0:
+                lv = {n: float(v) for n, v in out['log_vars'].items()}
+                print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
+                      f'time: {(time.time() - t0) / (it - start_iter):.3f} ' +
+                      ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
+        if rank == 0 and cfg.get('checkpoint_config', {}).get('interval', 0):
+            path = os.path.join(work_dir, f'epoch_{epoch + 1}.pth')
+            torch.save(dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
+                            meta=dict(iter=it, epoch=epoch + 1, mmdet_version='2.20.0-compatible keys')), path)
+            torch.save(dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
+                            meta=dict(iter=it, epoch=epoch + 1)), os.path.join(work_dir, 'latest.pth'))
+        if a.max_iters is not None and it >= a.max_iters:
+            break
+
+
+if __name__ == '__main__':
+    main()
