@@ -150,6 +150,18 @@ int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_hos
                          int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * NHWC bf16 implicit-GEMM convolution on the MFMA cores, fused bias / residual / ReLU epilogue
+ *   replaces the cuDNN convolutions of  mmdet/models/necks/fpn.py:112-129, dense_heads/rpn_head.py:54-68,
+ *   backbones/resnet.py:166-205 (with the eval-mode BN of :648-657 folded into w / bias)
+ * x [N,H,W,C] bf16, w [K,R,S,C] bf16, bias [K] fp32 or NULL, residual [N,Ho,Wo,K] bf16 or NULL, y [N,Ho,Wo,K]
+ * bf16, zeros16: >= 16 zero bytes.  Requires C % 64 == 0 and K % 128 == 0 (other shapes: argument error).
+ * The stride-1 data gradient is the same call on the flipped/transposed weight with pad' = dil*(R-1) - pad.
+ */
+int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                          const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
+                          int pad, int dil, int relu, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58
  * state624/left/next are the generator's engine words (in/out); out [k] int64.

@@ -1,0 +1,96 @@
+"""autograd wrapper of the MFMA implicit-GEMM convolution (csrc/conv_mfma.hip) and its registration as the
+convolution implementation of :mod:`oadg_amd.layers`.
+
+Forward and the stride-1 data gradient run on the hand-written kernel; the weight/bias gradients (a GEMM reduced
+over the pixel dimension) still go through ``aten.convolution_backward`` (MIOpen) this round.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+_ZEROS = {}
+
+
+def _zeros(device):
+    z = _ZEROS.get(device)
+    if z is None:
+        z = _ZEROS[device] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return z
+
+
+def supported(x, weight, stride, padding, dilation):
+    K, C, R, S = weight.shape
+    return (x.is_cuda and x.dim() == 4 and C % 64 == 0 and K % 128 == 0 and stride[0] == stride[1] and
+            padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
+
+
+def conv_forward(x, w, bias, residual, stride, pad, dil, relu):
+    """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last."""
+    L = _lib.lib()
+    N, C, H, W = x.shape
+    K, _, R, S = w.shape
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    y = torch.empty((N, K, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    check(L.oadg_conv2d_nhwc_bf16(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N, H, W,
+                                  C, K, R, S, stride, pad, dil, int(bool(relu)), stream_ptr()),
+          'oadg_conv2d_nhwc_bf16')
+    return y
+
+
+def _nhwc_bf16(t):
+    return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+
+class _Conv2dMFMA(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        x16, w16 = _nhwc_bf16(x), _nhwc_bf16(weight)
+        b32 = bias.float().contiguous() if bias is not None else None
+        y = conv_forward(x16, w16, b32, None, stride, pad, dil, False)
+        ctx.save_for_backward(x16, w16)
+        ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, weight.dtype,
+                   bias.dtype if bias is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x16, w16 = ctx.saved_tensors
+        stride, pad, dil, has_bias, xdt, wdt, bdt = ctx.cfg
+        gy = _nhwc_bf16(gy)
+        K, C, R, S = w16.shape
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = None
+        pad_t = dil * (R - 1) - pad
+        if need_x and stride == 1 and pad_t >= 0 and K % 64 == 0 and C % 128 == 0:
+            # dx = conv(dy, W^T rotated by 180 degrees): the same kernel, channels swapped
+            wt = _nhwc_bf16(w16.flip(2, 3).transpose(0, 1))
+            gx = conv_forward(gy, wt, None, None, 1, pad_t, dil, False)
+            need_x = False
+        outs = torch.ops.aten.convolution_backward(
+            gy, x16, w16, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
+            [need_x, need_w, has_bias and ctx.needs_input_grad[2]])
+        if gx is None:
+            gx = outs[0]
+        gw = outs[1].to(wdt) if outs[1] is not None else None
+        gb = outs[2].to(bdt) if outs[2] is not None else None
+        return (gx.to(xdt) if gx is not None else None), gw, gb, None, None, None
+
+
+def conv2d(x, weight, bias, stride, padding, dilation):
+    """layers.conv2d implementation hook: returns None for shapes the kernel does not cover."""
+    stride = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
+    padding = tuple(padding) if isinstance(padding, (tuple, list)) else (padding, padding)
+    dilation = tuple(dilation) if isinstance(dilation, (tuple, list)) else (dilation, dilation)
+    if not supported(x, weight, stride, padding, dilation):
+        return None
+    if not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
+        return None      # fp32 parity runs keep fp32 arithmetic
+    return _Conv2dMFMA.apply(x, weight, bias, stride[0], padding[0], dilation[0])
+
+
+def enable(on=True):
+    from . import layers
+    layers.set_conv_impl(conv2d if on else None)

@@ -1,0 +1,73 @@
+"""-m gpu numerics: the MFMA implicit-GEMM convolution (C ABI oadg_conv2d_nhwc_bf16) against a plain PyTorch
+fp32 convolution of the same bf16-rounded operands.  fp32 accumulation on both sides: the difference is the
+bf16 rounding of the output (<= 2^-8 relative) plus summation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b, stride, pad, dil, res=None, relu=False):
+    y = F.conv2d(x.float(), w.float(), b, stride, pad, dil)
+    if res is not None:
+        y = y + res.float()
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize('N,C,H,W,K,R,stride,pad,dil', [
+    (2, 256, 32, 48, 256, 3, 1, 1, 1),      # FPN / RPN 3x3
+    (1, 64, 17, 23, 128, 3, 1, 1, 1),       # ragged M tail
+    (2, 512, 20, 28, 128, 1, 1, 0, 1),      # bottleneck 1x1
+    (1, 128, 33, 31, 128, 3, 2, 1, 1),      # stride-2 3x3
+    (1, 512, 16, 16, 512, 3, 1, 2, 2),      # dilated (DC5)
+    (1, 256, 14, 18, 1024, 1, 2, 0, 1),     # stride-2 1x1 downsample
+])
+def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(C + K + R)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) / np.sqrt(C * R * R)).bfloat16() \
+        .contiguous(memory_format=torch.channels_last)
+    b = torch.randn(K, device=dev, generator=g)
+    y = hip_conv.conv_forward(x, w, b, None, stride, pad, dil, False)
+    ref = _ref(x, w, b, stride, pad, dil)
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 8e-3 * ref.abs().max().item(), err
+    # asymmetric check against transposes: a single non-zero weight tap / channel
+    w2 = torch.zeros_like(w)
+    w2[3, 5, R - 1, 0] = 1.0
+    y2 = hip_conv.conv_forward(x, w2, None, None, stride, pad, dil, False)
+    assert torch.equal(y2.float(), _ref(x, w2, None, stride, pad, dil).bfloat16().float())
+
+
+def test_conv_fused_epilogue(dev):
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn(2, 128, 24, 40, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 128, 3, 3, device=dev, generator=g) / 34).bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, device=dev, generator=g)
+    res = torch.randn(2, 256, 24, 40, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = hip_conv.conv_forward(x, w, b, res, 1, 1, 1, True)
+    ref = _ref(x, w, b, 1, 1, 1, res, True)
+    assert (y.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    assert (y >= 0).all()
+
+
+def test_conv_autograd_matches_reference(dev):
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(2, 256, 20, 28, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 256, 3, 3, device=dev, generator=g) / 48).bfloat16()
+    b = torch.randn(256, device=dev, generator=g)
+    gy = torch.randn(2, 256, 20, 28, device=dev, generator=g).bfloat16()
+    xa, wa, ba = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = hip_conv.conv2d(xa, wa, ba, 1, 1, 1)
+    assert y is not None
+    (y.float() * gy.float()).sum().backward()
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, br, 1, 1, 1) * gy.float()).sum().backward()
+    for a, r, tol in ((xa.grad, xr.grad, 1e-2), (wa.grad, wr.grad, 2e-2), (ba.grad, br.grad, 1e-2)):
+        assert (a.float() - r).abs().max().item() <= tol * r.abs().max().item()
