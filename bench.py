@@ -37,6 +37,8 @@ def parse():
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv', default='mfma', choices=['mfma', 'miopen'],
+                    help='mfma: hand-written implicit-GEMM kernels where they apply; miopen: torch.conv2d only')
     return ap.parse_args()
 
 
@@ -119,6 +121,9 @@ def main():
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     cfg = Config.fromfile(CFG)
     amp = torch.bfloat16 if a.dtype == 'bf16' else None
+    if a.conv == 'mfma' and amp is not None:
+        from oadg_amd import hip_conv
+        hip_conv.enable()
     set_random_seed(0)                       # identical initial weights on every rank
     det = build_detector(cfg.model)
     det.init_weights()
@@ -132,9 +137,17 @@ def main():
     batches = [ds.batch(range(i * a.batch, (i + 1) * a.batch)) for i in range(nb)]   # resident in HBM
     torch.cuda.synchronize()
 
+    # software pipeline, as a DataLoader with prefetching would give: the pipeline of batch i+1 is enqueued on
+    # a side stream right after the step of batch i.  Every timed step contains one pipeline pass (OA-Mix +
+    # Normalize/Pad of 4 images) and one train step; the batch for the first timed step is produced by the last
+    # warm-up step and the last timed step produces one more batch, so K pipeline passes run inside the region.
+    state = {'next': pipe.prefetch(*batches[0])}
+
     def step(i):
-        imgs, boxes, labels = batches[i % nb]
-        return engine.step(pipe(imgs, boxes, labels))
+        data = state['next'].get()
+        out = engine.step(data)
+        state['next'] = pipe.prefetch(*batches[(i + 1) % nb])
+        return out
 
     for i in range(a.warmup):
         out = step(i)

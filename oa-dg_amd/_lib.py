@@ -84,8 +84,9 @@ def ptr(t):
 
 
 def stream_ptr():
+    """raw hipStream_t of torch's current stream on the current device"""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def require_cuda(*tensors):

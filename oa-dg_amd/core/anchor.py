@@ -65,6 +65,15 @@ class AnchorGenerator:
         return torch.stack([xc - 0.5 * ws, yc - 0.5 * hs, xc + 0.5 * ws, yc + 0.5 * hs], dim=-1)
 
     def single_level_grid_priors(self, featmap_size, level_idx, dtype=torch.float32, device='cuda'):
+        """Anchors only depend on (feature-map size, level): computed once per shape and kept on the device
+        (the reference rebuilds them, with a host->device copy of the base anchors, on every call)."""
+        key = (tuple(int(v) for v in featmap_size), level_idx, dtype, str(device))
+        cache = self.__dict__.setdefault('_prior_cache', {})
+        if key not in cache:
+            cache[key] = self._single_level_grid_priors(featmap_size, level_idx, dtype, device)
+        return cache[key]
+
+    def _single_level_grid_priors(self, featmap_size, level_idx, dtype, device):
         base = self.base_anchors[level_idx].to(device).to(dtype)
         fh, fw = featmap_size
         sw, sh = self.strides[level_idx]
@@ -84,6 +93,13 @@ class AnchorGenerator:
     grid_anchors = lambda self, featmap_sizes, device='cuda': self.grid_priors(featmap_sizes, device=device)  # noqa: E731
 
     def valid_flags(self, featmap_sizes, pad_shape, device='cuda'):
+        key = (tuple(tuple(int(v) for v in f) for f in featmap_sizes), tuple(pad_shape[:2]), str(device))
+        cache = self.__dict__.setdefault('_flag_cache', {})
+        if key not in cache:
+            cache[key] = self._valid_flags(featmap_sizes, pad_shape, device)
+        return cache[key]
+
+    def _valid_flags(self, featmap_sizes, pad_shape, device):
         flags = []
         for i in range(self.num_levels):
             fh, fw = featmap_sizes[i]

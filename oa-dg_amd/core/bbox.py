@@ -39,12 +39,12 @@ def bbox_overlaps(b1, b2, mode='iou', is_aligned=False, eps=1e-6):
         if mode == 'giou':
             elt = torch.min(b1[..., :, None, :2], b2[..., None, :, :2])
             erb = torch.max(b1[..., :, None, 2:], b2[..., None, :, 2:])
-    union = torch.max(union, union.new_tensor([eps]))
+    union = union.clamp(min=eps)
     ious = overlap / union
     if mode in ('iou', 'iof'):
         return ious
     ewh = (erb - elt).clamp(min=0)
-    earea = torch.max(ewh[..., 0] * ewh[..., 1], union.new_tensor([eps]))
+    earea = (ewh[..., 0] * ewh[..., 1]).clamp(min=eps)
     return ious - (earea - union) / earea
 
 
@@ -313,6 +313,18 @@ def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_
 
 
 # ----------------------------------------------------------------------------------------------- coder
+_CONSTS = {}
+
+
+def _const(values, like):
+    """small constant tensor on ``like``'s device, built once (new_tensor copies host->device every call)."""
+    key = (tuple(float(v) for v in values), like.dtype, str(like.device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(key[0], dtype=like.dtype, device=like.device)
+    return t
+
+
 def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     """delta_xywh_bbox_coder.py:119-180, including the fork's zero-size guard (:152-160) and its
     mismatched mask ``gy[nan_x] = py[nan_y]``."""
@@ -326,16 +338,20 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     gy = (gt[..., 1] + gt[..., 3]) * 0.5
     gw = gt[..., 2] - gt[..., 0]
     gh = gt[..., 3] - gt[..., 1]
+    # fork guard against zero-size proposals (:152-160), written without boolean indexing (which reads the
+    # mask count back to the host).  The reference's last line is ``gy[nan_x] = py[nan_y]``: with equal masks
+    # (the only case in which that statement is well-formed and meaningful) it is the line below.
     nan_x, nan_y = (pw == 0), (ph == 0)
-    pw[nan_x] = 1e-6
-    ph[nan_y] = 1e-6
-    gw[nan_x] = 1e-6
-    gh[nan_y] = 1e-6
-    gx[nan_x] = px[nan_x]
-    gy[nan_x] = py[nan_y]
+    tiny = pw.new_full((), 1e-6)
+    pw = torch.where(nan_x, tiny, pw)
+    ph = torch.where(nan_y, tiny, ph)
+    gw = torch.where(nan_x, tiny, gw)
+    gh = torch.where(nan_y, tiny, gh)
+    gx = torch.where(nan_x, px, gx)
+    gy = torch.where(nan_x & nan_y, py, gy)
     deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
-    means = deltas.new_tensor(means).unsqueeze(0)
-    stds = deltas.new_tensor(stds).unsqueeze(0)
+    means = _const(means, deltas).unsqueeze(0)
+    stds = _const(stds, deltas).unsqueeze(0)
     return deltas.sub_(means).div_(stds)
 
 
@@ -346,8 +362,8 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     if num_bboxes == 0:
         return deltas
     deltas = deltas.reshape(-1, 4)
-    means = deltas.new_tensor(means).view(1, -1)
-    stds = deltas.new_tensor(stds).view(1, -1)
+    means = _const(means, deltas).view(1, -1)
+    stds = _const(stds, deltas).view(1, -1)
     d = deltas * stds + means
     dxy, dwh = d[:, :2], d[:, 2:]
     rois_ = rois.repeat(1, num_classes).reshape(-1, 4)

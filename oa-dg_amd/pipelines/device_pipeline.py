@@ -84,6 +84,22 @@ class DevicePipeline:
         assert self.norm is not None, 'the pipeline needs a Normalize step'
         self.dtype = dtype
 
+    def prefetch(self, imgs_u8, gt_bboxes, gt_labels):
+        """Enqueue the whole pipeline for one batch on a side stream and return a handle (``.get()``).
+
+        This is the device-side analogue of the reference's DataLoader workers (``workers_per_gpu`` processes
+        with prefetching, configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes.py:27): augmentation of
+        batch i+1 overlaps the training step of batch i.  The inputs must already be complete on the device
+        (resident batches); OA-Mix's small host reads only wait on this stream."""
+        if getattr(self, '_stream', None) is None:
+            self._stream = torch.cuda.Stream(device=imgs_u8.device)
+            self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):
+            out = self(imgs_u8, gt_bboxes, gt_labels)
+            evt = torch.cuda.Event()
+            evt.record()
+        return _Prefetched(out, evt)
+
     def __call__(self, imgs_u8, gt_bboxes, gt_labels):
         """imgs_u8: uint8 [N,H,W,3] cuda tensor (BGR bytes); gt_bboxes: list of float32 [n_i,4] numpy arrays;
         gt_labels: list of int64 numpy arrays.  Returns the collated dict for ``train_step``."""
@@ -134,6 +150,23 @@ class DevicePipeline:
             out['multilevel_boxes'] = ml
             out['oamix_boxes'] = oa
         return {k: v for k, v in out.items() if k in self.keys or k == 'img_metas'}
+
+
+class _Prefetched:
+    """A batch being produced on the pipeline's side stream."""
+
+    def __init__(self, out, event):
+        self.out, self.event = out, event
+
+    def get(self):
+        """Make the current stream wait for the batch and hand its tensors over to it."""
+        cur = torch.cuda.current_stream()
+        cur.wait_event(self.event)
+        for v in self.out.values():
+            for t in (v if isinstance(v, (list, tuple)) else [v]):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(cur)
+        return self.out
 
 
 class _PtrView:

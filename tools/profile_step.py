@@ -44,8 +44,12 @@ def main():
     ap.add_argument('--amp', default='bf16')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--prof', action='store_true')
+    ap.add_argument('--conv', default='mfma')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
+    if a.conv == 'mfma' and a.amp == 'bf16':
+        from oadg_amd import hip_conv
+        hip_conv.enable()
     cfg = Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
     det = build_detector(cfg.model)
     det.init_weights()
