@@ -27,13 +27,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.relu(conv_bn(x, self.conv1, self.bn1))
-        out = self.relu(conv_bn(out, self.conv2, self.bn2))
-        out = conv_bn(out, self.conv3, self.bn3)
         if self.downsample is not None:
             identity = conv_bn(x, self.downsample[0], self.downsample[1])
-        out += identity
-        return self.relu(out)
+        out = conv_bn(x, self.conv1, self.bn1, relu=True)
+        out = conv_bn(out, self.conv2, self.bn2, relu=True)
+        return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)   # relu(bn3(conv3) + identity)
 
 
 def make_res_layer(inplanes, planes, num_blocks, stride, dilation, style, norm_cfg):
@@ -109,7 +107,7 @@ class ResNet(nn.Module):
                 p.requires_grad = False
 
     def forward(self, x):
-        x = self.maxpool(self.relu(conv_bn(x, self.conv1, self.bn1)))
+        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, relu=True))
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

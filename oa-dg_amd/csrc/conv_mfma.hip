@@ -142,24 +142,45 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = pixel][col = channel]; lane holds column l31, rows (r&3) + 8*(r>>2) + 4*lh
+    // ---- epilogue.  D[row = pixel][col = channel]: a lane holds column l31 and rows (r&3) + 8*(r>>2) + 4*lh of
+    // each 32x32 sub-tile.  bias is added in fp32, the tile is staged as bf16 [128 pixels][128 channels] in the
+    // (now idle) LDS stages, then written with 16-byte stores: 16 lanes cover the 256 contiguous bytes of one
+    // pixel's channels.  Residual add and ReLU happen on the way out (fp32).
+    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);      // 32 KiB
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ch = k0 + wn * 64 + j * 32 + l31;
-        const float bv = a.bias ? a.bias[ch] : 0.f;
+        const int col = wn * 64 + j * 32 + l31;
+        const float bv = a.bias ? a.bias[k0 + col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) {
-                    float v = acc[i][j][r] + bv;
-                    if (a.res) v += bf16_to_f32(a.res[(size_t)m * a.K + ch]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[(size_t)m * a.K + ch] = f32_to_bf16(v);
-                }
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float v = acc[i][j][r] + bv;
+                if (a.relu && !a.res) v = fmaxf(v, 0.f);
+                tile[row * BN + col] = f32_to_bf16(v);
             }
         }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (BM * BN / 8) / 256; ++it) {
+        const int q = it * 256 + tid;
+        const int row = q >> 4, sg = q & 15;
+        const long m = m0 + row;
+        if (m >= a.M) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * BN + sg * 8);
+        const size_t off = (size_t)m * a.K + k0 + sg * 8;
+        if (a.res) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf16_to_f32((unsigned short)v[e]) + bf16_to_f32((unsigned short)rv[e]);
+                if (a.relu) f = fmaxf(f, 0.f);
+                v[e] = (short)f32_to_bf16(f);
+            }
+        }
+        *reinterpret_cast<bf16x8*>(a.y + off) = v;
     }
 }
 

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 from . import hip_ops
 from .core import anchor_inside_flags, images_to_levels, multi_apply, unmap
 from .core.bbox import sample_many
-from .layers import Conv2d, normal_init
+from .layers import Conv2d, conv2d, normal_init
 from .registry import (HEADS, build_assigner, build_bbox_coder, build_loss, build_prior_generator,
                        build_sampler)
 
@@ -213,7 +213,8 @@ class RPNHead(AnchorHead):
             normal_init(m, std=0.01)
 
     def forward_single(self, x):
-        x = F.relu(self.rpn_conv(x), inplace=True)
+        c = self.rpn_conv
+        x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True)   # relu(rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):

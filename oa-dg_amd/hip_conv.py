@@ -44,22 +44,27 @@ def _nhwc_bf16(t):
 
 
 class _Conv2dMFMA(torch.autograd.Function):
+    """y = [relu]( conv(x, w) + b [+ residual] ) in one kernel; backward = ReLU mask (one element-wise pass),
+    stride-1 data gradient on the same kernel, weight/bias gradients through aten (MIOpen) for now."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, residual, stride, pad, dil, relu):
         x16, w16 = _nhwc_bf16(x), _nhwc_bf16(weight)
         b32 = bias.float().contiguous() if bias is not None else None
-        y = conv_forward(x16, w16, b32, None, stride, pad, dil, False)
-        ctx.save_for_backward(x16, w16)
+        r16 = _nhwc_bf16(residual) if residual is not None else None
+        y = conv_forward(x16, w16, b32, r16, stride, pad, dil, relu)
+        ctx.save_for_backward(x16, w16, y if relu else None)
         ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, weight.dtype,
-                   bias.dtype if bias is not None else None)
+                   bias.dtype if bias is not None else None, residual.dtype if residual is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x16, w16 = ctx.saved_tensors
-        stride, pad, dil, has_bias, xdt, wdt, bdt = ctx.cfg
+        x16, w16, y = ctx.saved_tensors
+        stride, pad, dil, has_bias, xdt, wdt, bdt, rdt = ctx.cfg
         gy = _nhwc_bf16(gy)
+        if y is not None:
+            gy = torch.ops.aten.threshold_backward(gy, y, 0)
         K, C, R, S = w16.shape
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
@@ -69,26 +74,33 @@ class _Conv2dMFMA(torch.autograd.Function):
             wt = _nhwc_bf16(w16.flip(2, 3).transpose(0, 1))
             gx = conv_forward(gy, wt, None, None, 1, pad_t, dil, False)
             need_x = False
-        outs = torch.ops.aten.convolution_backward(
-            gy, x16, w16, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0], 1,
-            [need_x, need_w, has_bias and ctx.needs_input_grad[2]])
-        if gx is None:
-            gx = outs[0]
-        gw = outs[1].to(wdt) if outs[1] is not None else None
-        gb = outs[2].to(bdt) if outs[2] is not None else None
-        return (gx.to(xdt) if gx is not None else None), gw, gb, None, None, None
+        want_b = has_bias and ctx.needs_input_grad[2]
+        gw = gb = None
+        if need_x or need_w or want_b:
+            outs = torch.ops.aten.convolution_backward(
+                gy, x16, w16, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
+                1, [need_x, need_w, want_b])
+            if gx is None:
+                gx = outs[0]
+            gw = outs[1].to(wdt) if outs[1] is not None else None
+            gb = outs[2].to(bdt) if outs[2] is not None else None
+        gres = gy.to(rdt) if (rdt is not None and ctx.needs_input_grad[3]) else None
+        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None
 
 
-def conv2d(x, weight, bias, stride, padding, dilation):
+def _norm3(stride, padding, dilation):
+    t = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)  # noqa: E731
+    return t(stride), t(padding), t(dilation)
+
+
+def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None):
     """layers.conv2d implementation hook: returns None for shapes the kernel does not cover."""
-    stride = tuple(stride) if isinstance(stride, (tuple, list)) else (stride, stride)
-    padding = tuple(padding) if isinstance(padding, (tuple, list)) else (padding, padding)
-    dilation = tuple(dilation) if isinstance(dilation, (tuple, list)) else (dilation, dilation)
+    stride, padding, dilation = _norm3(stride, padding, dilation)
     if not supported(x, weight, stride, padding, dilation):
         return None
     if not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
         return None      # fp32 parity runs keep fp32 arithmetic
-    return _Conv2dMFMA.apply(x, weight, bias, stride[0], padding[0], dilation[0])
+    return _Conv2dMFMA.apply(x, weight, bias, residual, stride[0], padding[0], dilation[0], bool(relu))
 
 
 def enable(on=True):

@@ -16,12 +16,16 @@ def set_conv_impl(fn):
     _CONV_IMPL = fn
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
+    """[relu]( conv2d(x, weight, bias) [+ residual] ): fused in the MFMA kernel's epilogue when it applies."""
     if _CONV_IMPL is not None and x.is_cuda:
-        y = _CONV_IMPL(x, weight, bias, stride, padding, dilation)
+        y = _CONV_IMPL(x, weight, bias, stride, padding, dilation, relu, residual)
         if y is not None:
             return y
-    return F.conv2d(x, weight, bias, stride, padding, dilation)
+    y = F.conv2d(x, weight, bias, stride, padding, dilation)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
 
 
 class Conv2d(nn.Conv2d):
@@ -40,10 +44,14 @@ class Conv2d(nn.Conv2d):
 FOLD_EVAL_BN = True
 
 
-def conv_bn(x, conv, bn):
-    """bn(conv(x)) for a BatchNorm in eval mode, folded; falls back to the two-step form otherwise."""
+def conv_bn(x, conv, bn, relu=False, residual=None):
+    """[relu]( bn(conv(x)) [+ residual] ) for a BatchNorm in eval mode, folded into the convolution; falls back
+    to the module-by-module form otherwise."""
     if not FOLD_EVAL_BN or bn.training or conv.bias is not None:
-        return bn(conv(x))
+        y = bn(conv(x))
+        if residual is not None:
+            y = y + residual
+        return F.relu(y, inplace=True) if relu else y
     frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)
     key = None
     if frozen:   # constant until the parameters/buffers are overwritten: fold once
@@ -51,14 +59,14 @@ def conv_bn(x, conv, bn):
                bn.running_var._version, conv.weight.device, conv.weight.data_ptr())
         cached = getattr(conv, '_folded', None)
         if cached is not None and cached[0] == key:
-            return conv2d(x, cached[1], cached[2], conv.stride, conv.padding, conv.dilation)
+            return conv2d(x, cached[1], cached[2], conv.stride, conv.padding, conv.dilation, relu, residual)
     scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
     w = conv.weight * scale.view(-1, 1, 1, 1)
     b = bn.bias - bn.running_mean * scale
     if frozen:
         w, b = w.detach(), b.detach()
         conv._folded = (key, w, b)
-    return conv2d(x, w, b, conv.stride, conv.padding, conv.dilation)
+    return conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, relu, residual)
 
 
 def build_norm_layer(cfg, num_features, postfix=''):

@@ -27,14 +27,28 @@ def main():
     ds = SyntheticCityscapes(device=dev)
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
     batches = [ds.batch(range(i * 4, i * 4 + 4)) for i in range(3)]
+    nxt = pipe.prefetch(*batches[0])
     for i in range(4):
-        eng.step(pipe(*batches[i % 3]))
+        data = nxt.get()
+        eng.step(data)
+        nxt = pipe.prefetch(*batches[(i + 1) % 3])
     torch.cuda.synchronize()
+    if '--torchprof' in sys.argv:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p:
+            for i in range(2):
+                data = nxt.get()
+                eng.step(data)
+                nxt = pipe.prefetch(*batches[(i + 1) % 3])
+            torch.cuda.synchronize()
+        print(p.key_averages().table(sort_by='self_cuda_time_total', row_limit=40, max_name_column_width=70))
+        return
     pr = cProfile.Profile()
     pr.enable()
     for i in range(3):
-        data = pipe(*batches[i % 3])
+        data = nxt.get()
         eng.step(data)
+        nxt = pipe.prefetch(*batches[(i + 1) % 3])
     torch.cuda.synchronize()
     pr.disable()
     st = pstats.Stats(pr)
