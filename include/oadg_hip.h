@@ -161,6 +161,13 @@ int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const
                           const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
                           int pad, int dil, int relu, void* stream);
 
+/* weight gradient of the same convolution: dw [K,R,S,C] fp32 = sum over output pixels of dy (x) x@tap
+ * (transposing LDS reads + split-K partials in `workspace`, summed in fixed order).  C % 128 == 0, K % 128 == 0. */
+size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);
+int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,
+                                size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
+                                int stride, int pad, int dil, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

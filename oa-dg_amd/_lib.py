@@ -37,6 +37,8 @@ SIGNATURES = {
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_conv2d_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 11 + [vp]),
+    'oadg_conv2d_wgrad_workspace_bytes': (cs, [ci] * 7),
+    'oadg_conv2d_wgrad_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, cs] + [ci] * 10 + [vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

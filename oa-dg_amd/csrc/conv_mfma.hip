@@ -207,3 +207,193 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
+
+// ================================================================================================ weight gradient
+// dW[k][r][s][c] = sum_p dy[p][k] * x[p @ tap(r,s)][c]   (p runs over the N*Ho*Wo output pixels)
+//
+// GEMM view: M = K (output channels), N = C (input channels), reduction over pixels.  Both operands are stored
+// pixel-major in HBM (NHWC), i.e. TRANSPOSED with respect to what an MFMA fragment wants (8 consecutive reduction
+// indices per lane).  The tiles are therefore staged as they are ([64 pixels][128 channels], filled by
+// global_load_lds) and read with ds_read_b64_tr_b16, the gfx950 transposing LDS read: inside a 16-lane group
+// source lane 4j+q supplies the 8-byte segment {row j, columns 4q..4q+3} of a 4 x 16 block and lane l receives
+// column l (4 consecutive pixels of one channel); two reads make one 8-pixel fragment.  Slot swizzle
+// slot' = slot ^ ((row & 3) << 2) keeps the 32 lanes of a read group on 64 distinct banks.
+// One workgroup owns one (k tile, c tile, tap) and a contiguous range of pixel chunks (split-K); fp32 partial
+// tiles go to a workspace and are summed by a second kernel in fixed order (deterministic, no atomics).
+namespace {
+
+struct WgradArgs {
+    const unsigned short* x;      // [N,H,W,C]
+    const unsigned short* dy;     // [N,Ho,Wo,K]
+    float* part;                  // [splits][K][R*S][C] fp32
+    const unsigned short* zeros;
+    int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil, splits, chunks_per_split;
+    long P;
+};
+
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_ptr;
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int pix0, int chan0, int lane) {
+    // 8 consecutive pixels (pix0 + 8*(lane>>5) ...) of channel chan0 + (lane & 31), from a [64][128] bf16 tile
+    const int g = lane >> 4, s = lane & 15;
+    const int chan = chan0 + (g & 1) * 16 + (s & 3) * 4;
+    const int rowb = pix0 + (g >> 1) * 8 + (s >> 2);
+    bf16x8 out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = rowb + u * 4;
+        const int slot = (chan >> 3) ^ ((row & 3) << 2);
+        const unsigned char* p = tile + row * 256 + slot * 16 + (chan & 7) * 2;
+        const v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)p);
+        out[u * 4 + 0] = r[0]; out[u * 4 + 1] = r[1]; out[u * 4 + 2] = r[2]; out[u * 4 + 3] = r[3];
+    }
+    return out;
+}
+
+constexpr int WP = 64;                                  // pixels per chunk
+constexpr int WSTAGE = 2 * WP * 128 * 2;                // dy tile + x tile = 32 KiB
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kt_n = a.K / 128, ct_n = a.C / 128, RS = a.R * a.S;
+    long bid = blockIdx.x;
+    const int split = (int)(bid % a.splits); bid /= a.splits;
+    const int ct = (int)(bid % ct_n); bid /= ct_n;
+    const int kt = (int)(bid % kt_n); bid /= kt_n;
+    const int rs = (int)bid;
+    const int r = rs / a.S, s = rs - r * a.S;
+    const int k0 = kt * 128, c0 = ct * 128;
+    const long nchunks = (a.P + WP - 1) / WP;
+    const long ch0 = (long)split * a.chunks_per_split;
+    const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
+
+    auto stage = [&](long ch, int buf) {
+        unsigned char* sa = smem + buf * WSTAGE;        // dy tile [64][128]
+        unsigned char* sb = sa + WP * 256;              // x tile  [64][128]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * 256 + tid;
+            const int row = q >> 4, slot = (q & 15) ^ ((row & 3) << 2);
+            const long p = ch * WP + row;
+            const unsigned short* sdy = a.zeros;
+            const unsigned short* sx = a.zeros;
+            if (p < a.P) {
+                sdy = a.dy + (size_t)p * a.K + k0 + slot * 8;
+                const int wo = (int)(p % a.Wo);
+                const long t = p / a.Wo;
+                const int ho = (int)(t % a.Ho);
+                const int n = (int)(t / a.Ho);
+                const int hi = ho * a.stride - a.pad + r * a.dil, wi = wo * a.stride - a.pad + s * a.dil;
+                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
+                    sx = a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.C + c0 + slot * 8;
+            }
+            glds16(sdy, sa + i * 4096 + wave * 1024);
+            glds16(sx, sb + i * 4096 + wave * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (ch0 < ch1) {
+        stage(ch0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (long ch = ch0; ch < ch1; ++ch) {
+            const int cur = (int)((ch - ch0) & 1);
+            if (ch + 1 < ch1) stage(ch + 1, cur ^ 1);
+            const unsigned char* sa = smem + cur * WSTAGE;
+            const unsigned char* sb = sa + WP * 256;
+#pragma unroll
+            for (int t = 0; t < WP / 16; ++t) {
+                bf16x8 fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sa, t * 16, wm * 64 + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sb, t * 16, wn * 64 + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    float* out = a.part + (size_t)split * a.K * RS * a.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                const int c = c0 + wn * 64 + j * 32 + l31;
+                out[((size_t)k * RS + rs) * a.C + c] = acc[i][j][e];
+            }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long n, float* __restrict__ dw) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];
+    dw[i] = s;
+}
+
+int wgrad_splits(long P, int K, int C, int RS) {
+    const long tiles = (long)(K / 128) * (C / 128) * RS;
+    const long nchunks = (P + WP - 1) / WP;
+    long s = (1024 + tiles - 1) / tiles;
+    if (s > nchunks / 4) s = nchunks / 4;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+}  // namespace
+
+extern "C" size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S) {
+    if (C % 128 || K % 128) return 0;
+    const int sp = wgrad_splits((long)N * Ho * Wo, K, C, R * S);
+    return (size_t)sp * K * R * S * C * sizeof(float);
+}
+
+// dw [K,R,S,C] fp32 (overwritten).  x [N,H,W,C] bf16, dy [N,Ho,Wo,K] bf16.  Requires C % 128 == 0, K % 128 == 0.
+extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16,
+                                           void* workspace, size_t workspace_bytes, int N, int H, int W, int C,
+                                           int K, int R, int S, int stride, int pad, int dil, void* stream) {
+    if (!x || !dy || !dw || !zeros16 || !workspace) return OADG_EARG;
+    if (C % 128 != 0 || K % 128 != 0 || N < 1 || R < 1 || S < 1) return OADG_EARG;
+    WgradArgs a;
+    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.part = (float*)workspace;
+    a.zeros = (const unsigned short*)zeros16;
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
+    a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+    a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    a.P = (long)N * a.Ho * a.Wo;
+    a.splits = wgrad_splits(a.P, K, C, R * S);
+    const long nchunks = (a.P + WP - 1) / WP;
+    a.chunks_per_split = (int)((nchunks + a.splits - 1) / a.splits);
+    const size_t need = (size_t)a.splits * K * R * S * C * sizeof(float);
+    if (workspace_bytes < need) return OADG_ESIZE;
+    const long blocks = (long)a.splits * (K / 128) * (C / 128) * R * S;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 2 * WSTAGE, st, a);
+    OADG_LAUNCH_CHECK();
+    const long n = (long)K * R * S * C;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const float*)workspace, a.splits, n, dw);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}

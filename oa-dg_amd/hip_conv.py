@@ -39,6 +39,20 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu):
     return y
 
 
+def conv_wgrad(x16, gy16, K, R, S, stride, pad, dil):
+    """dW [K,C,R,S] (fp32, channels_last strides) of y = conv(x, W): csrc/conv_mfma.hip conv_wgrad_kernel."""
+    L = _lib.lib()
+    N, C, H, W = x16.shape
+    Ho, Wo = gy16.shape[2], gy16.shape[3]
+    nbytes = L.oadg_conv2d_wgrad_workspace_bytes(N, Ho, Wo, C, K, R, S)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x16.device)
+    dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x16.device)
+    check(L.oadg_conv2d_wgrad_nhwc_bf16(ptr(x16), ptr(gy16), ptr(dw), ptr(_zeros(x16.device)), ptr(ws), nbytes, N,
+                                        H, W, C, K, R, S, stride, pad, dil, stream_ptr()),
+          'oadg_conv2d_wgrad_nhwc_bf16')
+    return dw.permute(0, 3, 1, 2)
+
+
 def _nhwc_bf16(t):
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
@@ -76,14 +90,22 @@ class _Conv2dMFMA(torch.autograd.Function):
             need_x = False
         want_b = has_bias and ctx.needs_input_grad[2]
         gw = gb = None
+        if need_w and K % 128 == 0 and C % 128 == 0:
+            gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil).to(wdt)
+            need_w = False
+            if want_b:
+                gb = gy.float().sum((0, 2, 3)).to(bdt)
+                want_b = False
         if need_x or need_w or want_b:
             outs = torch.ops.aten.convolution_backward(
                 gy, x16, w16, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
                 1, [need_x, need_w, want_b])
             if gx is None:
                 gx = outs[0]
-            gw = outs[1].to(wdt) if outs[1] is not None else None
-            gb = outs[2].to(bdt) if outs[2] is not None else None
+            if outs[1] is not None:
+                gw = outs[1].to(wdt)
+            if outs[2] is not None:
+                gb = outs[2].to(bdt)
         gres = gy.to(rdt) if (rdt is not None and ctx.needs_input_grad[3]) else None
         return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None
 

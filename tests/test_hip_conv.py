@@ -82,3 +82,25 @@ def test_conv_autograd_matches_reference(dev):
         d = (a.float() - r).abs()
         assert d.mean().item() <= 1e-2 * r.abs().mean().item() + 1e-6, (d.mean().item(), r.abs().mean().item())
         assert d.max().item() <= 10 * tol * r.abs().max().item(), (d.max().item(), r.abs().max().item())
+
+
+@pytest.mark.parametrize('N,C,H,W,K,R,stride,pad,dil', [
+    (2, 256, 20, 28, 256, 3, 1, 1, 1),
+    (1, 128, 19, 21, 128, 3, 1, 1, 1),      # ragged pixel tail
+    (2, 512, 16, 24, 128, 1, 1, 0, 1),
+    (1, 128, 33, 31, 256, 3, 2, 1, 1),
+    (1, 512, 16, 16, 512, 3, 1, 2, 2),
+])
+def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(C + K + R + stride)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    gy = torch.randn(N, K, Ho, Wo, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    dw = hip_conv.conv_wgrad(x, gy, K, R, R, stride, pad, dil)
+    w = torch.zeros(K, C, R, R, device=dev, requires_grad=True)
+    (F.conv2d(x.float(), w, None, stride, pad, dil) * gy.float()).sum().backward()
+    assert dw.shape == w.grad.shape
+    err = (dw - w.grad).abs().max().item()
+    assert err <= 2e-3 * w.grad.abs().max().item(), (err, w.grad.abs().max().item())

@@ -50,7 +50,14 @@ def main():
         t1 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False))
         bb = b.bfloat16()
         t2 = timeit(lambda: F.conv2d(x, w, bb, st, pad))
-        print(f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x')
+        line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x'
+        if C % 128 == 0 and K % 128 == 0:
+            gy = torch.randn(N, K, Ho, Wo, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+            t3 = timeit(lambda: hip_conv.conv_wgrad(x, gy, K, R, R, st, pad, 1))
+            t4 = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [st, st], [pad, pad], [1, 1], False,
+                                                                    [0, 0], 1, [False, True, False]))
+            line += f'   wgrad ours {t3:7.3f} ms {gf / t3:6.1f} TF/s | torch {t4:7.3f} ms {gf / t4:6.1f} TF/s  {t4 / t3:5.2f}x'
+        print(line)
 
 
 if __name__ == '__main__':
