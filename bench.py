@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
 
 def parse():
@@ -121,8 +122,8 @@ def main():
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     cfg = Config.fromfile(CFG)
     amp = torch.bfloat16 if a.dtype == 'bf16' else None
+    from oadg_amd import hip_conv
     if a.conv == 'mfma' and amp is not None:
-        from oadg_amd import hip_conv
         hip_conv.enable()
     set_random_seed(0)                       # identical initial weights on every rank
     det = build_detector(cfg.model)
@@ -152,6 +153,8 @@ def main():
     for i in range(a.warmup):
         out = step(i)
     hip_ops.TIMERS = {'roi_align_bwd': []}
+    if a.conv == 'mfma' and amp is not None:
+        hip_conv.TIMERS = []
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -170,35 +173,49 @@ def main():
         dt = float(t.item())
     pairs = hip_ops.TIMERS['roi_align_bwd']
     hip_ops.TIMERS = None
+    conv_timers, hip_conv.TIMERS = hip_conv.TIMERS, None
     loss = float(out['loss'])
     assert np.isfinite(loss), 'training diverged'
     if rank != 0:
         return
-    # ---- roofline of the dominant hand-written kernel (RoIAlign backward: atomic scatter into the fp32
-    #      pyramid gradient), HIP-event durations from the timed region
-    ms = [s.elapsed_time(e) for s, e in pairs]
-    K = 2 * a.batch * 512
-    rois = det.roi_head._last_rois if hasattr(det.roi_head, '_last_rois') else None
+    # ---- roofline of the dominant hand-written kernel, from HIP events recorded on the kernel's stream inside
+    #      the timed region.  With the MFMA convolutions enabled that is conv_igemm_kernel (forward + stride-1
+    #      data gradient of the 3x3 / 1x1 convs): algorithmic FLOPs per launch = 2*M*K*R*S*C summed over the
+    #      launches / number of launches, divided by the mean launch duration.  Otherwise RoIAlign backward.
     elem = 2 if amp is not None else 4
-    # per-launch algorithmic bytes: average of the two launches per step (sampled RoIs, random-proposal RoIs)
-    if rois is not None:
-        total_bytes = sum(roi_algorithmic_bytes(r, [4, 8, 16, 32], 256, elem) for r in rois)
-        per_launch = total_bytes / max(len(rois), 1)
+    if conv_timers:
+        ms = [s_.elapsed_time(e_) for s_, e_, _ in conv_timers]
+        flops = [f for _, _, f in conv_timers]
+        avg_ms, per_launch = sum(ms) / len(ms), sum(flops) / len(flops)
+        achieved = per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {'kernel': 'conv_igemm_kernel', 'bound': 'mfma', 'achieved': round(achieved, 1),
+                'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+                'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
+                'algorithmic_flops_per_launch': int(per_launch),
+                'launches_per_step': round(len(ms) / a.steps, 1),
+                'kernel_ms_per_step': round(sum(ms) / a.steps, 2)}
     else:
-        per_launch = K * 49 * 256 * elem
-    avg_ms = sum(ms) / max(len(ms), 1)
-    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        ms = [s_.elapsed_time(e_) for s_, e_ in pairs]
+        rois = getattr(det.roi_head, '_last_rois', None)
+        if rois is not None:
+            per_launch = sum(roi_algorithmic_bytes(r_, [4, 8, 16, 32], 256, elem) for r_ in rois) / max(len(rois), 1)
+        else:
+            per_launch = 2 * a.batch * 512 * 49 * 256 * elem
+        avg_ms = sum(ms) / max(len(ms), 1)
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roof = {'kernel': 'roi_align_bwd_kernel', 'bound': 'hbm', 'achieved': round(achieved, 2),
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
+                'algorithmic_bytes_per_launch': int(per_launch)}
     res = {
         'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
         'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '
                                f'{a.batch} img/GPU x 2 views, {a.height}x{a.width}, 20 boxes/img, SGD step',
-                   'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'final_loss': round(loss, 4)},
-        'roofline': {'kernel': 'roi_align_bwd_kernel', 'bound': 'hbm', 'achieved': round(achieved, 2),
-                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                     'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
-                     'algorithmic_bytes_per_launch': int(per_launch)},
+                   'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'final_loss': round(loss, 4),
+                   'conv': a.conv},
+        'roofline': roof,
     }
     if a.gpus == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(cfg)

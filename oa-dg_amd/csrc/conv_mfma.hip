@@ -259,39 +259,69 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int kt_n = a.K / 128, ct_n = a.C / 128, RS = a.R * a.S;
+    // Work order: all (tap, k tile, c tile) workgroups of ONE pixel range run back to back on ONE XCD (block b
+    // is dispatched to XCD b % 8), so the dy / x slices of that range are read from HBM once and then served by
+    // that XCD's L2 to the other ~36 workgroups.  (Placement is a speed assumption only.)
+    const int combos = kt_n * ct_n * RS;
     long bid = blockIdx.x;
-    const int split = (int)(bid % a.splits); bid /= a.splits;
-    const int ct = (int)(bid % ct_n); bid /= ct_n;
-    const int kt = (int)(bid % kt_n); bid /= kt_n;
-    const int rs = (int)bid;
+    int split, combo;
+    if (a.splits % 8 == 0) {
+        const long xcd = bid & 7, j = bid >> 3;
+        combo = (int)(j % combos);
+        split = (int)((j / combos) * 8 + xcd);
+    } else {
+        combo = (int)(bid % combos);
+        split = (int)(bid / combos);
+    }
+    const int ct = combo % ct_n;
+    const int kt = (combo / ct_n) % kt_n;
+    const int rs = combo / (ct_n * kt_n);
     const int r = rs / a.S, s = rs - r * a.S;
     const int k0 = kt * 128, c0 = ct * 128;
     const long nchunks = (a.P + WP - 1) / WP;
     const long ch0 = (long)split * a.chunks_per_split;
     const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
 
+    // per-thread loader state: the 4 pieces a thread fetches per tile sit on rows (i*256 + tid) >> 4; their
+    // (n, ho, wo) is decomposed once and advanced by 64 pixels per chunk (no per-chunk divisions)
+    int ln[4], lho[4], lwo[4], lslot[4], lrow[4];
+    {
+        const long pbase = ch0 * WP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * 256 + tid;
+            lrow[i] = q >> 4;
+            lslot[i] = (q & 15) ^ ((lrow[i] & 3) << 2);
+            const long p = pbase + lrow[i];
+            lwo[i] = (int)(p % a.Wo);
+            const long t = p / a.Wo;
+            lho[i] = (int)(t % a.Ho);
+            ln[i] = (int)(t / a.Ho);
+        }
+    }
+    const int adv_h = WP / a.Wo, adv_w = WP - adv_h * a.Wo;     // 64 pixels = adv_h rows + adv_w columns
+
     auto stage = [&](long ch, int buf) {
         unsigned char* sa = smem + buf * WSTAGE;        // dy tile [64][128]
         unsigned char* sb = sa + WP * 256;              // x tile  [64][128]
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = i * 256 + tid;
-            const int row = q >> 4, slot = (q & 15) ^ ((row & 3) << 2);
-            const long p = ch * WP + row;
+            const long p = ch * WP + lrow[i];
             const unsigned short* sdy = a.zeros;
             const unsigned short* sx = a.zeros;
             if (p < a.P) {
-                sdy = a.dy + (size_t)p * a.K + k0 + slot * 8;
-                const int wo = (int)(p % a.Wo);
-                const long t = p / a.Wo;
-                const int ho = (int)(t % a.Ho);
-                const int n = (int)(t / a.Ho);
-                const int hi = ho * a.stride - a.pad + r * a.dil, wi = wo * a.stride - a.pad + s * a.dil;
+                sdy = a.dy + (size_t)p * a.K + k0 + lslot[i] * 8;
+                const int hi = lho[i] * a.stride - a.pad + r * a.dil, wi = lwo[i] * a.stride - a.pad + s * a.dil;
                 if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-                    sx = a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.C + c0 + slot * 8;
+                    sx = a.x + (((size_t)ln[i] * a.H + hi) * a.W + wi) * a.C + c0 + lslot[i] * 8;
             }
             glds16(sdy, sa + i * 4096 + wave * 1024);
             glds16(sx, sb + i * 4096 + wave * 1024);
+            // advance this row's pixel by one chunk
+            lwo[i] += adv_w;
+            lho[i] += adv_h;
+            if (lwo[i] >= a.Wo) { lwo[i] -= a.Wo; ++lho[i]; }
+            while (lho[i] >= a.Ho) { lho[i] -= a.Ho; ++ln[i]; }
         }
     };
 
@@ -356,6 +386,7 @@ int wgrad_splits(long P, int K, int C, int RS) {
     const long nchunks = (P + WP - 1) / WP;
     long s = (1024 + tiles - 1) / tiles;
     if (s > nchunks / 4) s = nchunks / 4;
+    if (s >= 8) s = (s + 7) / 8 * 8;       // multiples of 8: one pixel range per XCD at a time
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     return (int)s;
