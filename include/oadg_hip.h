@@ -168,6 +168,17 @@ int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const 
                                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, int dil, void* stream);
 
+/* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
+ * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with
+ * bias_in), fp32 [K,C,R,S] -> bf16 wf [K,R,S,C] and (optional) wt [C,R,S,K] flipped for the data gradient.
+ * _bwd: gwf bf16 [K,R,S,C], gbias fp32 [K] -> dw fp32 [K,C,R,S], dgamma fp32 [K] (d beta = gbias). */
+int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
+                           const float* var, float eps, const float* bias_in, int K, int C, int R, int S, void* wf,
+                           void* wt, float* bias, float* scale, void* stream);
+int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
+                               const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
+                               float* dgamma, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

@@ -39,6 +39,8 @@ SIGNATURES = {
     'oadg_conv2d_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 11 + [vp]),
     'oadg_conv2d_wgrad_workspace_bytes': (cs, [ci] * 7),
     'oadg_conv2d_wgrad_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, cs] + [ci] * 10 + [vp]),
+    'oadg_prep_conv_weights': (ci, [vp, vp, vp, vp, vp, cf, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
+    'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

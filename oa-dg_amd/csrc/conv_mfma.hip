@@ -428,3 +428,89 @@ extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float*
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
+
+// ================================================================================================ weight preparation
+// One launch per layer and step instead of ~10 element-wise launches: fold the eval-mode BatchNorm of
+// mmdet/models/backbones/resnet.py:648-657 into the convolution weight (w * gamma / sqrt(var + eps)) and bias
+// (beta - mean * scale), cast to bf16, lay out as KRSC for the forward kernel and as the flipped/transposed
+// C(R)(S)K copy the stride-1 data gradient consumes.  Its backward: d w = d wf * scale,
+// d gamma = (sum d wf * w - d bias * mean) / sqrt(var + eps), d beta = d bias.
+namespace {
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ var, float eps,
+                                                           const float* __restrict__ bias_in, int K, int C, int R,
+                                                           int S, unsigned short* __restrict__ wf,
+                                                           unsigned short* __restrict__ wt, float* __restrict__ bias,
+                                                           float* __restrict__ scale_out) {
+    const int k = blockIdx.x;
+    float scale = 1.f, b = bias_in ? bias_in[k] : 0.f;
+    if (gamma) {
+        scale = gamma[k] * rsqrtf(var[k] + eps);
+        b = beta[k] - mean[k] * scale;
+    }
+    if (threadIdx.x == 0) {
+        if (bias) bias[k] = b;
+        if (scale_out) scale_out[k] = scale;
+    }
+    const int RS = R * S, n = C * RS;
+    const float* wk = w + (size_t)k * n;
+    for (int i = threadIdx.x; i < n; i += 256) {      // i runs over the OUTPUT order (r, s, c): coalesced writes
+        const int c = i % C, rs = i / C;
+        const unsigned short v = f32_to_bf16(wk[(size_t)c * RS + rs] * scale);
+        wf[(size_t)k * n + i] = v;
+        if (wt) wt[((size_t)c * RS + (RS - 1 - rs)) * K + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned short* __restrict__ gwf,
+                                                               const float* __restrict__ gbias,
+                                                               const float* __restrict__ w,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ var, float eps, int K, int C,
+                                                               int R, int S, float* __restrict__ dw,
+                                                               float* __restrict__ dgamma) {
+    __shared__ float red[16];
+    const int k = blockIdx.x;
+    const int RS = R * S, n = C * RS;
+    const float sc = scale ? scale[k] : 1.f;
+    const float* wk = w + (size_t)k * n;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {      // i over (c, r, s): coalesced reads of w / writes of dw
+        const int rs = i % RS, c = i / RS;
+        const float g = bf16_to_f32(gwf[(size_t)k * n + (size_t)rs * C + c]);
+        dw[(size_t)k * n + i] = g * sc;
+        dot += g * wk[i];
+    }
+    if (dgamma) {
+        const float tot = block_sum(dot, red);
+        if (threadIdx.x == 0) dgamma[k] = (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
+                                      const float* var, float eps, const float* bias_in, int K, int C, int R, int S,
+                                      void* wf, void* wt, float* bias, float* scale, void* stream) {
+    if (!w || !wf || K < 1 || C < 1 || R < 1 || S < 1) return OADG_EARG;
+    if (gamma && (!beta || !mean || !var)) return OADG_EARG;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean, var, eps,
+                       bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+extern "C" int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
+                                          const float* mean, const float* var, float eps, int K, int C, int R, int S,
+                                          float* dw, float* dgamma, void* stream) {
+    if (!gwf || !w || !dw) return OADG_EARG;
+    if (dgamma && (!mean || !var)) return OADG_EARG;
+    hipLaunchKernelGGL(prep_weights_bwd_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)gwf, gbias, w, scale, mean, var, eps, K, C, R, S, dw, dgamma);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}

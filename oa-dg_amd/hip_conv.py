@@ -68,57 +68,131 @@ def _nhwc_bf16(t):
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
 
-class _Conv2dMFMA(torch.autograd.Function):
-    """y = [relu]( conv(x, w) + b [+ residual] ) in one kernel; backward = ReLU mask (one element-wise pass),
-    stride-1 data gradient on the same kernel, weight/bias gradients through aten (MIOpen) for now."""
+class _PrepWeights(torch.autograd.Function):
+    """(w fp32 [K,C,R,S], optional eval-mode BN, optional bias) -> (wf bf16 KRSC, bias fp32, wt bf16 for dgrad):
+    one launch (csrc/conv_mfma.hip prep_weights_kernel) instead of the ~10 element-wise ops of the unfused fold
+    and casts; the backward is one launch as well."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, stride, pad, dil, relu):
-        x16, w16 = _nhwc_bf16(x), _nhwc_bf16(weight)
-        b32 = bias.float().contiguous() if bias is not None else None
+    def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt):
+        L = _lib.lib()
+        K, C, R, S = w.shape
+        w = w.detach().float().contiguous()
+        dev = w.device
+        wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        wt = torch.empty((C, K, R, S), dtype=torch.bfloat16, device=dev,
+                         memory_format=torch.channels_last) if want_wt else None
+        has_bias = gamma is not None or bias_in is not None
+        bias = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+        scale = torch.empty((K,), dtype=torch.float32, device=dev) if gamma is not None else None
+        f = lambda t: t.detach().float().contiguous() if t is not None else None  # noqa: E731
+        g_, b_, m_, v_, bi_ = f(gamma), f(beta), f(mean), f(var), f(bias_in)
+        check(L.oadg_prep_conv_weights(ptr(w), ptr(g_), ptr(b_), ptr(m_), ptr(v_), float(eps), ptr(bi_), K, C, R, S,
+                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), stream_ptr()),
+              'oadg_prep_conv_weights')
+        ctx.save_for_backward(w, scale, m_, v_)
+        ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S)
+        outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
+        ctx.mark_non_differentiable(outs[2])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gwf, gbias, _gwt):
+        w, scale, mean, var = ctx.saved_tensors
+        eps, has_bn, has_bias_in, K, C, R, S = ctx.cfg
+        L = _lib.lib()
+        dw = dgamma = dbeta = dbias_in = None
+        gb = gbias.float().contiguous() if (gbias is not None and gbias.numel()) else None
+        if gwf is not None:
+            gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
+            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
+                                               R, S, ptr(dw), ptr(dgamma), stream_ptr()),
+                  'oadg_prep_conv_weights_bwd')
+        if has_bn:
+            dbeta = gb
+        elif has_bias_in:
+            dbias_in = gb
+        return dw, dgamma, dbeta, None, None, None, dbias_in, None
+
+
+def _wt_useful(x, K, C, stride, pad, dil, R):
+    return bool(x.requires_grad and stride == 1 and dil * (R - 1) - pad >= 0 and K % 64 == 0 and C % 128 == 0)
+
+
+def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
+    """(wf, bias, wt) for a convolution, BN-folded when ``bn`` is given.  Layers without trainable parameters are
+    prepared once (``cache_on`` = the module that owns the weight)."""
+    frozen = not (conv_weight.requires_grad or (bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad))
+                  or (bias_in is not None and bias_in.requires_grad))
+    key = None
+    if frozen and cache_on is not None:
+        key = (conv_weight._version, conv_weight.data_ptr(), want_wt) + \
+            ((bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+             if bn is not None else ())
+        c = getattr(cache_on, '_prepared', None)
+        if c is not None and c[0] == key:
+            return c[1]
+    if bn is not None:
+        out = _PrepWeights.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None,
+                                 want_wt)
+    else:
+        out = _PrepWeights.apply(conv_weight, None, None, None, None, 0.0, bias_in, want_wt)
+    wf, bias, wt = out
+    out = (wf, bias if bias.numel() else None, wt if wt.numel() else None)
+    if key is not None:
+        cache_on._prepared = (key, out)
+    return out
+
+
+class _Conv2dMFMA(torch.autograd.Function):
+    """y = [relu]( conv(x, wf) + bias [+ residual] ) in one kernel, on prepared bf16 weights; backward = ReLU mask
+    (one element-wise pass), stride-1 data gradient on the same kernel with ``wt``, weight/bias gradients through
+    aten (MIOpen) unless USE_HIP_WGRAD."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu):
+        x16 = _nhwc_bf16(x)
         r16 = _nhwc_bf16(residual) if residual is not None else None
-        y = conv_forward(x16, w16, b32, r16, stride, pad, dil, relu)
-        ctx.save_for_backward(x16, w16, y if relu else None)
-        ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, weight.dtype,
-                   bias.dtype if bias is not None else None, residual.dtype if residual is not None else None)
+        y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu)
+        ctx.save_for_backward(x16, wf, wt, y if relu else None)
+        ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, residual.dtype if residual is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x16, w16, y = ctx.saved_tensors
-        stride, pad, dil, has_bias, xdt, wdt, bdt, rdt = ctx.cfg
+        x16, wf, wt, y = ctx.saved_tensors
+        stride, pad, dil, has_bias, xdt, rdt = ctx.cfg
         gy = _nhwc_bf16(gy)
         if y is not None:
             gy = torch.ops.aten.threshold_backward(gy, y, 0)
-        K, C, R, S = w16.shape
+        K, C, R, S = wf.shape
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
-        pad_t = dil * (R - 1) - pad
-        if need_x and stride == 1 and pad_t >= 0 and K % 64 == 0 and C % 128 == 0:
-            # dx = conv(dy, W^T rotated by 180 degrees): the same kernel, channels swapped
-            wt = _nhwc_bf16(w16.flip(2, 3).transpose(0, 1))
-            gx = conv_forward(gy, wt, None, None, 1, pad_t, dil, False)
+        if need_x and wt is not None:
+            gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)   # dx = conv(dy, rot180(W)^T)
             need_x = False
         want_b = has_bias and ctx.needs_input_grad[2]
         gw = gb = None
         if USE_HIP_WGRAD and need_w and K % 128 == 0 and C % 128 == 0:
-            gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil).to(wdt)
+            gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
             need_w = False
             if want_b:
-                gb = gy.float().sum((0, 2, 3)).to(bdt)
+                gb = gy.float().sum((0, 2, 3))
                 want_b = False
         if need_x or need_w or want_b:
             outs = torch.ops.aten.convolution_backward(
-                gy, x16, w16, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
+                gy, x16, wf, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
                 1, [need_x, need_w, want_b])
             if gx is None:
                 gx = outs[0]
             if outs[1] is not None:
-                gw = outs[1].to(wdt)
+                gw = outs[1]
             if outs[2] is not None:
-                gb = outs[2].to(bdt)
+                gb = outs[2].float()
         gres = gy.to(rdt) if (rdt is not None and ctx.needs_input_grad[3]) else None
-        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None
+        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None
 
 
 def _norm3(stride, padding, dilation):
@@ -126,16 +200,31 @@ def _norm3(stride, padding, dilation):
     return t(stride), t(padding), t(dilation)
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None):
+def _applies(x, weight, stride, padding, dilation):
+    return supported(x, weight, stride, padding, dilation) and \
+        (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())     # fp32 parity runs keep fp32 arithmetic
+
+
+def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None, owner=None):
     """layers.conv2d implementation hook: returns None for shapes the kernel does not cover."""
     stride, padding, dilation = _norm3(stride, padding, dilation)
-    if not supported(x, weight, stride, padding, dilation):
+    if not _applies(x, weight, stride, padding, dilation):
         return None
-    if not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
-        return None      # fp32 parity runs keep fp32 arithmetic
-    return _Conv2dMFMA.apply(x, weight, bias, residual, stride[0], padding[0], dilation[0], bool(relu))
+    K, C, R, S = weight.shape
+    wf, b, wt = prepared(weight, None, bias, _wt_useful(x, K, C, stride[0], padding[0], dilation[0], R), owner)
+    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu))
+
+
+def conv_bn(x, conv, bn, relu=False, residual=None):
+    """layers.conv_bn implementation hook (eval-mode BN folded by the preparation kernel)."""
+    stride, padding, dilation = _norm3(conv.stride, conv.padding, conv.dilation)
+    if bn.training or conv.bias is not None or not _applies(x, conv.weight, stride, padding, dilation):
+        return None
+    K, C, R, S = conv.weight.shape
+    wf, b, wt = prepared(conv.weight, bn, None, _wt_useful(x, K, C, stride[0], padding[0], dilation[0], R), conv)
+    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu))
 
 
 def enable(on=True):
     from . import layers
-    layers.set_conv_impl(conv2d if on else None)
+    layers.set_conv_impl(conv2d if on else None, conv_bn if on else None)

@@ -8,12 +8,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-_CONV_IMPL = None   # set by hip_conv.enable(); signature (x, w, b, stride, padding, dilation) -> y or None
+_CONV_IMPL = None      # set by hip_conv.enable(): (x, w, b, stride, padding, dilation, relu, residual) -> y | None
+_CONV_BN_IMPL = None   # set by hip_conv.enable(): (x, conv, bn, relu, residual) -> y | None
 
 
-def set_conv_impl(fn):
-    global _CONV_IMPL
-    _CONV_IMPL = fn
+def set_conv_impl(fn, fn_bn=None):
+    global _CONV_IMPL, _CONV_BN_IMPL
+    _CONV_IMPL, _CONV_BN_IMPL = fn, fn_bn
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
@@ -52,6 +53,10 @@ def conv_bn(x, conv, bn, relu=False, residual=None):
         if residual is not None:
             y = y + residual
         return F.relu(y, inplace=True) if relu else y
+    if _CONV_BN_IMPL is not None and x.is_cuda:
+        y = _CONV_BN_IMPL(x, conv, bn, relu, residual)
+        if y is not None:
+            return y
     frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)
     key = None
     if frozen:   # constant until the parameters/buffers are overwritten: fold once

@@ -104,3 +104,34 @@ def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, d
     assert dw.shape == w.grad.shape
     err = (dw - w.grad).abs().max().item()
     assert err <= 2e-3 * w.grad.abs().max().item(), (err, w.grad.abs().max().item())
+
+
+def test_prepared_weights_fold_bn_forward_backward(dev):
+    """csrc prep_weights kernels: BN fold + layouts and their backward against the unfused torch expression."""
+    import torch.nn as nn
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(5)
+    K, C, R = 128, 64, 3
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) / 24).requires_grad_(True)
+    bn = nn.BatchNorm2d(K).to(dev).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(K, device=dev, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(K, device=dev, generator=g))
+        bn.running_mean.copy_(torch.randn(K, device=dev, generator=g))
+        bn.running_var.copy_(torch.rand(K, device=dev, generator=g) + 0.5)
+    wf, b, wt = hip_conv.prepared(w, bn, None, True)
+    scale = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    wref = w.detach() * scale.view(-1, 1, 1, 1)
+    assert (wf.float() - wref).abs().max() <= 4e-3 * wref.abs().max()
+    assert torch.allclose(b, bn.bias.detach() - bn.running_mean * scale, rtol=1e-6, atol=1e-6)
+    assert torch.equal(wt, wf.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+    gw = torch.randn(K, C, R, R, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    gb = torch.randn(K, device=dev, generator=g)
+    torch.autograd.backward([wf, b], [gw, gb])
+    w2 = w.detach().clone().requires_grad_(True)
+    gam, bet = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    s2 = gam * torch.rsqrt(bn.running_var + bn.eps)
+    torch.autograd.backward([w2 * s2.view(-1, 1, 1, 1), bet - bn.running_mean * s2], [gw.float(), gb])
+    assert torch.allclose(w.grad, w2.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.weight.grad, gam.grad, rtol=1e-4, atol=1e-4)
+    assert torch.allclose(bn.bias.grad, bet.grad, rtol=1e-6, atol=1e-6)
