@@ -257,18 +257,69 @@ def _pinned_to(t_cpu, device):
     return t_cpu.pin_memory().to(device, non_blocking=True)
 
 
-def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):
-    """RandomSampler.sample for a list of images with ONE device->host read.
+class PendingSampling:
+    """RandomSampler.sample for a list of images, split in two so that the single device->host read never
+    stalls the stream: :func:`sample_many_begin` enqueues the candidate masks and an asynchronous copy of the
+    candidate counts (pinned buffer + event recorded right behind it); ``finish()`` waits for THAT event only -
+    work enqueued in between keeps the device busy - draws the permutations on the host in image order and
+    locates the chosen candidates on the device by their rank among the candidates.
 
-    Equivalent, image by image and in image order, to ``sampler.sample(...)`` (base_sampler.py:38-103,
-    random_sampler.py:32-82): the same candidates, the same ``torch.randperm(n)`` draws from the global CPU
-    generator (first positives, then negatives), the same sorted index lists.  The reference discovers the
-    candidate counts through ``nonzero`` (one synchronisation per call); here the counts of all images are
-    read at once, the permutations are drawn on the host and the chosen candidates are located on the
-    device through their rank among the candidates."""
-    n_img = len(assign_results)
+    Equivalent, image by image, to ``sampler.sample(...)`` (base_sampler.py:38-103, random_sampler.py:32-82):
+    same candidates, same ``torch.randperm(n)[:num]`` draws from the global CPU generator (positives first, then
+    negatives), same sorted index lists."""
+
+    def __init__(self, sampler, prepared, gt_bboxes_list, counts_dev):
+        self.sampler, self.prepared, self.gt_bboxes_list = sampler, prepared, gt_bboxes_list
+        self.results = None
+        self.event = None
+        if counts_dev is None:
+            self.counts = []
+        elif counts_dev.is_cuda:
+            self.counts = torch.empty(counts_dev.shape, dtype=counts_dev.dtype, pin_memory=True)
+            self.counts.copy_(counts_dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.counts = counts_dev
+
+    def finish(self):
+        if self.results is not None:
+            return self.results
+        if self.event is not None:
+            self.event.synchronize()
+        sampler = self.sampler
+        counts = self.counts.tolist() if isinstance(self.counts, torch.Tensor) else self.counts
+        num_pos_exp = int(sampler.num * sampler.pos_fraction)
+        results = []
+        for i, ((ar, bboxes, gt_flags, pos_mask, neg_mask), (n_pos, n_neg)) in enumerate(zip(self.prepared, counts)):
+            dev = bboxes.device
+
+            def choose(mask, n_cand, n_exp):
+                if n_cand <= n_exp:
+                    k, sel = n_cand, mask
+                else:
+                    k = n_exp
+                    perm = _pinned_to(randperm_prefix(n_cand, n_exp), dev)       # random_sampler.py:58
+                    flags = torch.zeros(mask.numel() + 1, dtype=torch.bool, device=dev)
+                    flags[perm] = True
+                    rank = torch.cumsum(mask, 0) - 1
+                    sel = mask & flags[rank.clamp(min=0)]
+                if k == 0:
+                    return torch.zeros((0,), dtype=torch.long, device=dev), 0
+                return torch.nonzero_static(sel, size=k).squeeze(1), k
+            pos_inds, k_pos = choose(pos_mask, n_pos, num_pos_exp)
+            n_neg_exp = sampler.num - k_pos
+            if sampler.neg_pos_ub >= 0:
+                n_neg_exp = min(n_neg_exp, int(sampler.neg_pos_ub * max(1, k_pos)))
+            neg_inds, _ = choose(neg_mask, n_neg, n_neg_exp)
+            results.append(SamplingResult(pos_inds, neg_inds, bboxes, self.gt_bboxes_list[i], ar, gt_flags))
+        self.results = results
+        return results
+
+
+def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):
     prepared = []
-    for i in range(n_img):
+    for i in range(len(assign_results)):
         ar, bboxes, gtb = assign_results[i], bboxes_list[i], gt_bboxes_list[i]
         if len(bboxes.shape) < 2:
             bboxes = bboxes[None, :]
@@ -280,36 +331,14 @@ def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_
             bboxes = torch.cat([gtb, bboxes], dim=0)
             ar.add_gt_(gt_labels_list[i])
             gt_flags = torch.cat([bboxes.new_ones(gtb.shape[0], dtype=torch.uint8), gt_flags])
-        pos_mask, neg_mask = ar.gt_inds > 0, ar.gt_inds == 0
-        prepared.append((ar, bboxes, gt_flags, pos_mask, neg_mask))
-    if n_img == 0:
-        return []
-    dev = prepared[0][1].device
-    counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared]).tolist()   # the one read
-    num_pos_exp = int(sampler.num * sampler.pos_fraction)
-    results = []
-    for i, ((ar, bboxes, gt_flags, pos_mask, neg_mask), (n_pos, n_neg)) in enumerate(zip(prepared, counts)):
-        def choose(mask, n_cand, n_exp):
-            if n_cand <= n_exp:
-                k = n_cand
-                sel = mask
-            else:
-                k = n_exp
-                perm = _pinned_to(randperm_prefix(n_cand, n_exp), dev)       # random_sampler.py:58
-                flags = torch.zeros(mask.numel() + 1, dtype=torch.bool, device=dev)
-                flags[perm] = True
-                rank = torch.cumsum(mask, 0) - 1
-                sel = mask & flags[rank.clamp(min=0)]
-            if k == 0:
-                return torch.zeros((0,), dtype=torch.long, device=dev), 0
-            return torch.nonzero_static(sel, size=k).squeeze(1), k
-        pos_inds, k_pos = choose(pos_mask, n_pos, num_pos_exp)
-        n_neg_exp = sampler.num - k_pos
-        if sampler.neg_pos_ub >= 0:
-            n_neg_exp = min(n_neg_exp, int(sampler.neg_pos_ub * max(1, k_pos)))
-        neg_inds, _ = choose(neg_mask, n_neg, n_neg_exp)
-        results.append(SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes_list[i], ar, gt_flags))
-    return results
+        prepared.append((ar, bboxes, gt_flags, ar.gt_inds > 0, ar.gt_inds == 0))
+    counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared]) if prepared else None
+    return PendingSampling(sampler, prepared, gt_bboxes_list, counts)
+
+
+def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):
+    """begin + finish in one call."""
+    return sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list).finish()
 
 
 # ----------------------------------------------------------------------------------------------- coder

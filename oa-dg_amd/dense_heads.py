@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 from . import hip_ops
 from .core import anchor_inside_flags, images_to_levels, multi_apply, unmap
-from .core.bbox import sample_many
+from .core.bbox import sample_many, sample_many_begin
 from .layers import Conv2d, conv2d, normal_init
 from .registry import (HEADS, build_assigner, build_bbox_coder, build_loss, build_prior_generator,
                        build_sampler)
@@ -120,7 +120,11 @@ class AnchorHead(nn.Module):
             gt_labels_list = [None] * num_imgs
         fast = (getattr(self, '_all_anchors_valid', False) and self.train_cfg.allowed_border < 0 and
                 all(g is None for g in gt_bboxes_ignore_list) and hasattr(self.sampler, 'random_choice'))
-        if fast:   # one host read for the whole batch instead of ~6 per image
+        pending = getattr(self, '_pending_targets', None)
+        self._pending_targets = None
+        if fast and pending is not None and pending[0] == (num_imgs, tuple(num_level_anchors)):
+            srs = pending[1].finish()       # assigned at the start of the step (begin_targets)
+        elif fast:   # one host read for the whole batch instead of ~6 per image
             ars = [self.assigner.assign(concat_anchors[i], gt_bboxes_list[i], None,
                                         None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]
             srs = sample_many(self.sampler, ars, concat_anchors, gt_bboxes_list)
@@ -138,6 +142,22 @@ class AnchorHead(nn.Module):
                 images_to_levels(all_label_weights, num_level_anchors),
                 images_to_levels(all_bbox_targets, num_level_anchors),
                 images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
+
+    def begin_targets(self, pad_hw, gt_bboxes, img_metas, device):
+        """Anchor targets depend on anchors and gts only, not on the network: enqueue the IoU / assignment of all
+        images and the asynchronous read of the sampler's candidate counts BEFORE the backbone runs, so the
+        read has long completed when :meth:`loss` needs it (the reference computes them inside loss(),
+        anchor_head.py:455-544, and stalls the device there)."""
+        import math
+        sizes = [(math.ceil(pad_hw[0] / s[1]), math.ceil(pad_hw[1] / s[0])) for s in self.prior_generator.strides]
+        anchor_list, _ = self.get_anchors(sizes, img_metas, device=device)
+        if not (self._all_anchors_valid and self.train_cfg.allowed_border < 0 and
+                hasattr(self.sampler, 'random_choice')):
+            return
+        flat = torch.cat(anchor_list[0])
+        ars = [self.assigner.assign(flat, gt_bboxes[i], None, None) for i in range(len(img_metas))]
+        pend = sample_many_begin(self.sampler, ars, [flat] * len(img_metas), gt_bboxes)
+        self._pending_targets = ((len(img_metas), tuple(a.size(0) for a in anchor_list[0])), pend)
 
     # -- loss ----------------------------------------------------------------------------------------
     def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
@@ -176,7 +196,8 @@ class AnchorHead(nn.Module):
         return multi_apply(self.forward_single, feats)
 
     def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None,
-                      proposal_cfg=None, num_proposal_imgs=None, padded_proposals=False, **kwargs):
+                      proposal_cfg=None, num_proposal_imgs=None, padded_proposals=False, after_proposals=None,
+                      **kwargs):
         """base_dense_head.py:302-342.  ``num_proposal_imgs`` limits proposal generation to the first images
         (the contrastive RoI head only consumes the view-1 lists, contrastive_roi_head.py:85-95)."""
         outs = self(x)
@@ -186,6 +207,8 @@ class AnchorHead(nn.Module):
         if proposal_cfg is not None:
             proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
                                             num_imgs=num_proposal_imgs, padded=padded_proposals)
+        if after_proposals is not None:
+            after_proposals(proposal_list)      # e.g. the RoI head's assignment + asynchronous count read
         losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
         if proposal_cfg is None:
             return losses

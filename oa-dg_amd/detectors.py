@@ -144,15 +144,27 @@ class TwoStageDetector(BaseDetector):
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None,
                       proposals=None, **kwargs):
+        # Host/device choreography: the two host reads of the step (sampler candidate counts
+        # of the RPN and of the RoI head) are asynchronous copies followed by an event; each is waited for only
+        # after more device work has been enqueued behind it, so the stream never drains.
+        if self.with_rpn and gt_bboxes_ignore is None and hasattr(self.rpn_head, 'begin_targets'):
+            self.rpn_head.begin_targets(img.shape[2:], gt_bboxes, img_metas, img.device)
         x = self.extract_feat(img)
         losses = dict()
+        pending = {}
         if self.with_rpn:
             proposal_cfg = self.train_cfg.get('rpn_proposal', self.test_cfg.rpn if self.test_cfg else None)
             # the contrastive RoI head reads the view-1 proposal lists only (contrastive_roi_head.py:85-95)
             n_prop = kwargs['batch_size'] if 'num_views' in kwargs else None
+
+            def after_proposals(props):
+                if gt_bboxes_ignore is None and hasattr(self.roi_head, 'begin_sampling'):
+                    pending['roi'] = self.roi_head.begin_sampling(props, gt_bboxes, gt_labels, len(img_metas),
+                                                                  **kwargs)
             rpn_losses, proposal_list = self.rpn_head.forward_train(
                 x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
-                proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop, padded_proposals=True)
+                proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop, padded_proposals=True,
+                after_proposals=after_proposals)
             losses.update(rpn_losses)
         else:
             proposal_list = proposals
@@ -163,7 +175,8 @@ class TwoStageDetector(BaseDetector):
             kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
             kwargs.pop('img_metas_host', None)
         losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
-                                                  gt_bboxes_ignore, gt_masks, **kwargs))
+                                                  gt_bboxes_ignore, gt_masks,
+                                                  pending_sampling=pending.get('roi'), **kwargs))
         return losses
 
     def get_random_proposal_list(self, img, gt_bboxes, kwargs):

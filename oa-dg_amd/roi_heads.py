@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from . import hip_ops
 from .core import bbox2roi, multi_apply
-from .core.bbox import sample_many
+from .core.bbox import sample_many, sample_many_begin
 from .layers import normal_init, xavier_init
 from .losses import accuracy
 from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_bbox_coder, build_head,
@@ -316,7 +316,7 @@ class BaseRoIHead(nn.Module):
 class StandardRoIHead(BaseRoIHead):
     """standard_roi_head.py:11-200 (bbox branch)."""
 
-    def _assign_and_sample(self, x, n, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore):
+    def _assign_and_sample(self, x, n, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore, defer=False):
         """Per image: MaxIoU assign + RandomSampler (standard_roi_head.py:88-101).  Proposal lists may be
         padded to a fixed length with score -1 rows (RPNHead.get_bboxes(padded=True)); those rows are never
         candidates.  All images share one host read of the candidate counts."""
@@ -327,7 +327,8 @@ class StandardRoIHead(BaseRoIHead):
                 p = proposal_list[i]
                 valid = p[:, 4] >= 0 if p.size(1) == 5 else torch.ones_like(p[:, 0], dtype=torch.bool)
                 ars.append(self.bbox_assigner.assign_masked(p[:, :4], valid, gt_bboxes[i], gt_labels[i]))
-            return sample_many(self.bbox_sampler, ars, proposal_list[:n], gt_bboxes[:n], gt_labels[:n])
+            pend = sample_many_begin(self.bbox_sampler, ars, proposal_list[:n], gt_bboxes[:n], gt_labels[:n])
+            return pend if defer else pend.finish()
         out = []
         for i in range(n):
             ar = self.bbox_assigner.assign(proposal_list[i], gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
@@ -344,12 +345,25 @@ class StandardRoIHead(BaseRoIHead):
             total += npos + nneg
         return total, (torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long))
 
+    def begin_sampling(self, proposal_list, gt_bboxes, gt_labels, num_imgs, **kwargs):
+        """Enqueue assignment + the asynchronous candidate-count read for the images that will be sampled; the
+        detector calls this right after the NMS and passes the handle back as ``pending_sampling``."""
+        n = kwargs['batch_size'] if 'num_views' in kwargs else num_imgs
+        return self._assign_and_sample(None, n, proposal_list, gt_bboxes, gt_labels, [None] * num_imgs, defer=True)
+
     def forward_train(self, x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None,
-                      gt_masks=None, **kwargs):
+                      gt_masks=None, pending_sampling=None, **kwargs):
         num_imgs = len(img_metas)
         if gt_bboxes_ignore is None:
             gt_bboxes_ignore = [None] * num_imgs
-        if 'num_views' not in kwargs:
+        if pending_sampling is not None and hasattr(pending_sampling, 'finish'):
+            first = pending_sampling.finish()
+            sampling_results = list(first)
+            if 'num_views' in kwargs:
+                sampling_results = []
+                for _ in range(kwargs['num_views']):
+                    sampling_results.extend(first)
+        elif 'num_views' not in kwargs:
             sampling_results = self._assign_and_sample(x, num_imgs, proposal_list, gt_bboxes, gt_labels,
                                                        gt_bboxes_ignore)
         else:   # assign/sample on the first view only, replicate the lists (contrastive_roi_head.py:84-97)
