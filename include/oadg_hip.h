@@ -115,7 +115,12 @@ enum {
     OADG_OP_SOLARIZE = 4,    /* param = threshold */
     OADG_OP_IMAGE = 5,       /* image = uint8 [H,W,3] holding the op's full result (bboxes_only_* ops) */
     OADG_OP_BG_WARP = 6,     /* bg_only_* : minv = inverted affine */
-    OADG_OP_WARP_NEG = 7     /* 'invert' of augmix.all: -warpAffine (uint8 wrap) */
+    OADG_OP_WARP_NEG = 7,    /* 'invert' of augmix.all: -warpAffine (uint8 wrap) */
+    /* PIL.ImageEnhance of augmix.all (augmix.py:192-212): minv[0] = factor; CONTRAST: image -> int64 luma sum */
+    OADG_OP_ENH_BRIGHTNESS = 8,
+    OADG_OP_ENH_COLOR = 9,
+    OADG_OP_ENH_CONTRAST = 10,
+    OADG_OP_ENH_SHARPNESS = 11
 };
 typedef struct {
     int kind;
@@ -137,6 +142,7 @@ int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int 
                         double* scores, void* stream);
 int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream);
 int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream);
+int oadg_oamix_gray_sum(const uint8_t* img, long npix, long long* sum, void* stream);
 int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, int rx0, int ry0, int rw, int rh,
                          const float* My_row, const float* Mx_row, uint8_t* scratch, void* stream);
 int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,

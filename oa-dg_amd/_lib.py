@@ -20,6 +20,7 @@ class RegionOp(Structure):
 
 
 OP_COPY, OP_LUT_AUTOCONTRAST, OP_LUT_EQUALIZE, OP_POSTERIZE, OP_SOLARIZE, OP_IMAGE, OP_BG_WARP, OP_WARP_NEG = range(8)
+OP_ENH_BRIGHTNESS, OP_ENH_COLOR, OP_ENH_CONTRAST, OP_ENH_SHARPNESS = 8, 9, 10, 11
 
 # name -> (restype, argtypes); must list every symbol include/oadg_hip.h declares
 SIGNATURES = {
@@ -47,6 +48,7 @@ SIGNATURES = {
     'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp]),
     'oadg_oamix_hist': (ci, [vp, cl, vp, vp]),
     'oadg_oamix_luts': (ci, [vp, vp, vp]),
+    'oadg_oamix_gray_sum': (ci, [vp, cl, vp, vp]),
     'oadg_oamix_bbox_step': (ci, [vp, ci, ci, POINTER(cd), ci, ci, ci, ci, vp, vp, vp, vp]),
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,

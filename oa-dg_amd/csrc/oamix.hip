@@ -329,6 +329,45 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
             }
             break;
         }
+        case OADG_OP_ENH_BRIGHTNESS:
+        case OADG_OP_ENH_COLOR:
+        case OADG_OP_ENH_CONTRAST:
+        case OADG_OP_ENH_SHARPNESS: {
+            // PIL.ImageEnhance: Image.blend(degenerate, image, factor) with float32 arithmetic; the degenerate
+            // image is black / the pixel's luma / the global mean luma / the 3x3 SMOOTH filter output
+            const float alpha = (float)op.minv[0];
+            int deg[3];
+            if (op.kind == OADG_OP_ENH_BRIGHTNESS) {
+                deg[0] = deg[1] = deg[2] = 0;
+            } else if (op.kind == OADG_OP_ENH_COLOR) {
+                deg[0] = deg[1] = deg[2] = (src[p] * 19595 + src[p + 1] * 38470 + src[p + 2] * 7471 + 0x8000) >> 16;
+            } else if (op.kind == OADG_OP_ENH_CONTRAST) {
+                const long long sum = *reinterpret_cast<const long long*>(op.image);
+                deg[0] = deg[1] = deg[2] = (int)((double)sum / (double)((long)H * W) + 0.5);
+            } else {
+                if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
+                    deg[0] = src[p]; deg[1] = src[p + 1]; deg[2] = src[p + 2];
+                } else {
+                    const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+                    for (int c = 0; c < 3; ++c) {
+                        float ss = 0.5f;
+                        for (int dy = 1; dy >= -1; --dy) {           // rows y+1, y, y-1 (Filter.c order)
+                            const uint8_t* r = src + ((size_t)(y + dy) * W + x) * 3 + c;
+                            const float kc = dy == 0 ? k5 : k1;
+                            ss = ss + (((float)r[-3] * k1 + (float)r[0] * kc) + (float)r[3] * k1);
+                        }
+                        deg[c] = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+                    }
+                }
+            }
+            for (int c = 0; c < 3; ++c) {
+                const int a0 = deg[c], b0 = src[p + c];
+                const float t = (float)a0 + alpha * (float)(b0 - a0);
+                if (alpha >= 0.f && alpha <= 1.f) out[c] = (uint8_t)t;
+                else out[c] = t <= 0.f ? 0 : (t >= 255.f ? 255 : (uint8_t)t);
+            }
+            break;
+        }
         case OADG_OP_WARP_NEG: {
             Warp wp;
             for (int i = 0; i < 6; ++i) wp.m[i] = op.minv[i];
@@ -626,6 +665,19 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     if (tid == 0) scores[b] = tot / (double)((long)w * h);
 }
 
+__global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* __restrict__ img, long npix,
+                                                       unsigned long long* __restrict__ out) {
+    // sum of PIL's "L" conversion over the image (ImageStat mean for ImageEnhance.Contrast)
+    unsigned long long s = 0;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npix; p += (long)gridDim.x * 256)
+        s += (unsigned long long)((img[p * 3] * 19595 + img[p * 3 + 1] * 38470 + img[p * 3 + 2] * 7471 + 0x8000) >> 16);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
 int grid1d(long n, int block) { return (int)((n + block - 1) / block); }
 
 }  // namespace
@@ -682,6 +734,19 @@ int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream) {
     return OADG_OK;
 }
 
+int oadg_oamix_gray_sum(const uint8_t* img, long npix, long long* sum, void* stream) {
+    if (!img || !sum || npix < 0) return OADG_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sum, 0, sizeof(long long), st);
+    if (e != hipSuccess) return (int)e;
+    int g = grid1d(npix, 256 * 8);
+    if (g > 1024) g = 1024;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(gray_sum_kernel, dim3(g), dim3(256), 0, st, img, npix, (unsigned long long*)sum);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
 int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream) {
     if (!hist || !luts) return OADG_EARG;
     hipLaunchKernelGGL(luts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, hist, luts);
@@ -718,7 +783,7 @@ int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oad
         a.op[k] = ops_host[k];
         const int kd = a.op[k].kind;
         if ((kd == OADG_OP_LUT_AUTOCONTRAST || kd == OADG_OP_LUT_EQUALIZE) && !luts) return OADG_EARG;
-        if (kd == OADG_OP_IMAGE && !a.op[k].image) return OADG_EARG;
+        if ((kd == OADG_OP_IMAGE || kd == OADG_OP_ENH_CONTRAST) && !a.op[k].image) return OADG_EARG;
         if (kd == OADG_OP_BG_WARP && (!union_f || !union_u8)) return OADG_EARG;
     }
     for (int k = 0; k < 2; ++k)

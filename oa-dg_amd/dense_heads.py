@@ -118,15 +118,15 @@ class AnchorHead(nn.Module):
             gt_bboxes_ignore_list = [None] * num_imgs
         if gt_labels_list is None:
             gt_labels_list = [None] * num_imgs
-        fast = (getattr(self, '_all_anchors_valid', False) and self.train_cfg.allowed_border < 0 and
-                all(g is None for g in gt_bboxes_ignore_list) and hasattr(self.sampler, 'random_choice'))
+        fast = (all(g is None for g in gt_bboxes_ignore_list) and hasattr(self.sampler, 'random_choice') and
+                hasattr(self.assigner, 'assign_masked') and not getattr(self, 'reference_order_targets', False))
         pending = getattr(self, '_pending_targets', None)
         self._pending_targets = None
         if fast and pending is not None and pending[0] == (num_imgs, tuple(num_level_anchors)):
             srs = pending[1].finish()       # assigned at the start of the step (begin_targets)
         elif fast:   # one host read for the whole batch instead of ~6 per image
-            ars = [self.assigner.assign(concat_anchors[i], gt_bboxes_list[i], None,
-                                        None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]
+            ars = [self._assign_inside(concat_anchors[i], concat_flags[i], gt_bboxes_list[i], img_metas[i],
+                                       None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]
             srs = sample_many(self.sampler, ars, concat_anchors, gt_bboxes_list)
         else:
             srs = [None] * num_imgs
@@ -143,6 +143,16 @@ class AnchorHead(nn.Module):
                 images_to_levels(all_bbox_targets, num_level_anchors),
                 images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
 
+    def _assign_inside(self, flat_anchors, valid_flags, gt_bboxes, img_meta, gt_labels=None):
+        """Assignment over the anchors the reference keeps (anchor_inside_flags, anchor/utils.py:19-43) without
+        compacting them: anchors outside get gt_ind -1, so they are neither candidates nor part of any maximum,
+        and the targets come out already 'unmapped' (anchor_head.py:285-295)."""
+        if self._all_anchors_valid and self.train_cfg.allowed_border < 0:
+            return self.assigner.assign(flat_anchors, gt_bboxes, None, gt_labels)
+        inside = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2],
+                                     self.train_cfg.allowed_border)
+        return self.assigner.assign_masked(flat_anchors, inside, gt_bboxes, gt_labels)
+
     def begin_targets(self, pad_hw, gt_bboxes, img_metas, device):
         """Anchor targets depend on anchors and gts only, not on the network: enqueue the IoU / assignment of all
         images and the asynchronous read of the sampler's candidate counts BEFORE the backbone runs, so the
@@ -150,12 +160,12 @@ class AnchorHead(nn.Module):
         anchor_head.py:455-544, and stalls the device there)."""
         import math
         sizes = [(math.ceil(pad_hw[0] / s[1]), math.ceil(pad_hw[1] / s[0])) for s in self.prior_generator.strides]
-        anchor_list, _ = self.get_anchors(sizes, img_metas, device=device)
-        if not (self._all_anchors_valid and self.train_cfg.allowed_border < 0 and
-                hasattr(self.sampler, 'random_choice')):
+        anchor_list, flag_list = self.get_anchors(sizes, img_metas, device=device)
+        if not (hasattr(self.sampler, 'random_choice') and hasattr(self.assigner, 'assign_masked')):
             return
         flat = torch.cat(anchor_list[0])
-        ars = [self.assigner.assign(flat, gt_bboxes[i], None, None) for i in range(len(img_metas))]
+        ars = [self._assign_inside(flat, torch.cat(flag_list[i]), gt_bboxes[i], img_metas[i])
+               for i in range(len(img_metas))]
         pend = sample_many_begin(self.sampler, ars, [flat] * len(img_metas), gt_bboxes)
         self._pending_targets = ((len(img_metas), tuple(a.size(0) for a in anchor_list[0])), pend)
 

@@ -202,7 +202,8 @@ class OAMix:
             b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()], scratch=u8(),
                      acc=torch.empty((H, W, 3), dtype=torch.float32, device=dev),
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
-                     luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev))
+                     luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
+                     gray=torch.empty((1,), dtype=torch.int64, device=dev))
             self._bufs[key] = b
         return b
 
@@ -267,7 +268,17 @@ class OAMix:
             op.kind = OP_WARP_NEG
             op.minv[:] = invert_affine(np.float32([[1, 0, tx], [0, 1, ty]]))
         elif name in ('color', 'contrast', 'brightness', 'sharpness'):
-            raise NotImplementedError(f'{name}: the ImageEnhance ops of version="augmix.all" are not built yet')
+            # PIL.ImageEnhance.X(img).enhance(factor), augmix.py:192-212
+            op.minv[0] = float_parameter(sample_level(self.severity), 1.8) + 0.1
+            op.kind = {'color': _lib.OP_ENH_COLOR, 'contrast': _lib.OP_ENH_CONTRAST,
+                       'brightness': _lib.OP_ENH_BRIGHTNESS, 'sharpness': _lib.OP_ENH_SHARPNESS}[name]
+            if name == 'contrast':
+                if step.get('gray_for') is not src:
+                    b = self._buffers(st)
+                    check(_lib.lib().oadg_oamix_gray_sum(ptr(src), st.H * st.W, ptr(b['gray']), stream_ptr()),
+                          'oadg_oamix_gray_sum')
+                    step['gray_for'] = src
+                op.image = self._buffers(st)['gray'].data_ptr()
         else:
             scope, kind = name.split('_only_')
             if kind.endswith('_xy'):

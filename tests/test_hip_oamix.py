@@ -65,7 +65,11 @@ def test_saliency_scores_close(dev):
 @pytest.mark.parametrize('seed,version,H,W,n_gt', [(0, 'augmix', 128, 256, 5), (1, 'augmix', 160, 256, 5),
                                                    (2, 'augmix', 192, 320, 7), (3, 'augmix', 128, 256, 0),
                                                    (4, 'augmix', 256, 512, 12), (5, 'augmix', 130, 254, 4),
-                                                   (6, 'augmix', 128, 256, 5), (7, 'augmix', 128, 256, 5)])
+                                                   (6, 'augmix', 128, 256, 5), (7, 'augmix', 128, 256, 5),
+                                                   (0, 'augmix.all', 128, 256, 5), (1, 'augmix.all', 160, 256, 5),
+                                                   (2, 'augmix.all', 192, 320, 7), (3, 'augmix.all', 128, 256, 4),
+                                                   (4, 'augmix.all', 256, 512, 9), (5, 'augmix.all', 130, 254, 4),
+                                                   (8, 'augmix.all', 128, 256, 5), (9, 'augmix.all', 128, 256, 5)])
 def test_oamix_view_bit_exact(dev, seed, version, H, W, n_gt):
     from oadg_amd.pipelines import OAMix
     img, gts = _case(seed, H, W, n_gt)

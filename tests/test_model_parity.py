@@ -122,3 +122,31 @@ def test_product_step_matches_reference_on_gpu(dev, golden_dir):
     for k, v in grad_groups(det).items():
         ref = float(g['gn_' + k])
         assert abs(v - ref) <= 2e-2 * ref, (k, v, ref)
+
+
+@pytest.mark.gpu
+def test_r101_dc5_oadg_config_trains_one_step(dev):
+    """BASELINE configs[3]: R101-DC5 (dilated C5, no FPN, 2048-channel RoI path, allowed_border=0, OA-Mix
+    'augmix.all') builds from configs/oadg/faster_rcnn_r101_dc5_1x_dwd_oadg.py and runs a full bf16 step."""
+    from oadg_amd import Config, build_detector, hip_conv
+    from oadg_amd.apis import TrainEngine, build_optimizer, set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r101_dc5_1x_dwd_oadg.py'))
+    set_random_seed(0)
+    det = build_detector(cfg.model)
+    det.init_weights()
+    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    assert sum(p.numel() for p in det.parameters()) == 184580783
+    hip_conv.enable()
+    try:
+        eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
+        ds = SyntheticCityscapes(img_shape=(352, 640), num_boxes=8, num_classes=7, box_size=(24, 160), device=dev)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
+        for it in range(2):
+            imgs, boxes, labels = ds.batch([2 * it, 2 * it + 1])
+            out = eng.step(pipe(imgs, boxes, labels))
+            loss = float(out['loss'])
+            assert np.isfinite(loss) and loss > 0
+    finally:
+        hip_conv.enable(False)
+    assert {'loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'acc', 'loss_bbox', 'loss_cont', 'loss'} <= set(out['log_vars'])
