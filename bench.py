@@ -26,6 +26,24 @@ CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_o
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
+PROFILE_TAG = 'r01'
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of this same command
+    (profiles/r01_pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter).  Counters are in
+    KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide coalesced reads; WRITE_SIZE is
+    taken as reported (uncalibrated).  PMC counters cannot be collected from inside the timed run, so the value
+    is the latest committed measurement, with its source named; null when no summary is present."""
+    try:
+        tot = 0.0
+        for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+            rows = json.load(open(os.path.join(ROOT, 'profiles', f'{PROFILE_TAG}_pmc_{c}.json')))
+            tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
+        return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
+                'traffic_source': f'profiles/{PROFILE_TAG}_pmc_FETCH_SIZE.json x2 + {PROFILE_TAG}_pmc_WRITE_SIZE.json'}
+    except (OSError, StopIteration, KeyError, ValueError):
+        return {'traffic': None}
 
 
 def parse():
@@ -55,8 +73,8 @@ def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56):
 
 
 def cpu_baseline(cfg, seconds_budget=30.0):
-    """The CPU port of the step (our host logic + oracle/ ops + the OA-Mix oracle) on ONE quarter-resolution
-    image (512x1024): a bounded sample of the same workload.  value is scaled by the pixel ratio (1/4)."""
+    """The CPU port of the step (our host logic + oracle/ ops + the OA-Mix oracle) on ONE full-resolution image
+    (1024x2048, 20 boxes, both views): a bounded sample of the same workload, no extrapolation."""
     from oadg_amd import build_detector
     from oadg_amd.apis import build_optimizer
     from oadg_amd.detectors import integrate_data
@@ -67,7 +85,7 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     prev_threads = torch.get_num_threads()
     threads = min(prev_threads, 32)      # many-core hosts: small CPU ops do not scale past a few dozen threads
     torch.set_num_threads(threads)
-    H, W = 512, 1024
+    H, W = 1024, 2048
     rs = np.random.RandomState(0)
     img = lowpass_image(rs, H, W)
     gts = synthetic_boxes(rs, 20, H, W, 12, 200)
@@ -98,9 +116,8 @@ def cpu_baseline(cfg, seconds_budget=30.0):
         opt.step()
     t_all = time.time() - t0
     torch.set_num_threads(prev_threads)
-    return dict(value=round((1.0 / t_all) * (H * W) / (1024.0 * 2048.0), 5), unit='images/s', cores=threads,
-                kind='port',
-                sample=f'1 image at {H}x{W} (1/4 of the pixels; value scaled by 1/4): OA-Mix oracle {t_mix:.1f}s + '
+    return dict(value=round(1.0 / t_all, 5), unit='images/s', cores=threads, kind='port',
+                sample=f'1 image at {H}x{W} (one of the 4 images of a step): OA-Mix oracle {t_mix:.1f}s + '
                        f'detector step with oracle ops {t_all - t_mix:.1f}s, torch {threads} threads, '
                        f'nproc={os.cpu_count()}')
 
@@ -184,16 +201,18 @@ def main():
     #      launches / number of launches, divided by the mean launch duration.  Otherwise RoIAlign backward.
     elem = 2 if amp is not None else 4
     if conv_timers:
-        ms = [s_.elapsed_time(e_) for s_, e_, _ in conv_timers]
-        flops = [f for _, _, f in conv_timers]
+        ms = [t[0].elapsed_time(t[1]) for t in conv_timers]
+        flops = [t[2] for t in conv_timers]
         avg_ms, per_launch = sum(ms) / len(ms), sum(flops) / len(flops)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12
         roof = {'kernel': 'conv_igemm_kernel', 'bound': 'mfma', 'achieved': round(achieved, 1),
                 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                 'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
                 'algorithmic_flops_per_launch': int(per_launch),
+                'algorithmic_bytes_per_launch': int(sum(t[3] for t in conv_timers) / len(conv_timers)),
                 'launches_per_step': round(len(ms) / a.steps, 1),
                 'kernel_ms_per_step': round(sum(ms) / a.steps, 2)}
+        roof.update(pmc_traffic('conv_igemm_kernel'))
     else:
         ms = [s_.elapsed_time(e_) for s_, e_ in pairs]
         rois = getattr(det.roi_head, '_last_rois', None)

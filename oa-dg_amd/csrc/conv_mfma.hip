@@ -46,10 +46,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // block -> (m tile, n tile): the K/BN column blocks of one pixel tile are adjacent (shared A through L2)
+    // Workgroup b is dispatched to XCD b % 8 (observed; used for speed only).  Each XCD gets a CONTIGUOUS range
+    // of pixel tiles (and all K/BN column tiles of a pixel tile back to back), so the halo rows that neighbouring
+    // tiles of a 3x3 convolution share, and the A rows the column tiles share, are served by that XCD's L2
+    // instead of being fetched through the fabric once per XCD.
     const int n_tiles = a.K / BN;
+    const long m_tiles = (a.M + BM - 1) / BM;
     const long bid = blockIdx.x;
-    const int nt = (int)(bid % n_tiles);
-    const long mt = bid / n_tiles;
+    long mt;
+    int nt;
+    {
+        const long xcd = bid & 7, j = bid >> 3;              // j-th workgroup of this XCD
+        const long per = (m_tiles + 7) >> 3;                 // pixel tiles per XCD
+        nt = (int)(j % n_tiles);
+        mt = xcd * per + j / n_tiles;
+        if (j / n_tiles >= per || mt >= m_tiles) return;     // padding of the last XCD range
+    }
     const long m0 = mt * BM;
     const int k0 = nt * BN;
 
@@ -201,7 +213,8 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
-    const long blocks = ((a.M + BM - 1) / BM) * (K / BN);
+    const long m_tiles = (a.M + BM - 1) / BM;
+    const long blocks = ((m_tiles + 7) / 8) * 8 * (K / BN);      // 8 equal XCD ranges (the kernel drops the padding)
     if (blocks > 0x7fffffffL) return OADG_EARG;
     hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, a);
     OADG_LAUNCH_CHECK();
