@@ -301,7 +301,7 @@ class PendingSampling:
                     k = n_exp
                     perm = _pinned_to(randperm_prefix(n_cand, n_exp), dev)       # random_sampler.py:58
                     flags = torch.zeros(mask.numel() + 1, dtype=torch.bool, device=dev)
-                    flags[perm] = True
+                    flags.index_fill_(0, perm, True)   # (flags[perm] = True blocks the host, see dense_heads)
                     rank = torch.cumsum(mask, 0) - 1
                     sel = mask & flags[rank.clamp(min=0)]
                 if k == 0:

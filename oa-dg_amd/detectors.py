@@ -7,6 +7,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .core import bbox_overlaps_np
+from .core.bbox import _pinned_to
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
@@ -86,18 +87,46 @@ class BaseDetector(nn.Module):
         log_vars['loss'] = loss
         names = list(log_vars.keys())
         packed = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
-        if dist.is_available() and dist.is_initialized():
-            packed = torch.cat([packed, packed.new_tensor([float(len(names))])])
+        distributed = dist.is_available() and dist.is_initialized()
+        if distributed:
+            # base.py:258-265 checks that every rank logs the same variables; the count rides in the same
+            # all-reduce and is verified without a per-step host synchronisation (see _check_log_count)
+            packed = torch.cat([packed, packed.new_full((1,), float(len(names)))])
             dist.all_reduce(packed)
-            assert int(round(packed[-1].item())) == len(names) * dist.get_world_size(), \
-                f'loss log variables are different across GPUs! rank {dist.get_rank()} keys: {names}'
-            packed = packed[:-1] / dist.get_world_size()
+            expect = len(names) * dist.get_world_size()
+            count, packed = packed[-1], packed[:-1] / dist.get_world_size()
         if getattr(self, 'log_vars_on_host', True):
-            vals = packed.tolist()
+            if distributed:
+                vals = torch.cat([packed, count.view(1)]).tolist()          # one host read
+                assert int(round(vals.pop())) == expect, \
+                    f'loss log variables are different across GPUs! rank {dist.get_rank()} keys: {names}'
+            else:
+                vals = packed.tolist()
             log_vars = OrderedDict(zip(names, vals))
         else:   # benchmark mode: keep the packed device tensor, no host synchronisation per step
+            if distributed:
+                self._check_log_count(count, expect, names)
             log_vars = OrderedDict(zip(names, packed.unbind(0)))
         return loss, log_vars
+
+    def _check_log_count(self, count, expect, names):
+        """Deferred form of the reference's cross-rank assertion: this step's all-reduced count is copied to a
+        pinned buffer asynchronously and the PREVIOUS step's copy (long complete) is the one asserted on."""
+        prev = getattr(self, '_log_count_pending', None)
+        if prev is not None:
+            buf, ev, exp, nm = prev
+            ev.synchronize()
+            assert int(round(buf.item())) == exp, \
+                f'loss log variables are different across GPUs! rank {dist.get_rank()} keys: {nm}'
+        if count.is_cuda:
+            buf = torch.empty((), dtype=count.dtype, pin_memory=True)
+            buf.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._log_count_pending = (buf, ev, expect, names)
+        else:
+            assert int(round(count.item())) == expect, \
+                f'loss log variables are different across GPUs! rank {dist.get_rank()} keys: {names}'
 
     def train_step(self, data, optimizer):
         """base.py:413-455."""
@@ -208,7 +237,7 @@ class TwoStageDetector(BaseDetector):
                                             bboxes_xy=gts[i % kwargs['num_views']], scales=cfg['scales'],
                                             ratios=cfg['ratios'], iou_max=cfg['iou_max'], iou_min=cfg['iou_min'])
             out[i] = np.concatenate([out[i], new[:, :4].astype(np.float32)], axis=0)
-        return [torch.as_tensor(o).float().to(device) for o in out]
+        return [_pinned_to(torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32)), device) for o in out]
 
 
 @DETECTORS.register_module()

@@ -64,11 +64,15 @@ def main():
         out = eng.step(batch())
     torch.cuda.synchronize()
     print('warm log_vars', out['log_vars'])
+    batches = [batch() for _ in range(a.steps)]
+    torch.cuda.synchronize()
     t0 = time.time()
-    for _ in range(a.steps):
-        out = eng.step(batch())
+    for b_ in batches:
+        out = eng.step(b_)
+    t_host = (time.time() - t0) / a.steps
     torch.cuda.synchronize()
     dt = (time.time() - t0) / a.steps
+    print(f'host enqueue {t_host * 1e3:.1f} ms/step')
     print(f'amp={a.amp} n={a.n} {a.h}x{a.w}: {dt * 1e3:.1f} ms/step  {a.n / dt:.2f} img/s  '
           f'mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
     if a.prof:
@@ -77,6 +81,7 @@ def main():
             eng.step(batch())
             torch.cuda.synchronize()
         print(p.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60))
+        print(p.key_averages().table(sort_by='self_cpu_time_total', row_limit=45, max_name_column_width=60))
 
 
 if __name__ == '__main__':
