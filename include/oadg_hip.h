@@ -185,6 +185,15 @@ int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float*
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
                                float* dgamma, void* stream);
 
+/* fused backward of the conv epilogue y = relu(conv + bias [+ residual]) (Bottleneck.forward resnet.py:285-300,
+ * RPNHead.forward_single rpn_head.py:62 `F.relu(x, inplace=True)`, the bias/BN-shift gradient of every conv):
+ *   g = dy * (y > 0) as bf16 (y == NULL: no mask), dbias[k] = sum over the M pixels of g[., k]
+ * dy: bf16 or fp32 (dy_is_f32) [M,K] rows = NHWC pixels; g may be NULL when only dbias is wanted from a bf16 dy.
+ * K % 8 == 0.  Deterministic (fixed-order partials in `workspace`). */
+size_t oadg_relu_bias_bwd_workspace_bytes(long M, int K);
+int oadg_relu_bias_bwd(const void* dy, int dy_is_f32, const void* y, void* g, float* dbias, void* workspace,
+                       size_t workspace_bytes, long M, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

@@ -1,0 +1,177 @@
+// Fused backward of the convolution epilogue  y = relu(conv + bias [+ residual]):
+//   g = dy * (y > 0)            (torch threshold_backward; relu of resnet.py:285-300 / rpn_head.py:62)
+//   dbias[k] = sum over pixels of g[., k]
+// in ONE pass over dy (and y) instead of a mask pass, a cast pass and a strided column reduction.  HBM-bound:
+// reads M*K*(sizeof dy + 2) bytes, writes M*K*2 bytes (nothing when only the column sums are wanted).
+// Deterministic: per-block column partials in a fixed row order, then a fixed-order reduction over the blocks.
+#include "common.h"
+#include "../../include/oadg_hip.h"
+
+namespace {
+
+constexpr int EB_THREADS = 256;
+constexpr int EB_MAX_BLOCKS = 1024;
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {   // round to nearest even (torch's fp32 -> bf16)
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// Thread t owns channel group cg = t % G (8 channels, 16 B of bf16) and row phase rp = t / G of the block's row
+// range; consecutive threads read consecutive 16-B pieces of a pixel row (coalesced).
+template <bool DY_F32, bool MASK, bool WRITE>
+__global__ __launch_bounds__(EB_THREADS) void relu_bias_bwd_kernel(const void* __restrict__ dy_,
+                                                                    const unsigned short* __restrict__ y,
+                                                                    unsigned short* __restrict__ g, float* __restrict__ part,
+                                                                    long M, int K, long rows_per_block) {
+    __shared__ float red[EB_THREADS][9];
+    const int G = K >> 3;                                  // channel groups per row
+    const int RP = EB_THREADS / G > 0 ? EB_THREADS / G : 1;  // row phases per pass (G <= 256)
+    const int t = threadIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    // G > 256 (K > 2048): a thread strides over several channel groups of the row
+    for (int cg = t % (G < EB_THREADS ? G : EB_THREADS); cg < G; cg += EB_THREADS) {
+        const int rp = G < EB_THREADS ? t / G : 0;
+        if (rp >= RP) break;
+#pragma unroll 2
+        for (long r = r0 + rp; r < r1; r += RP) {
+            const long off = r * K + ((long)cg << 3);
+            float v[8];
+            if (DY_F32) {
+                const float4 a = *reinterpret_cast<const float4*>((const float*)dy_ + off);
+                const float4 b = *reinterpret_cast<const float4*>((const float*)dy_ + off + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+                const uint4 a = *reinterpret_cast<const uint4*>((const unsigned short*)dy_ + off);
+                const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[2 * i] = __uint_as_float(w[i] << 16);
+                    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+                }
+            }
+            if (MASK) {
+                const uint4 m = *reinterpret_cast<const uint4*>(y + off);
+                const unsigned w[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (!(bf2f((unsigned short)(w[i] & 0xffffu)) > 0.f)) v[2 * i] = 0.f;
+                    if (!(bf2f((unsigned short)(w[i] >> 16)) > 0.f)) v[2 * i + 1] = 0.f;
+                }
+            }
+            if (WRITE) {
+                unsigned o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned short lo = f2bf(v[2 * i]), hi = f2bf(v[2 * i + 1]);
+                    o[i] = (unsigned)lo | ((unsigned)hi << 16);
+                    if (DY_F32) {      // sum what the consumers of g will see
+                        v[2 * i] = bf2f(lo);
+                        v[2 * i + 1] = bf2f(hi);
+                    }
+                }
+                *reinterpret_cast<uint4*>(g + off) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+        if (G >= EB_THREADS) {       // no row phases to combine: this thread owns the whole column group
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                part[(long)blockIdx.x * K + (cg << 3) + i] = acc[i];
+                acc[i] = 0.f;
+            }
+        }
+    }
+    if (G >= EB_THREADS) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[t][i] = acc[i];
+    __syncthreads();
+    if (t < G) {
+        float s[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[i] = 0.f;
+        for (int rp = 0; rp < RP; ++rp)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s[i] += red[rp * G + t][i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[(long)blockIdx.x * K + (t << 3) + i] = s[i];
+    }
+}
+
+// out[k] = sum_b part[b][k] in a fixed order: 16 block slices x 16 channels per workgroup.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             int nblocks, int K) {
+    __shared__ float red[16][17];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (k < K) {
+        const int per = (nblocks + 15) >> 4;
+        const int b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += part[(long)b * K + k];
+    }
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][c];
+        out[k] = tot;
+    }
+}
+
+int plan_blocks(long M, int K, long* rows_per_block) {
+    const int G = K >> 3;
+    const int RP = EB_THREADS / G > 0 ? EB_THREADS / G : 1;
+    long rpb = (M + EB_MAX_BLOCKS - 1) / EB_MAX_BLOCKS;
+    const long min_rows = (long)RP * 4;                    // at least 4 passes per block
+    if (rpb < min_rows) rpb = min_rows;
+    rpb = (rpb + RP - 1) / RP * RP;
+    *rows_per_block = rpb;
+    return (int)((M + rpb - 1) / rpb);
+}
+
+}  // namespace
+
+extern "C" size_t oadg_relu_bias_bwd_workspace_bytes(long M, int K) {
+    if (M <= 0 || K <= 0 || (K & 7)) return 0;
+    long rpb;
+    return (size_t)plan_blocks(M, K, &rpb) * K * sizeof(float);
+}
+
+extern "C" int oadg_relu_bias_bwd(const void* dy, int dy_is_f32, const void* y, void* g, float* dbias,
+                                  void* workspace, size_t workspace_bytes, long M, int K, void* stream) {
+    if (!dy || !dbias || !workspace || M <= 0 || K <= 0 || (K & 7)) return OADG_EARG;
+    if (!g && (y || dy_is_f32)) return OADG_EARG;         // a masked / converted gradient has to be written somewhere
+    long rpb;
+    const int nb = plan_blocks(M, K, &rpb);
+    if (workspace_bytes < (size_t)nb * K * sizeof(float)) return OADG_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)workspace;
+    const unsigned short* yy = (const unsigned short*)y;
+    unsigned short* gg = (unsigned short*)g;
+#define EB_LAUNCH(F32, MASK, WRITE) \
+    hipLaunchKernelGGL((relu_bias_bwd_kernel<F32, MASK, WRITE>), dim3(nb), dim3(EB_THREADS), 0, st, dy, yy, gg, part, M, K, rpb)
+    if (dy_is_f32) {
+        if (y) EB_LAUNCH(true, true, true); else EB_LAUNCH(true, false, true);
+    } else if (y) {
+        EB_LAUNCH(false, true, true);
+    } else if (g) {
+        EB_LAUNCH(false, false, true);
+    } else {
+        EB_LAUNCH(false, false, false);
+    }
+#undef EB_LAUNCH
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(256), 0, st, part, dbias, nb, K);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}

@@ -70,6 +70,24 @@ def _nhwc_bf16(t):
     return t.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 
 
+def relu_bias_bwd(gy, y, want_bias):
+    """(g, dbias): g = bf16(gy) * (y > 0) (``y`` None: no mask) and dbias = g.sum over (N,H,W), in one pass over gy
+    (csrc/eltwise.hip).  gy: fp32 or bf16 [N,K,H,W] with channels_last strides."""
+    N, K, H, W = gy.shape
+    f32 = gy.dtype == torch.float32
+    write = f32 or y is not None
+    L = _lib.lib()
+    M = N * H * W
+    g = torch.empty((N, K, H, W), dtype=torch.bfloat16, device=gy.device,
+                    memory_format=torch.channels_last) if write else None
+    nbytes = L.oadg_relu_bias_bwd_workspace_bytes(M, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=gy.device)
+    db = torch.empty((K,), dtype=torch.float32, device=gy.device)
+    check(L.oadg_relu_bias_bwd(ptr(gy), int(f32), ptr(y), ptr(g), ptr(db), ptr(ws), nbytes, M, K, stream_ptr()),
+          'oadg_relu_bias_bwd')
+    return (g if write else gy), (db if want_bias else None)
+
+
 class _PrepWeights(torch.autograd.Function):
     """(w fp32 [K,C,R,S], optional eval-mode BN, optional bias) -> (wf bf16 KRSC, bias fp32, wt bf16 for dgrad):
     one launch (csrc/conv_mfma.hip prep_weights_kernel) instead of the ~10 element-wise ops of the unfused fold
@@ -166,17 +184,23 @@ class _Conv2dMFMA(torch.autograd.Function):
     def backward(ctx, gy):
         x16, wf, wt, y = ctx.saved_tensors
         stride, pad, dil, has_bias, xdt, rdt = ctx.cfg
-        gy = _nhwc_bf16(gy)
-        if y is not None:
-            gy = torch.ops.aten.threshold_backward(gy, y, 0)
         K, C, R, S = wf.shape
+        want_b = has_bias and ctx.needs_input_grad[2]
+        gb = None
+        if (y is not None or want_b) and gy.dtype in (torch.bfloat16, torch.float32) and K % 8 == 0 and \
+                gy.is_contiguous(memory_format=torch.channels_last):
+            gy, gb = relu_bias_bwd(gy, y, want_b)            # mask + cast + bias gradient: one pass over dy
+            want_b = False
+        else:
+            gy = _nhwc_bf16(gy)
+            if y is not None:
+                gy = torch.ops.aten.threshold_backward(gy, y, 0)
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
         if need_x and wt is not None:
             gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)   # dx = conv(dy, rot180(W)^T)
             need_x = False
-        want_b = has_bias and ctx.needs_input_grad[2]
-        gw = gb = None
+        gw = None
         if USE_HIP_WGRAD and need_w and K % 128 == 0 and C % 128 == 0:
             gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
             need_w = False

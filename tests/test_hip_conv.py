@@ -135,3 +135,35 @@ def test_prepared_weights_fold_bn_forward_backward(dev):
     assert torch.allclose(w.grad, w2.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn.weight.grad, gam.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(bn.bias.grad, bet.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,K,H,W,f32,mask', [
+    (2, 256, 37, 53, False, True),      # bottleneck / RPN relu gradient
+    (1, 64, 19, 21, False, True),
+    (2, 2048, 9, 11, False, True),      # one channel group per thread
+    (1, 4096, 5, 7, False, True),       # more channel groups than threads
+    (2, 24, 33, 17, False, True),       # thread count not a multiple of the group count
+    (2, 256, 40, 48, True, False),      # fp32 dy (RoIAlign backward output): cast + bias gradient
+    (2, 512, 16, 24, True, True),
+    (3, 256, 31, 29, False, False),     # bias gradient only, nothing written
+])
+def test_relu_bias_bwd_matches_torch(dev, N, K, H, W, f32, mask):
+    """g bit-exact with torch's cast + threshold_backward; dbias within fp32 summation-order error."""
+    from oadg_amd import hip_conv
+    gen = torch.Generator(device=dev).manual_seed(K + H)
+    dy = torch.randn(N, K, H, W, device=dev, generator=gen).contiguous(memory_format=torch.channels_last)
+    if not f32:
+        dy = dy.bfloat16()
+    y = torch.relu(torch.randn(N, K, H, W, device=dev, generator=gen)).bfloat16() \
+        .contiguous(memory_format=torch.channels_last) if mask else None
+    g, db = hip_conv.relu_bias_bwd(dy, y, True)
+    ref = dy.to(torch.bfloat16)
+    if mask:
+        ref = torch.ops.aten.threshold_backward(ref, y, 0)
+    assert g.dtype == torch.bfloat16 and g.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(g, ref)
+    ref_db = ref.double().sum((0, 2, 3))
+    scale = ref.double().abs().sum((0, 2, 3)).max().item()
+    assert (db.double() - ref_db).abs().max().item() <= 1e-6 * scale
+    # deterministic: same bits on a second call
+    assert torch.equal(db, hip_conv.relu_bias_bwd(dy, y, True)[1])

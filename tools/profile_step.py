@@ -77,11 +77,11 @@ def main():
           f'mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB')
     if a.prof:
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as p:
             eng.step(batch())
             torch.cuda.synchronize()
         print(p.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60))
-        print(p.key_averages().table(sort_by='self_cpu_time_total', row_limit=45, max_name_column_width=60))
+        print(p.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=90, max_name_column_width=50, max_shapes_column_width=90))
 
 
 if __name__ == '__main__':
