@@ -194,6 +194,14 @@ size_t oadg_relu_bias_bwd_workspace_bytes(long M, int K);
 int oadg_relu_bias_bwd(const void* dy, int dy_is_f32, const void* y, void* g, float* dbias, void* workspace,
                        size_t workspace_bytes, long M, int K, void* stream);
 
+/* FPN top-down step  laterals[i-1] += F.interpolate(laterals[i], size=..., mode='nearest')  (necks/fpn.py:166-175)
+ * in one pass, bf16 NHWC: out[n,h,w,:] = lat[n,h,w,:] + top[n, src(h), src(w), :] with ATen's nearest index
+ * src(d) = min(floor(d * in/out), in-1).  _bwd: dtop = the sum of g over the pixels each source feeds
+ * (d lat = g itself).  C % 8 == 0. */
+int oadg_fpn_topdown_fwd(const void* lat, const void* top, void* out, int N, int H, int W, int Ht, int Wt, int C,
+                         void* stream);
+int oadg_fpn_topdown_bwd(const void* g, void* dtop, int N, int H, int W, int Ht, int Wt, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

@@ -44,6 +44,8 @@ SIGNATURES = {
     'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_relu_bias_bwd_workspace_bytes': (ctypes.c_size_t, [cl, ci]),
     'oadg_relu_bias_bwd': (ci, [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, cl, ci, vp]),
+    'oadg_fpn_topdown_fwd': (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    'oadg_fpn_topdown_bwd': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -139,6 +139,86 @@ int plan_blocks(long M, int K, long* rows_per_block) {
     return (int)((M + rpb - 1) / rpb);
 }
 
+// ---- FPN top-down step (fpn.py:166-175): out = lat + nearest_upsample(top), and its backward ------------------
+// ATen's nearest index: src = min(floor(dst * (float)in / out), in - 1).
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+    const int s = (int)floorf((float)dst * scale);
+    return s < in_size - 1 ? s : in_size - 1;
+}
+
+__device__ __forceinline__ void unpack8(const uint4 a, float* v) {
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(w[i] << 16);
+        v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    unsigned o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+    return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+__global__ __launch_bounds__(256) void fpn_topdown_fwd_kernel(const unsigned short* __restrict__ lat,
+                                                              const unsigned short* __restrict__ top,
+                                                              unsigned short* __restrict__ out, int N, int H, int W,
+                                                              int Ht, int Wt, int C8, float sh, float sw) {
+    const long total = (long)N * H * W * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int w = (int)(p % W);
+        p /= W;
+        const int h = (int)(p % H), n = (int)(p / H);
+        const long src = (((long)n * Ht + nearest_src(h, sh, Ht)) * Wt + nearest_src(w, sw, Wt)) * C8 + c8;
+        float a[8], b[8];
+        unpack8(reinterpret_cast<const uint4*>(lat)[i], a);
+        unpack8(reinterpret_cast<const uint4*>(top)[src], b);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += b[k];
+        reinterpret_cast<uint4*>(out)[i] = pack8(a);
+    }
+}
+
+// d top[n, ht, wt, :] = sum of g over the destination pixels whose nearest source is (ht, wt)
+__global__ __launch_bounds__(256) void fpn_topdown_bwd_kernel(const unsigned short* __restrict__ g,
+                                                              unsigned short* __restrict__ dtop, int N, int H, int W,
+                                                              int Ht, int Wt, int C8, float sh, float sw) {
+    const long total = (long)N * Ht * Wt * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int wt = (int)(p % Wt);
+        p /= Wt;
+        const int ht = (int)(p % Ht), n = (int)(p / Ht);
+        // candidate destination range: a superset of {d : nearest_src(d) == s}, filtered exactly below
+        int h0 = (int)floorf((float)ht / sh) - 1, h1 = (int)ceilf((float)(ht + 1) / sh) + 1;
+        int w0 = (int)floorf((float)wt / sw) - 1, w1 = (int)ceilf((float)(wt + 1) / sw) + 1;
+        if (ht == Ht - 1) h1 = H - 1;          // the clamp of nearest_src folds every overshoot into the last source
+        if (wt == Wt - 1) w1 = W - 1;
+        h0 = h0 < 0 ? 0 : h0;
+        w0 = w0 < 0 ? 0 : w0;
+        h1 = h1 > H - 1 ? H - 1 : h1;
+        w1 = w1 > W - 1 ? W - 1 : w1;
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int h = h0; h <= h1; ++h) {
+            if (nearest_src(h, sh, Ht) != ht) continue;
+            for (int w = w0; w <= w1; ++w) {
+                if (nearest_src(w, sw, Wt) != wt) continue;
+                float v[8];
+                unpack8(reinterpret_cast<const uint4*>(g)[(((long)n * H + h) * W + w) * C8 + c8], v);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += v[k];
+            }
+        }
+        reinterpret_cast<uint4*>(dtop)[i] = pack8(acc);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t oadg_relu_bias_bwd_workspace_bytes(long M, int K) {
@@ -172,6 +252,30 @@ extern "C" int oadg_relu_bias_bwd(const void* dy, int dy_is_f32, const void* y, 
 #undef EB_LAUNCH
     OADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(256), 0, st, part, dbias, nb, K);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+extern "C" int oadg_fpn_topdown_fwd(const void* lat, const void* top, void* out, int N, int H, int W, int Ht, int Wt,
+                                    int C, void* stream) {
+    if (!lat || !top || !out || N <= 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || C <= 0 || (C & 7)) return OADG_EARG;
+    const long total = (long)N * H * W * (C >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fpn_topdown_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)lat, (const unsigned short*)top, (unsigned short*)out, N, H, W, Ht, Wt,
+                       C >> 3, (float)Ht / (float)H, (float)Wt / (float)W);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+extern "C" int oadg_fpn_topdown_bwd(const void* g, void* dtop, int N, int H, int W, int Ht, int Wt, int C,
+                                    void* stream) {
+    if (!g || !dtop || N <= 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || C <= 0 || (C & 7)) return OADG_EARG;
+    const long total = (long)N * Ht * Wt * (C >> 3);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(fpn_topdown_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)g, (unsigned short*)dtop, N, H, W, Ht, Wt, C >> 3,
+                       (float)Ht / (float)H, (float)Wt / (float)W);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -186,6 +186,38 @@ def roi_align_fpn(feats, rois, out_size, scales, finest_scale=56, sampling_ratio
                               aligned, *feats)
 
 
+# ------------------------------------------------------------------------------- FPN top-down
+class _FpnTopDown(torch.autograd.Function):
+    """lat + nearest_upsample(top) (necks/fpn.py:166-175) on bf16 NHWC maps, one pass each way."""
+
+    @staticmethod
+    def forward(ctx, lat, top):
+        require_cuda(lat, top)
+        lat, top = _as_nhwc(lat), _as_nhwc(top)
+        N, C, H, W = lat.shape
+        out = torch.empty_like(lat)
+        check(_lib.lib().oadg_fpn_topdown_fwd(ptr(lat), ptr(top), ptr(out), N, H, W, top.shape[2], top.shape[3], C,
+                                              stream_ptr()), 'oadg_fpn_topdown_fwd')
+        ctx.shapes = (tuple(lat.shape), tuple(top.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (N, C, H, W), ts = ctx.shapes
+        g = _as_nhwc(g.to(torch.bfloat16))
+        dtop = None
+        if ctx.needs_input_grad[1]:
+            dtop = torch.empty(ts, dtype=torch.bfloat16, device=g.device, memory_format=torch.channels_last)
+            check(_lib.lib().oadg_fpn_topdown_bwd(ptr(g), ptr(dtop), N, H, W, ts[2], ts[3], C, stream_ptr()),
+                  'oadg_fpn_topdown_bwd')
+        return (g if ctx.needs_input_grad[0] else None), dtop
+
+
+def fpn_topdown(lat, top):
+    """laterals[i-1] + F.interpolate(laterals[i], size=laterals[i-1].shape[2:], mode='nearest')."""
+    return _FpnTopDown.apply(lat, top)
+
+
 # --------------------------------------------------------------------------------------- NMS
 def nms_sorted_batched(boxes, counts, iou_thr, max_keep=-1):
     """Greedy NMS on boxes [I, Mmax, 4] already sorted by descending score (and class-offset).

@@ -1,8 +1,11 @@
 """FPN neck (mmdet/models/necks/fpn.py:12-205) for the configurations the named configs use:
 add_extra_convs=False, no norm/activation on the lateral/output convs, nearest-neighbour top-down path,
 extra levels by stride-2 subsampling (max_pool2d with kernel 1)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import hip_ops
 
 from .layers import ConvModule, xavier_init
 from .registry import NECKS
@@ -50,6 +53,10 @@ class FPN(nn.Module):
         for i in range(n - 1, 0, -1):   # fpn.py:166-175
             if 'scale_factor' in self.upsample_cfg:
                 laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], **self.upsample_cfg)
+            elif laterals[i].is_cuda and laterals[i].dtype == torch.bfloat16 and \
+                    laterals[i - 1].dtype == torch.bfloat16 and self.upsample_cfg.get('mode') == 'nearest' and \
+                    laterals[i].shape[1] % 8 == 0:
+                laterals[i - 1] = hip_ops.fpn_topdown(laterals[i - 1], laterals[i])      # fused, csrc/eltwise.hip
             else:
                 laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                                   **self.upsample_cfg)

@@ -167,3 +167,24 @@ def test_relu_bias_bwd_matches_torch(dev, N, K, H, W, f32, mask):
     assert (db.double() - ref_db).abs().max().item() <= 1e-6 * scale
     # deterministic: same bits on a second call
     assert torch.equal(db, hip_conv.relu_bias_bwd(dy, y, True)[1])
+
+
+@pytest.mark.parametrize('N,C,H,W,Ht,Wt', [(2, 256, 32, 48, 16, 24), (1, 64, 25, 31, 13, 16), (2, 8, 7, 9, 3, 4)])
+def test_fpn_topdown_matches_torch(dev, N, C, H, W, Ht, Wt):
+    """fused lat + nearest_upsample(top) and its backward (fpn.py:166-175) against torch in fp32 on the same bf16
+    operands: one bf16 rounding of the result."""
+    from oadg_amd import hip_ops
+    gen = torch.Generator(device=dev).manual_seed(H)
+    mk = lambda *s: torch.randn(*s, device=dev, generator=gen).bfloat16().contiguous(  # noqa: E731
+        memory_format=torch.channels_last)
+    lat, top, g = mk(N, C, H, W), mk(N, C, Ht, Wt), mk(N, C, H, W)
+    lat.requires_grad_(True)
+    top.requires_grad_(True)
+    out = hip_ops.fpn_topdown(lat, top)
+    out.backward(g)
+    lf, tf = lat.detach().float().requires_grad_(True), top.detach().float().requires_grad_(True)
+    ref = lf + F.interpolate(tf, size=(H, W), mode='nearest')
+    ref.backward(g.float())
+    assert torch.equal(out, ref.bfloat16())
+    assert torch.equal(lat.grad, g)
+    assert torch.equal(top.grad, tf.grad.bfloat16())

@@ -44,6 +44,7 @@ def main():
     ap.add_argument('--amp', default='bf16')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--prof', action='store_true')
+    ap.add_argument('--shapes', action='store_true')
     ap.add_argument('--conv', default='mfma')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -80,8 +81,21 @@ def main():
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as p:
             eng.step(batch())
             torch.cuda.synchronize()
-        print(p.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60))
-        print(p.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=90, max_name_column_width=50, max_shapes_column_width=90))
+        import collections
+        from torch.autograd import DeviceType
+        agg = collections.defaultdict(lambda: [0.0, 0])
+        for e in p.events():
+            if e.device_type == DeviceType.CUDA:
+                agg[e.name][0] += e.device_time
+                agg[e.name][1] += 1
+        tot = sum(v[0] for v in agg.values())
+        print(f'device kernels: {tot / 1e3:.2f} ms, {sum(v[1] for v in agg.values())} launches')
+        for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+            print(f'{v[0] / 1e3:8.3f} ms {v[1]:5d}  {k[:230]}')
+        if a.shapes:
+            print(p.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=90,
+                                                                  max_name_column_width=50,
+                                                                  max_shapes_column_width=90))
 
 
 if __name__ == '__main__':
