@@ -144,19 +144,24 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const flo
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 __device__ __forceinline__ float load1(const unsigned short* p) { return bf16_to_f32(*p); }
 
-// Backward: scatter g/count to the four corners of every sample (atomic fp32 adds into the level's gradient
-// map).  Lane l owns channels l, l+64, l+128, l+192 of a 256-channel group, so each wave-wide atomic covers
-// 256 contiguous bytes (two cache lines) of one pixel instead of 64 words strided over 1 KiB.
+// Backward.  The bilinear weight of a sample factorises, w(y, x) = wy(y) * wx(x), the samples of a bin form a
+// product grid and the validity test / border clamps of a sample are per axis, so the total weight a bin puts on
+// pixel (py, px) is WY[ph][py] * WX[pw][px] with two small 1-D tables (sum over iy, sum over ix).  The gradient
+// of a pixel of the RoI's footprint is then a GATHER over the few bins whose spans contain it:
+//     d feat[py][px][c] += (1/count) * sum_{ph, pw} WY[ph][py] WX[pw][px] g[ph][pw][c]
+// - ONE fp32 atomic per footprint pixel and channel instead of 4 * grid_h * grid_w per bin (about 3x fewer for
+// typical RoIs), still as dense wave-wide atomics: lane l owns channels l, l+64, l+128, l+192 of a 256-channel
+// chunk, so each wave instruction covers 256 contiguous bytes of one pixel.  The RoI's gradient slab
+// [PH*PW][256] is staged in LDS once per channel chunk.  RoIs whose bins span more than RB_SPAN pixels (or
+// PH/PW > 8) take the per-sample scatter path.
+constexpr int RB_SPAN = 96;
+constexpr int RB_MAXP = 8;
+
 template <typename T>
-__global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const float* __restrict__ rois,
-                                                            int K, int PH, int PW, int sampling_ratio,
-                                                            int aligned, const T* __restrict__ gout) {
-    const int k = blockIdx.x;
+__device__ void roi_bwd_scatter(const Pyramid& p, const RoiGeom& g, int k, int PH, int PW,
+                                const T* __restrict__ gout) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* roi = rois + (size_t)k * 5;
-    const RoiGeom g = roi_geom(roi, p, PH, PW, sampling_ratio, aligned);
     const int H = p.H[g.lvl], W = p.W[g.lvl], C = p.C;
-    if (g.batch < 0 || g.batch >= p.N) return;
     float* base = p.dfeat[g.lvl] + (size_t)g.batch * H * W * C;
     for (int bin = wave; bin < PH * PW; bin += 4) {
         const int ph = bin / PW, pw = bin - ph * PW;
@@ -184,6 +189,112 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const flo
                     }
                 }
             }
+        }
+    }
+}
+
+// 1-D weight table of one bin along one axis (the per-axis half of make_sample): returns false on overflow
+__device__ bool axis_table(float start, float bin, int grid, int b, int size, float* w, int* off, int* cnt) {
+    for (int j = 0; j < RB_SPAN; ++j) w[j] = 0.f;
+    int o = -1, n = 0;
+    bool ok = true;
+    for (int i = 0; i < grid; ++i) {
+        float v = start + b * bin + (i + 0.5f) * bin / (float)grid;
+        if (v < -1.0f || v > (float)size) continue;
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+        const float l = v - lo, h = 1.0f - l;
+        if (o < 0) o = lo;
+        if (hi - o >= RB_SPAN) { ok = false; break; }
+        w[lo - o] += h;
+        w[hi - o] += l;
+        n = hi - o + 1;
+    }
+    *off = o < 0 ? 0 : o;
+    *cnt = n;
+    return ok;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const float* __restrict__ rois,
+                                                            int K, int PH, int PW, int sampling_ratio,
+                                                            int aligned, const T* __restrict__ gout) {
+    __shared__ float wy[RB_MAXP][RB_SPAN], wx[RB_MAXP][RB_SPAN];
+    __shared__ int oy[RB_MAXP], ny[RB_MAXP], ox[RB_MAXP], nx[RB_MAXP];
+    __shared__ int overflow;
+    __shared__ T slab[RB_MAXP * RB_MAXP * 256];
+    const int k = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* roi = rois + (size_t)k * 5;
+    const RoiGeom g = roi_geom(roi, p, PH, PW, sampling_ratio, aligned);
+    const int H = p.H[g.lvl], W = p.W[g.lvl], C = p.C;
+    if (g.batch < 0 || g.batch >= p.N) return;
+    if (PH > RB_MAXP || PW > RB_MAXP) {
+        roi_bwd_scatter<T>(p, g, k, PH, PW, gout);
+        return;
+    }
+    if (tid == 0) overflow = 0;
+    __syncthreads();
+    if (tid < PH) {
+        if (!axis_table(g.start_h, g.bin_h, g.grid_h, tid, H, wy[tid], &oy[tid], &ny[tid])) overflow = 1;
+    } else if (tid >= 64 && tid < 64 + PW) {
+        const int b = tid - 64;
+        if (!axis_table(g.start_w, g.bin_w, g.grid_w, b, W, wx[b], &ox[b], &nx[b])) overflow = 1;
+    }
+    __syncthreads();
+    if (overflow) {
+        roi_bwd_scatter<T>(p, g, k, PH, PW, gout);
+        return;
+    }
+    int Y0 = 1 << 30, Y1 = -1, X0 = 1 << 30, X1 = -1;
+    for (int b = 0; b < PH; ++b)
+        if (ny[b] > 0) { Y0 = min(Y0, oy[b]); Y1 = max(Y1, oy[b] + ny[b]); }
+    for (int b = 0; b < PW; ++b)
+        if (nx[b] > 0) { X0 = min(X0, ox[b]); X1 = max(X1, ox[b] + nx[b]); }
+    if (Y1 < 0 || X1 < 0) return;              // no sample inside the map
+    const int FW = X1 - X0, npix = (Y1 - Y0) * FW;
+    const float inv = 1.0f / g.count;
+    float* base = p.dfeat[g.lvl] + (size_t)g.batch * H * W * C;
+    const int bins = PH * PW;
+    for (int cb = 0; cb < C; cb += 256) {
+        const int cw = min(256, C - cb);       // channels of this chunk (a multiple of 4)
+        __syncthreads();
+        for (int q = tid; q < bins * 64; q += 256) {          // 4 channels per piece
+            const int bin = q >> 6, c4 = (q & 63) << 2;
+            if (c4 < cw) {
+                const T* src = gout + ((size_t)k * bins + bin) * C + cb + c4;
+                T* dst = slab + bin * 256 + c4;
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+            }
+        }
+        __syncthreads();
+        for (int pi = wave; pi < npix; pi += 4) {
+            const int py = Y0 + pi / FW, px = X0 + pi % FW;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            bool any = false;
+            for (int ph = 0; ph < PH; ++ph) {
+                const int jy = py - oy[ph];
+                if (jy < 0 || jy >= ny[ph]) continue;
+                const float wyv = wy[ph][jy];
+                if (wyv == 0.f) continue;
+                for (int pw = 0; pw < PW; ++pw) {
+                    const int jx = px - ox[pw];
+                    if (jx < 0 || jx >= nx[pw]) continue;
+                    const float wv = wyv * wx[pw][jx];
+                    if (wv == 0.f) continue;
+                    any = true;
+                    const T* row = slab + (ph * PW + pw) * 256;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (lane + 64 * j < cw) acc[j] += wv * load1(row + lane + 64 * j);
+                }
+            }
+            if (!any) continue;
+            float* dst = base + ((size_t)py * W + px) * C + cb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lane + 64 * j < cw) unsafeAtomicAdd(dst + lane + 64 * j, acc[j] * inv);
         }
     }
 }
