@@ -196,14 +196,283 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
+
+// ================================================================================================ 256 x 256 tile
+// Deep-pipelined variant for the large layers: 256 pixels x 256 channels x 64 per 512-thread workgroup, 8 waves as
+// 2 (pixel groups) x 4 (channel groups), 128 x 64 outputs per wave as four 64 x 32 quadrants of
+// v_mfma_f32_16x16x32_bf16 tiles (channels on the MFMA rows, so a lane ends up with 4 consecutive channels of a
+// pixel).  LDS: two K-tile buffers of four 16 KiB half-tiles each - P0/P1 = pixel rows 0-127 / 128-255,
+// W0/W1 = channel rows likewise - 128 KiB, one workgroup per CU, two waves per SIMD.
+//
+// Schedule (per K-tile t, buffer t & 1): four phases, each = { ds_read one register sub-tile, issue ONE half-tile
+// of global_load_lds, s_barrier, 16 MFMAs (one quadrant x K = 64), s_barrier }.  Pixel group 1 runs one barrier
+// behind group 0, so on every SIMD one wave is in its MFMA phase while the other one is in its load phase.
+//   phase   reads (buffer t&1)   MFMA quadrant   stages (2 glds per thread)
+//     1     P0 + W0              (p0, w0)        P1 of tile t+1   (last read: tile t-1 phase 3)
+//     2     W1                   (p0, w1)        W0 of tile t+1   (last read: tile t-1 phase 4)
+//     3     P1                   (p1, w1)        P0 of tile t+2   (last read: tile t   phase 1)
+//     4     W0                   (p1, w0)        W1 of tile t+2   (last read: tile t   phase 2)
+// A half-tile is restaged two phases after its last read (the reads of the lagging group are complete by then),
+// and global_load_lds results are only waited for once per tile: `s_waitcnt vmcnt(4)` in phase 4 leaves the two
+// youngest half-tiles in flight and retires everything tile t+1 needs; the barrier that follows publishes it.
+// Tiles past the end are staged from the zero line so that the counts stay uniform.
+constexpr int TM = 256, TN = 256;
+constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
+constexpr int BUF_BYTES = 4 * HALF_BYTES;         // 64 KiB
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct TapState {
+    int t, r, s, rs, c0;
+};
+
+__global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int n_tiles = a.K / TN;
+    const long m_tiles = (a.M + TM - 1) / TM;
+    const long bid = blockIdx.x;
+    long mt;
+    int nt;
+    {
+        const long xcd = bid & 7, j = bid >> 3;
+        const long per = (m_tiles + 7) >> 3;
+        nt = (int)(j % n_tiles);
+        mt = xcd * per + j / n_tiles;
+        if (j / n_tiles >= per || mt >= m_tiles) return;
+    }
+    const long m0 = mt * TM;
+    const int k0 = nt * TN;
+    const int nk = a.R * a.S * (a.C / BK);
+
+    // ---- loader geometry: piece q = i*512 + tid of a half-tile -> row = q >> 3 (0..127), 16-byte slot q & 7
+    const unsigned short* pb[4];      // [h*2+i]: image base of the pixel + channel slot
+    int hi0[4], wi0[4];
+    const unsigned short* wb[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * 512 + tid;
+            const int row = q >> 3, lslot = (q & 7) ^ ((row >> 1) & 7);
+            const long m = m0 + h * 128 + row;
+            if (m < a.M) {
+                const int wo = (int)(m % a.Wo);
+                const long t = m / a.Wo;
+                const int ho = (int)(t % a.Ho);
+                const int n = (int)(t / a.Ho);
+                pb[h * 2 + i] = a.x + (size_t)n * a.H * a.W * a.C + lslot * 8;
+                hi0[h * 2 + i] = ho * a.stride - a.pad;
+                wi0[h * 2 + i] = wo * a.stride - a.pad;
+            } else {
+                pb[h * 2 + i] = a.x;
+                hi0[h * 2 + i] = -(1 << 28);            // fails every bounds test -> zero line
+                wi0[h * 2 + i] = 0;
+            }
+            wb[h * 2 + i] = a.w + (size_t)(k0 + h * 128 + row) * a.R * a.S * a.C + lslot * 8;
+        }
+
+    auto advance = [&](TapState& st) {
+        st.t++;
+        st.c0 += BK;
+        if (st.c0 == a.C) {
+            st.c0 = 0;
+            st.rs++;
+            if (++st.s == a.S) { st.s = 0; st.r++; }
+        }
+    };
+    auto stage_pix = [&](int h, const TapState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
+        const bool live = st.t < nk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = hi0[h * 2 + i] + st.r * a.dil, wi = wi0[h * 2 + i] + st.s * a.dil;
+            const bool ok = live && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            // offsets inside one image fit 32 bits (checked on the host)
+            const unsigned short* src = ok ? pb[h * 2 + i] + ((hi * a.W + wi) * a.C + st.c0) : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+    auto stage_wgt = [&](int h, const TapState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+        const bool live = st.t < nk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned short* src = live ? wb[h * 2 + i] + (st.rs * a.C + st.c0) : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+
+    // fragment addresses inside a half-tile (the same for every buffer): row = base + (lane & 15),
+    // 16-byte slot = ks*4 + (lane >> 4), swizzled like the loader
+    const int fr = lane & 15, fq = lane >> 4;
+    int poff[4][2], woff[2][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wr * 64 + it * 16 + fr;
+            poff[it][ks] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wc * 32 + jt * 16 + fr;
+            woff[jt][ks] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+
+    f32x4v acc[2][2][2][4];        // [w half][w tile][p half][p tile]
+#pragma unroll
+    for (int x0 = 0; x0 < 2; ++x0)
+#pragma unroll
+        for (int x1 = 0; x1 < 2; ++x1)
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 pf[4][2], wf[2][2];
+    auto read_pix = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pf[it][ks] = *reinterpret_cast<const bf16x8*>(base + poff[it][ks]);
+    };
+    auto read_wgt = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + woff[jt][ks]);
+    };
+#define OADG_QUADRANT(WH, PH_)                                                                               \
+    do {                                                                                                     \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+            _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                                 \
+                _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
+                    acc[WH][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], pf[it][ks],   \
+                                                                                   acc[WH][jt][PH_][it], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+    } while (0)
+
+    // ---- prologue: tile 0 complete, plus the two half-tiles of tile 1 that phases 3/4 of "tile -1" would stage
+    TapState s1{0, 0, 0, 0, 0};
+    stage_pix(0, s1, 0);
+    stage_wgt(0, s1, 0);
+    stage_wgt(1, s1, 0);
+    stage_pix(1, s1, 0);
+    advance(s1);                     // s1 = tile 1
+    stage_pix(0, s1, 1);
+    stage_wgt(1, s1, 1);
+    TapState s2 = s1;
+    advance(s2);                     // s2 = tile 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");     // stagger: group 1 runs one barrier behind
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // phase 1
+        read_wgt(0, buf);
+        read_pix(0, buf);
+        stage_pix(1, s1, buf ^ 1);
+        OADG_QUADRANT(0, 0);
+        // phase 2
+        read_wgt(1, buf);
+        stage_wgt(0, s1, buf ^ 1);
+        OADG_QUADRANT(1, 0);
+        // phase 3
+        read_pix(1, buf);
+        stage_pix(0, s2, buf);
+        OADG_QUADRANT(1, 1);
+        // phase 4
+        read_wgt(0, buf);
+        stage_wgt(1, s2, buf);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        OADG_QUADRANT(0, 1);
+        s1 = s2;
+        advance(s2);
+    }
+#undef OADG_QUADRANT
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");     // balance the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-line stages of the tail have landed
+    asm volatile("s_barrier" ::: "memory");
+
+    // ---- epilogue: bf16 C image [256 pixels][256 channels] in LDS (16-byte slot ^ (pixel & 15): the 16 pixels of a
+    // ds_write_b64 lane group land on 16 different bank groups), then 16-byte row-contiguous stores
+    {
+        const int cq = lane >> 4;
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int ch = wh * 128 + wc * 32 + jt * 16 + 4 * cq;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = a.bias[k0 + ch + e];
+                }
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int p = ph * 128 + wr * 64 + it * 16 + fr;
+                        unsigned short o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[wh][jt][ph][it][e] + bv[e];
+                            if (a.relu && !a.res) v = fmaxf(v, 0.f);
+                            o[e] = f32_to_bf16(v);
+                        }
+                        uint2 pk;
+                        pk.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+                        pk.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+                        *reinterpret_cast<uint2*>(smem + p * 512 + ((((ch >> 3) ^ (p & 15))) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                    }
+            }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < (TM * TN / 8) / 512; ++it) {
+        const int q = it * 512 + tid;
+        const int p = q >> 5, sg = q & 31;
+        const long m = m0 + p;
+        if (m >= a.M) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
+        const size_t off = (size_t)m * a.K + k0 + sg * 8;
+        if (a.res) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = bf16_to_f32((unsigned short)v[e]) + bf16_to_f32((unsigned short)rv[e]);
+                if (a.relu) f = fmaxf(f, 0.f);
+                v[e] = (short)f32_to_bf16(f);
+            }
+        }
+        *reinterpret_cast<bf16x8*>(a.y + off) = v;
+    }
+}
+
 }  // namespace
 
-extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual,
-                                     void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
-                                     int S, int stride, int pad, int dil, int relu, void* stream) {
+namespace {
+int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
+                int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
+                void* stream) {
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % BN != 0) return OADG_EARG;   // other shapes stay on the library path
+    if (variant < 0 || variant > 2 || (variant == 2 && K % TN != 0)) return OADG_EARG;
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
@@ -213,12 +482,50 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
-    const long m_tiles = (a.M + BM - 1) / BM;
-    const long blocks = ((m_tiles + 7) / 8) * 8 * (K / BN);      // 8 equal XCD ranges (the kernel drops the padding)
-    if (blocks > 0x7fffffffL) return OADG_EARG;
-    hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+    if (variant == 0) {
+        // the 256 x 256 tile runs one workgroup per CU: it wins as soon as there is one for every CU
+        // (tools/bench_conv.py: 920-1030 TFLOP/s vs 630-720 on the 3x3 layers; 625 vs 718 at 128 workgroups)
+        const long big = ((a.M + TM - 1) / TM) * (K / TN);
+        variant = (K % TN == 0 && big >= 256) ? 2 : 1;
+    }
+    if (variant == 2 && (long)H * W * C >= (1L << 31)) variant = 1;
+    if (variant == 2) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm256_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const long m_tiles = (a.M + TM - 1) / TM;
+        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / TN);
+        if (blocks > 0x7fffffffL) return OADG_EARG;
+        hipLaunchKernelGGL(conv_igemm256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES,
+                           (hipStream_t)stream, a);
+    } else {
+        const long m_tiles = (a.M + BM - 1) / BM;
+        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / BN);      // 8 equal XCD ranges (the kernel drops the padding)
+        if (blocks > 0x7fffffffL) return OADG_EARG;
+        hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream,
+                           a);
+    }
     OADG_LAUNCH_CHECK();
     return OADG_OK;
+}
+}  // namespace
+
+extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const void* residual,
+                                     void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
+                                     int S, int stride, int pad, int dil, int relu, void* stream) {
+    return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, 0, stream);
+}
+
+// same, with the kernel variant chosen by the caller: 0 = automatic, 1 = 128 x 128 tile, 2 = 256 x 256 tile
+extern "C" int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual,
+                                             void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
+                                             int S, int stride, int pad, int dil, int relu, int variant,
+                                             void* stream) {
+    return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, variant, stream);
 }
 
 // ================================================================================================ weight gradient

@@ -31,7 +31,7 @@ def supported(x, weight, stride, padding, dilation):
             padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
 
 
-def conv_forward(x, w, bias, residual, stride, pad, dil, relu):
+def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0):
     """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last."""
     L = _lib.lib()
     N, C, H, W = x.shape
@@ -42,8 +42,9 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu):
     if TIMERS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.oadg_conv2d_nhwc_bf16(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N, H, W,
-                                  C, K, R, S, stride, pad, dil, int(bool(relu)), stream_ptr()),
+    check(L.oadg_conv2d_nhwc_bf16_variant(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N,
+                                          H, W, C, K, R, S, stride, pad, dil, int(bool(relu)), int(variant),
+                                          stream_ptr()),
           'oadg_conv2d_nhwc_bf16')
     if TIMERS is not None:
         e1.record()

@@ -43,6 +43,43 @@ def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad,
     assert torch.equal(y2.float(), _ref(x, w2, None, stride, pad, dil).bfloat16().float())
 
 
+@pytest.mark.parametrize('N,C,H,W,K,R,stride,pad,dil', [
+    (2, 256, 32, 48, 256, 3, 1, 1, 1),      # FPN / RPN 3x3
+    (1, 64, 17, 23, 256, 3, 1, 1, 1),       # ragged pixel tail, a single 64-channel chunk per tap
+    (3, 128, 20, 28, 512, 1, 1, 0, 1),      # 1x1, two column tiles, two K-tiles only
+    (1, 64, 9, 11, 256, 1, 1, 0, 1),        # one K-tile: prologue + tail staging only
+    (1, 128, 33, 31, 256, 3, 2, 1, 1),      # stride 2
+    (1, 512, 16, 16, 512, 3, 1, 2, 2),      # dilated (DC5)
+])
+def test_conv_256_tile_variant_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
+    """the phase-pipelined 256x256 kernel (variant 2) on its own: same contract, same tolerance; repeated to
+    screen for staging races (results must be bit-identical from run to run and equal to the 128-tile kernel
+    up to the summation order inside an MFMA chain, i.e. the same bf16 rounding tolerance)."""
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(C + K + R + 1)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) / np.sqrt(C * R * R)).bfloat16() \
+        .contiguous(memory_format=torch.channels_last)
+    b = torch.randn(K, device=dev, generator=g)
+    res = torch.randn(N, K, (H + 2 * pad - dil * (R - 1) - 1) // stride + 1,
+                      (W + 2 * pad - dil * (R - 1) - 1) // stride + 1, device=dev, generator=g).bfloat16() \
+        .contiguous(memory_format=torch.channels_last)
+    y = hip_conv.conv_forward(x, w, b, None, stride, pad, dil, False, variant=2)
+    ref = _ref(x, w, b, stride, pad, dil)
+    assert y.shape == ref.shape
+    err = (y.float() - ref).abs().max().item()
+    assert err <= 8e-3 * ref.abs().max().item(), err
+    for _ in range(5):
+        assert torch.equal(y, hip_conv.conv_forward(x, w, b, None, stride, pad, dil, False, variant=2))
+    y2 = hip_conv.conv_forward(x, w, b, res, stride, pad, dil, True, variant=2)
+    ref2 = _ref(x, w, b, stride, pad, dil, res, True)
+    assert (y2.float() - ref2).abs().max().item() <= 8e-3 * ref2.abs().max().item()
+    w2 = torch.zeros_like(w)
+    w2[K - 3, 5, R - 1, 0] = 1.0
+    y3 = hip_conv.conv_forward(x, w2, None, None, stride, pad, dil, False, variant=2)
+    assert torch.equal(y3.float(), _ref(x, w2, None, stride, pad, dil).bfloat16().float())
+
+
 def test_conv_fused_epilogue(dev):
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(0)

@@ -22,6 +22,8 @@ SHAPES = [  # name, N, C, H, W, K, R, stride, pad
     ('layer3 1x1 1024->256', 8, 1024, 64, 128, 256, 1, 1, 0),
     ('layer3 1x1 256->1024', 8, 256, 64, 128, 1024, 1, 1, 0),
     ('lateral P2 1x1', 8, 256, 256, 512, 256, 1, 1, 0),
+    ('layer4 1x1 2048->512', 8, 2048, 32, 64, 512, 1, 1, 0),
+    ('layer4 1x1 512->2048', 8, 512, 32, 64, 2048, 1, 1, 0),
 ]
 
 
@@ -47,11 +49,13 @@ def main():
         b = torch.randn(K, device=dev)
         Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
         gf = 2.0 * N * Ho * Wo * K * C * R * R / 1e9
-        t1 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False))
+        t1 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False, variant=1))
+        t256 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False, variant=2)) if K % 256 == 0 \
+            else float('nan')
         bb = b.bfloat16()
         t2 = timeit(lambda: F.conv2d(x, w, bb, st, pad))
-        line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x'
-        if C % 128 == 0 and K % 128 == 0:
+        line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x | 256-tile {t256:7.3f} ms {gf / t256:7.1f} TF/s'
+        if '--wgrad' in sys.argv and C % 128 == 0 and K % 128 == 0:
             gy = torch.randn(N, K, Ho, Wo, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
             t3 = timeit(lambda: hip_conv.conv_wgrad(x, gy, K, R, R, st, pad, 1))
             t4 = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [st, st], [pad, pad], [1, 1], False,
