@@ -208,6 +208,23 @@ int oadg_fpn_topdown_fwd(const void* lat, const void* top, void* out, int N, int
 int oadg_fpn_topdown_bwd(const void* g, void* dtop, int N, int H, int W, int Ht, int Wt, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MaxIoUAssigner.assign for a batch of images (mmdet/core/bbox/assigners/max_iou_assigner.py:61-213 with
+ * BboxOverlaps2D iou_calculators/iou2d_calculator.py:78-...; the callers anchor_head.py:230-232 and
+ * standard_roi_head.py:88-95), gt_max_assign_all=True, no ignore boxes.
+ * boxes [B][N][4] fp32 (box_stride floats between images, 0 = one shared set), valid [B][N] bytes or NULL
+ * (invalid rows get -1 and take no part in any maximum, like the reference's pre-filtered anchors),
+ * gts [B][Gmax][4] with gt_counts[B] valid rows, gt_labels [B][Gmax] or NULL.
+ * Outputs gt_inds [B][N] int64 (0 negative, -1 ignore, k>0 gt k-1), max_overlaps [B][N], labels [B][N] or NULL,
+ * counts [B][2] = #(gt_inds > 0), #(gt_inds == 0) (the sampler's candidate counts).  Bit-identical to the
+ * reference's tensor expression in fp32. */
+size_t oadg_max_iou_assign_workspace_bytes(int B, int Gmax);
+int oadg_max_iou_assign(const float* boxes, long box_stride, const unsigned char* valid, const float* gts,
+                        const int* gt_counts, const int64_t* gt_labels, int B, int N, int Gmax, float pos_iou_thr,
+                        float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                        void* workspace, size_t workspace_bytes, int64_t* gt_inds, float* max_overlaps,
+                        int64_t* labels, int* counts, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58
  * state624/left/next are the generator's engine words (in/out); out [k] int64.

@@ -47,6 +47,9 @@ SIGNATURES = {
     'oadg_relu_bias_bwd': (ci, [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, cl, ci, vp]),
     'oadg_fpn_topdown_fwd': (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_fpn_topdown_bwd': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    'oadg_max_iou_assign_workspace_bytes': (ctypes.c_size_t, [ci, ci]),
+    'oadg_max_iou_assign': (ci, [vp, cl, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, ctypes.c_size_t, vp, vp, vp,
+                                 vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

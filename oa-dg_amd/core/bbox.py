@@ -3,6 +3,8 @@
 Sampling consumes the global CPU torch generator exactly like the reference (random_sampler.py:58:
 ``torch.randperm(n)`` with n = number of candidates), so seeded runs pick identical indices.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -145,6 +147,74 @@ class MaxIoUAssigner:
         res.gt_inds = res.gt_inds.masked_fill(~valid, -1)
         return res
 
+    def assign_many(self, boxes, valids, gt_bboxes_list, gt_labels_list=None):
+        """assign_masked() for a whole batch in one fused pass (csrc/assign.hip), bit-identical to the tensor
+        path.  ``boxes``: one [N,4] tensor shared by all images, or a list of [N,4(+)] tensors of equal N;
+        ``valids``: None, or a list of [N] bool masks (None entries = all valid).  Returns
+        (list of AssignResult, counts [B,2] int32 on the device = #(gt_inds > 0), #(gt_inds == 0) per image),
+        or None when the configuration / inputs are outside the kernel's domain (callers then loop)."""
+        from .. import _lib
+        if os.environ.get('OADG_ASSIGN_LOOP'):      # A/B switch for debugging: force the per-image tensor path
+            return None
+        B = len(gt_bboxes_list)
+        shared = isinstance(boxes, torch.Tensor)
+        first = boxes if shared else boxes[0]
+        if not (first.is_cuda and first.dtype == torch.float32 and self.gt_max_assign_all and B > 0
+                and isinstance(self.neg_iou_thr, (float, tuple))):
+            return None
+        if not shared and any(b.shape[0] != first.shape[0] for b in boxes):
+            return None
+        N = first.shape[0]
+        counts_host = [int(g.shape[0]) for g in gt_bboxes_list]
+        Gmax = max(counts_host)
+        if Gmax > 1024 or N == 0:
+            return None
+        dev = first.device
+        if shared:
+            bx, stride = first[:, :4].contiguous(), 0
+        else:
+            bx, stride = torch.stack([b[:, :4] for b in boxes]).contiguous(), N * 4
+        if all(c == Gmax for c in counts_host):
+            gts = torch.stack([g[:, :4] for g in gt_bboxes_list]).float().contiguous() if Gmax else None
+        else:
+            gts = first.new_zeros((B, Gmax, 4))
+            for i, g in enumerate(gt_bboxes_list):
+                gts[i, :counts_host[i]] = g[:, :4]
+        with_labels = gt_labels_list is not None and all(l is not None for l in gt_labels_list)
+        gl = None
+        if with_labels and Gmax:
+            if all(c == Gmax for c in counts_host):
+                gl = torch.stack(list(gt_labels_list)).long().contiguous()
+            else:
+                gl = torch.zeros((B, Gmax), dtype=torch.long, device=dev)
+                for i, l in enumerate(gt_labels_list):
+                    gl[i, :counts_host[i]] = l
+        vd = None
+        if valids is not None and any(v is not None for v in valids):
+            vd = torch.stack([v if v is not None else torch.ones(N, dtype=torch.bool, device=dev)
+                              for v in valids]).to(torch.uint8).contiguous()
+        gcnt = _pinned_to(torch.tensor(counts_host, dtype=torch.int32), dev)
+        gt_inds = torch.empty((B, N), dtype=torch.long, device=dev)
+        max_ov = torch.empty((B, N), dtype=torch.float32, device=dev)
+        labels = torch.empty((B, N), dtype=torch.long, device=dev) if (with_labels and Gmax) else None
+        counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        nbytes = L.oadg_max_iou_assign_workspace_bytes(B, Gmax)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        lo, hi = (0.0, self.neg_iou_thr) if isinstance(self.neg_iou_thr, float) else self.neg_iou_thr
+        _lib.check(L.oadg_max_iou_assign(_lib.ptr(bx), stride, _lib.ptr(vd), _lib.ptr(gts), _lib.ptr(gcnt),
+                                         _lib.ptr(gl), B, N, Gmax, float(self.pos_iou_thr), float(lo), float(hi),
+                                         float(self.min_pos_iou), int(bool(self.match_low_quality)), _lib.ptr(ws),
+                                         nbytes, _lib.ptr(gt_inds), _lib.ptr(max_ov), _lib.ptr(labels),
+                                         _lib.ptr(counts), _lib.stream_ptr()), 'oadg_max_iou_assign')
+        res = []
+        for i in range(B):
+            lab = None
+            if with_labels:
+                lab = labels[i] if labels is not None else gt_inds.new_full((N,), -1)
+            res.append(AssignResult(counts_host[i], gt_inds[i], max_ov[i], labels=lab))
+        return res, counts
+
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
         num_gts, num_bboxes = overlaps.size(0), overlaps.size(1)
         gt_inds = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
@@ -268,8 +338,9 @@ class PendingSampling:
     same candidates, same ``torch.randperm(n)[:num]`` draws from the global CPU generator (positives first, then
     negatives), same sorted index lists."""
 
-    def __init__(self, sampler, prepared, gt_bboxes_list, counts_dev):
+    def __init__(self, sampler, prepared, gt_bboxes_list, counts_dev, added_pos=None):
         self.sampler, self.prepared, self.gt_bboxes_list = sampler, prepared, gt_bboxes_list
+        self.added_pos = added_pos
         self.results = None
         self.event = None
         if counts_dev is None:
@@ -289,6 +360,8 @@ class PendingSampling:
             self.event.synchronize()
         sampler = self.sampler
         counts = self.counts.tolist() if isinstance(self.counts, torch.Tensor) else self.counts
+        if self.added_pos is not None:
+            counts = [(c[0] + a, c[1]) for c, a in zip(counts, self.added_pos)]
         num_pos_exp = int(sampler.num * sampler.pos_fraction)
         results = []
         for i, ((ar, bboxes, gt_flags, pos_mask, neg_mask), (n_pos, n_neg)) in enumerate(zip(self.prepared, counts)):
@@ -317,8 +390,11 @@ class PendingSampling:
         return results
 
 
-def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):
+def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None, counts=None):
+    """``counts`` ([B,2] int32 on the device, from MaxIoUAssigner.assign_many): candidate counts of the
+    assignment BEFORE the gts are added as proposals; without it they are reduced from the masks here."""
     prepared = []
+    added = []
     for i in range(len(assign_results)):
         ar, bboxes, gtb = assign_results[i], bboxes_list[i], gt_bboxes_list[i]
         if len(bboxes.shape) < 2:
@@ -331,9 +407,16 @@ def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_l
             bboxes = torch.cat([gtb, bboxes], dim=0)
             ar.add_gt_(gt_labels_list[i])
             gt_flags = torch.cat([bboxes.new_ones(gtb.shape[0], dtype=torch.uint8), gt_flags])
+            added.append(int(gtb.shape[0]))          # every added gt is a positive candidate (assign_result.py)
+        else:
+            added.append(0)
         prepared.append((ar, bboxes, gt_flags, ar.gt_inds > 0, ar.gt_inds == 0))
-    counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared]) if prepared else None
-    return PendingSampling(sampler, prepared, gt_bboxes_list, counts)
+    if not prepared:
+        counts = None
+    elif counts is None:
+        counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared])
+        added = None                                  # the masks already contain the added gts
+    return PendingSampling(sampler, prepared, gt_bboxes_list, counts, added)
 
 
 def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):

@@ -156,6 +156,22 @@ class AnchorHead(nn.Module):
                                      self.train_cfg.allowed_border)
         return self.assigner.assign_masked(flat_anchors, inside, gt_bboxes, gt_labels)
 
+    def _assign_batch(self, flat, flag_list, gt_bboxes, img_metas, gt_labels=None):
+        """_assign_inside for all images: one fused assignment (csrc/assign.hip) when the assigner offers it."""
+        n = len(img_metas)
+        if hasattr(self.assigner, 'assign_many'):
+            if self._all_anchors_valid and self.train_cfg.allowed_border < 0:
+                valids = None
+            else:
+                valids = [anchor_inside_flags(flat, torch.cat(flag_list[i]), img_metas[i]['img_shape'][:2],
+                                              self.train_cfg.allowed_border) for i in range(n)]
+            out = self.assigner.assign_many(flat, valids, gt_bboxes, None if self.sampling else gt_labels)
+            if out is not None:
+                return out
+        return [self._assign_inside(flat, torch.cat(flag_list[i]), gt_bboxes[i], img_metas[i],
+                                    None if (self.sampling or gt_labels is None) else gt_labels[i])
+                for i in range(n)], None
+
     def begin_targets(self, pad_hw, gt_bboxes, img_metas, device):
         """Anchor targets depend on anchors and gts only, not on the network: enqueue the IoU / assignment of all
         images and the asynchronous read of the sampler's candidate counts BEFORE the backbone runs, so the
@@ -167,9 +183,8 @@ class AnchorHead(nn.Module):
         if not (hasattr(self.sampler, 'random_choice') and hasattr(self.assigner, 'assign_masked')):
             return
         flat = torch.cat(anchor_list[0])
-        ars = [self._assign_inside(flat, torch.cat(flag_list[i]), gt_bboxes[i], img_metas[i])
-               for i in range(len(img_metas))]
-        pend = sample_many_begin(self.sampler, ars, [flat] * len(img_metas), gt_bboxes)
+        ars, counts = self._assign_batch(flat, flag_list, gt_bboxes, img_metas)
+        pend = sample_many_begin(self.sampler, ars, [flat] * len(img_metas), gt_bboxes, counts=counts)
         self._pending_targets = ((len(img_metas), tuple(a.size(0) for a in anchor_list[0])), pend)
 
     # -- loss ----------------------------------------------------------------------------------------

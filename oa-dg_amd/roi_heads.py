@@ -322,12 +322,19 @@ class StandardRoIHead(BaseRoIHead):
         candidates.  All images share one host read of the candidate counts."""
         if all(g is None for g in gt_bboxes_ignore[:n]) and hasattr(self.bbox_sampler, 'random_choice') and \
                 hasattr(self.bbox_assigner, 'assign_masked'):
-            ars = []
-            for i in range(n):
-                p = proposal_list[i]
-                valid = p[:, 4] >= 0 if p.size(1) == 5 else torch.ones_like(p[:, 0], dtype=torch.bool)
-                ars.append(self.bbox_assigner.assign_masked(p[:, :4], valid, gt_bboxes[i], gt_labels[i]))
-            pend = sample_many_begin(self.bbox_sampler, ars, proposal_list[:n], gt_bboxes[:n], gt_labels[:n])
+            props = proposal_list[:n]
+            valids = [p[:, 4] >= 0 if p.size(1) == 5 else None for p in props]
+            out = self.bbox_assigner.assign_many(props, valids, gt_bboxes[:n], gt_labels[:n]) \
+                if hasattr(self.bbox_assigner, 'assign_many') else None
+            if out is not None:          # one fused assignment for the batch (csrc/assign.hip)
+                ars, counts = out
+            else:
+                ars, counts = [], None
+                for i in range(n):
+                    p = props[i]
+                    valid = valids[i] if valids[i] is not None else torch.ones_like(p[:, 0], dtype=torch.bool)
+                    ars.append(self.bbox_assigner.assign_masked(p[:, :4], valid, gt_bboxes[i], gt_labels[i]))
+            pend = sample_many_begin(self.bbox_sampler, ars, props, gt_bboxes[:n], gt_labels[:n], counts=counts)
             return pend if defer else pend.finish()
         out = []
         for i in range(n):

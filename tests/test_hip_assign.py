@@ -1,0 +1,71 @@
+"""-m gpu parity: the fused batch MaxIoUAssigner (C ABI oadg_max_iou_assign) against the tensor-expression
+assigner (core/bbox.py MaxIoUAssigner.assign_masked, itself pinned to the reference by the whole-step fixture in
+test_model_parity.py).  Integer outputs and fp32 IoUs must be bit-identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(gen, n, dev, W=512., H=256., lo=4., hi=200.):
+    w = torch.rand(n, generator=gen, device=dev) * (hi - lo) + lo
+    h = torch.rand(n, generator=gen, device=dev) * (hi - lo) + lo
+    x = torch.rand(n, generator=gen, device=dev) * (W - w)
+    y = torch.rand(n, generator=gen, device=dev) * (H - h)
+    return torch.stack([x, y, x + w, y + h], 1)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True),     # RPN
+    dict(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False),    # R-CNN
+    dict(pos_iou_thr=0.6, neg_iou_thr=(0.1, 0.4), min_pos_iou=0.0, match_low_quality=True),
+])
+@pytest.mark.parametrize('shared', [True, False])
+def test_assign_many_is_bit_identical(dev, cfg, shared):
+    from oadg_amd.core.bbox import MaxIoUAssigner
+    gen = torch.Generator(device=dev).manual_seed(3)
+    asg = MaxIoUAssigner(**cfg)
+    N, counts = 20011, [20, 7, 0, 33]
+    gts = [_boxes(gen, c, dev, lo=20.) for c in counts]
+    labels = [torch.randint(0, 8, (c,), generator=gen, device=dev) for c in counts]
+    if shared:
+        boxes = _boxes(gen, N, dev)
+        per = [boxes] * len(counts)
+    else:
+        per = [_boxes(gen, N, dev) for _ in counts]
+        boxes = per
+    # some boxes coincide exactly with gts (IoU 1 and exact ties for low-quality matching)
+    for i, c in enumerate(counts):
+        if c and not shared:
+            per[i][:c] = gts[i]
+            per[i][c:2 * c] = gts[i]
+    valids = [torch.rand(N, generator=gen, device=dev) > 0.2, None, None,
+              torch.rand(N, generator=gen, device=dev) > 0.5]
+    out = asg.assign_many(boxes, valids, gts, labels)
+    assert out is not None
+    ars, cnt = out
+    cnt = cnt.cpu()
+    for i in range(len(counts)):
+        v = valids[i] if valids[i] is not None else torch.ones(N, dtype=torch.bool, device=dev)
+        ref = asg.assign_masked(per[i], v, gts[i], labels[i])
+        assert torch.equal(ars[i].gt_inds, ref.gt_inds), i
+        if counts[i]:
+            assert torch.equal(ars[i].max_overlaps, ref.max_overlaps), i
+            assert torch.equal(ars[i].labels, ref.labels), i
+        assert int(cnt[i, 0]) == int((ref.gt_inds > 0).sum()) and int(cnt[i, 1]) == int((ref.gt_inds == 0).sum())
+        assert ars[i].num_gts == counts[i]
+
+
+def test_assign_many_rpn_scale(dev):
+    """the bench shape: 523,776 anchors shared by 8 images, 20 gts each, no mask, no labels."""
+    from oadg_amd.core.bbox import MaxIoUAssigner
+    gen = torch.Generator(device=dev).manual_seed(5)
+    asg = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True)
+    anchors = _boxes(gen, 523776, dev, W=2048., H=1024., lo=8., hi=600.)
+    gts = [_boxes(gen, 20, dev, W=2048., H=1024., lo=24., hi=400.) for _ in range(8)]
+    ars, cnt = asg.assign_many(anchors, None, gts, None)
+    for i in (0, 7):
+        ref = asg.assign(anchors, gts[i])
+        assert torch.equal(ars[i].gt_inds, ref.gt_inds)
+        assert torch.equal(ars[i].max_overlaps, ref.max_overlaps)
+        assert ars[i].labels is None

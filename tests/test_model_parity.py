@@ -98,13 +98,17 @@ def test_host_logic_reproduces_reference_step(golden_dir, fold_bn, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_product_step_matches_reference_on_gpu(dev, golden_dir):
+def test_product_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
     """fp32 on the MI355X.  Convolutions come from a different library (MIOpen vs the CPU's oneDNN), and the
     step contains discrete decisions (top-k, NMS, IoU thresholds, sampling), so agreement is asserted at
     5e-3 for the loss terms and 2e-2 for the gradient norms rather than at 1e-4; the 1e-4 bar is held by
     the per-kernel tests, which feed identical inputs to both sides."""
     g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
     torch.backends.cudnn.allow_tf32 = False
+    # MIOpen's default fp32 solvers reduce split-K partials with atomics: ulp-level run-to-run noise that flips a
+    # discrete decision (NMS / top-k) about once in 15 runs and with it the whole RoI sample.  Deterministic
+    # solvers make the step reproducible (tools/probe/nondet_probe.py: 40/40 identical).
+    monkeypatch.setattr(torch.backends.cudnn, 'deterministic', True)
     det = build_and_load(dev)
     data = make_data(g, dev)
     torch.manual_seed(int(g['seed']))

@@ -41,7 +41,31 @@ def main():
                 eng.step(data)
                 nxt = pipe.prefetch(*batches[(i + 1) % 3])
             torch.cuda.synchronize()
-        print(p.key_averages().table(sort_by='self_cuda_time_total', row_limit=40, max_name_column_width=70))
+        p.export_chrome_trace('/tmp/trace.json')
+        import collections
+        import json
+        ev = json.load(open('/tmp/trace.json'))['traceEvents']
+        ks = [e for e in ev if e.get('cat') in ('kernel', 'gpu_memcpy', 'gpu_memset')]
+        per = collections.defaultdict(list)
+        for e in ks:
+            per[e['args'].get('stream')].append((e['ts'], e['ts'] + e['dur'], e['name']))
+        t0 = min(e['ts'] for e in ks)
+        t1 = max(e['ts'] + e['dur'] for e in ks)
+        print(f'GPU span {(t1 - t0) / 1e3:.2f} ms for 2 steps')
+        for st, lst in per.items():
+            busy = sum(b - a for a, b, _ in lst)
+            print(f'stream {st}: {len(lst)} launches, busy {busy / 1e3:.2f} ms')
+        main = max(per.values(), key=lambda l: sum(b - a for a, b, _ in l))
+        for lo, hi in ((0, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1e9)):
+            sel = [b - a for a, b, _ in main if lo <= b - a < hi]
+            print(f'  main-stream kernels {lo}-{hi} us: {len(sel) / 2:.0f} per step, {sum(sel) / 2e3:.2f} ms per step')
+        # idle gaps on the busiest stream
+        main = max(per.values(), key=lambda l: sum(b - a for a, b, _ in l))
+        main.sort()
+        gaps = [(main[i + 1][0] - main[i][1], main[i][2][:60], main[i + 1][2][:60]) for i in range(len(main) - 1)]
+        print('idle on the main stream: %.2f ms total; gaps > 50 us:' % (sum(g for g, _, _ in gaps if g > 0) / 1e3))
+        for g, a_, b_ in sorted(gaps, reverse=True)[:25]:
+            print(f'  {g:8.1f} us  after {a_}  before {b_}')
         return
     pr = cProfile.Profile()
     pr.enable()
