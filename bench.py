@@ -201,18 +201,25 @@ def main():
     #      launches / number of launches, divided by the mean launch duration.  Otherwise RoIAlign backward.
     elem = 2 if amp is not None else 4
     if conv_timers:
-        ms = [t[0].elapsed_time(t[1]) for t in conv_timers]
-        flops = [t[2] for t in conv_timers]
-        avg_ms, per_launch = sum(ms) / len(ms), sum(flops) / len(flops)
+        per_kernel = {}
+        for t in conv_timers:
+            per_kernel.setdefault(t[4], []).append((t[0].elapsed_time(t[1]), t[2], t[3]))
+        name, rows = max(per_kernel.items(), key=lambda kv: sum(r[0] for r in kv[1]))   # the dominant one
+        ms = [r[0] for r in rows]
+        avg_ms, per_launch = sum(ms) / len(ms), sum(r[1] for r in rows) / len(rows)
         achieved = per_launch / (avg_ms * 1e-3) / 1e12
-        roof = {'kernel': 'conv_igemm_kernel', 'bound': 'mfma', 'achieved': round(achieved, 1),
+        roof = {'kernel': name, 'bound': 'mfma', 'achieved': round(achieved, 1),
                 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
                 'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
                 'algorithmic_flops_per_launch': int(per_launch),
-                'algorithmic_bytes_per_launch': int(sum(t[3] for t in conv_timers) / len(conv_timers)),
+                'algorithmic_bytes_per_launch': int(sum(r[2] for r in rows) / len(rows)),
                 'launches_per_step': round(len(ms) / a.steps, 1),
-                'kernel_ms_per_step': round(sum(ms) / a.steps, 2)}
-        roof.update(pmc_traffic('conv_igemm_kernel'))
+                'kernel_ms_per_step': round(sum(ms) / a.steps, 2),
+                'other_conv_kernels': {k: {'launches_per_step': round(len(v) / a.steps, 1),
+                                           'ms_per_step': round(sum(r[0] for r in v) / a.steps, 2),
+                                           'achieved': round(sum(r[1] for r in v) / sum(r[0] for r in v) / 1e9, 1)}
+                                       for k, v in per_kernel.items() if k != name}}
+        roof.update(pmc_traffic(name))
     else:
         ms = [s_.elapsed_time(e_) for s_, e_ in pairs]
         rois = getattr(det.roi_head, '_last_rois', None)

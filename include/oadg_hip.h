@@ -174,6 +174,8 @@ int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const
 int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int dil, int relu, int variant, void* stream);
+/* the variant (1 or 2) variant 0 resolves to for a problem; 0 = shape not covered */
+int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);
 int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,

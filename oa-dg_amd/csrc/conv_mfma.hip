@@ -466,6 +466,13 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 }  // namespace
 
 namespace {
+// the 256 x 256 tile runs one workgroup per CU: it wins as soon as there is one for every CU
+// (tools/bench_conv.py: 920-1030 TFLOP/s vs 630-720 on the 3x3 layers; 625 vs 718 at 128 workgroups)
+int auto_variant(long M, int H, int W, int C, int K) {
+    const long big = ((M + TM - 1) / TM) * (K / TN);
+    return (K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31)) ? 2 : 1;
+}
+
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
                 void* stream) {
@@ -482,12 +489,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
-    if (variant == 0) {
-        // the 256 x 256 tile runs one workgroup per CU: it wins as soon as there is one for every CU
-        // (tools/bench_conv.py: 920-1030 TFLOP/s vs 630-720 on the 3x3 layers; 625 vs 718 at 128 workgroups)
-        const long big = ((a.M + TM - 1) / TM) * (K / TN);
-        variant = (K % TN == 0 && big >= 256) ? 2 : 1;
-    }
+    if (variant == 0) variant = auto_variant(a.M, H, W, C, K);
     if (variant == 2 && (long)H * W * C >= (1L << 31)) variant = 1;
     if (variant == 2) {
         static bool attr_set = false;
@@ -518,6 +520,15 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
                                      void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
                                      int S, int stride, int pad, int dil, int relu, void* stream) {
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, 0, stream);
+}
+
+// which kernel the automatic choice takes for a problem (1 or 2; 0 for unsupported shapes) - for profiling
+extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
+    if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return 0;
+    if (C % BK != 0 || K % BN != 0) return 0;
+    const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    if (Ho < 1 || Wo < 1) return 0;
+    return auto_variant((long)N * Ho * Wo, H, W, C, K);
 }
 
 // same, with the kernel variant chosen by the caller: 0 = automatic, 1 = 128 x 128 tile, 2 = 256 x 256 tile

@@ -13,7 +13,8 @@ _ZEROS = {}
 # The hand-written weight-gradient kernel is correct (tests/test_hip_conv.py) but at 0.8-1.0x of MIOpen's on the
 # large-pixel-count layers (tools/bench_conv.py), so it is opt-in until it wins.
 USE_HIP_WGRAD = False
-# live HIP-event timing of the kernel launches inside bench.py's timed region: list of (start, end, flops, bytes)
+# live HIP-event timing of the kernel launches inside bench.py's timed region: list of (start, end, flops, bytes,
+# kernel name)
 # (bytes = algorithmic HBM bytes of the launch: input + weights + output [+ residual], each touched once)
 TIMERS = None
 
@@ -48,8 +49,10 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0):
           'oadg_conv2d_nhwc_bf16')
     if TIMERS is not None:
         e1.record()
+        v = variant or L.oadg_conv2d_auto_variant(N, H, W, C, K, R, S, stride, pad, dil)
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
-                       2.0 * (N * H * W * C + K * C * R * S + N * Ho * Wo * K * (2 if residual is not None else 1))))
+                       2.0 * (N * H * W * C + K * C * R * S + N * Ho * Wo * K * (2 if residual is not None else 1)),
+                       'conv_igemm256_kernel' if v == 2 else 'conv_igemm_kernel'))
     return y
 
 

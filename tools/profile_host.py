@@ -59,6 +59,14 @@ def main():
         for lo, hi in ((0, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1e9)):
             sel = [b - a for a, b, _ in main if lo <= b - a < hi]
             print(f'  main-stream kernels {lo}-{hi} us: {len(sel) / 2:.0f} per step, {sum(sel) / 2e3:.2f} ms per step')
+        small = collections.defaultdict(lambda: [0, 0.0])
+        for a_, b_, nm in main:
+            if b_ - a_ < 10:
+                small[nm[:90]][0] += 1
+                small[nm[:90]][1] += b_ - a_
+        print('kernels < 10 us on the main stream, per step:')
+        for nm, (c, t) in sorted(small.items(), key=lambda kv: -kv[1][1])[:28]:
+            print(f'  {c / 2:6.0f} x  {t / 2e3:6.3f} ms  {nm}')
         # idle gaps on the busiest stream
         main = max(per.values(), key=lambda l: sum(b - a for a, b, _ in l))
         main.sort()
