@@ -704,6 +704,211 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             }
 }
 
+// ---- 256 x 256 tile weight gradient on the phase pipeline of conv_igemm256_kernel -------------------------------
+// dW tile [256 c][256 k] of one tap; reduction over 64-pixel K-tiles.  LDS: two buffers of four 16 KiB half-tiles
+// D0/D1 = dy channels 0-127 / 128-255, X0/X1 = x channels likewise, each [64 pixels][128 channels] as it lies in
+// HBM (filled by global_load_lds); MFMA fragments (8 consecutive pixels per lane) come out of the transposing
+// ds_read_b64_tr_b16.  16-byte slot swizzle slot ^ (((row & 3) << 2) | (((row >> 3) & 1) << 1)): the 8 pixel rows a
+// half-wave reads per instruction land on 8 different 32-byte bank groups.  Schedule, stagger and vmcnt
+// accounting are those of conv_igemm256_kernel with (P, W) -> (D, X).
+__device__ __forceinline__ bf16x8 tr_frag16(const unsigned char* half, int pix0, int chan0, int lane) {
+    // channel chan0 + (lane & 15), pixels pix0 + 8*(lane >> 4) + 0..7 of a [64][128] bf16 half-tile
+    const int s = lane & 15, q = lane >> 4;
+    const int chan = chan0 + (s & 3) * 4;
+    bf16x8 out;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = pix0 + q * 8 + u * 4 + (s >> 2);
+        const int slot = (chan >> 3) ^ (((row & 3) << 2) | (((row >> 3) & 1) << 1));
+        const unsigned char* p = half + row * 256 + slot * 16 + (chan & 7) * 2;
+        const v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)p);
+        out[u * 4 + 0] = r[0]; out[u * 4 + 1] = r[1]; out[u * 4 + 2] = r[2]; out[u * 4 + 3] = r[3];
+    }
+    return out;
+}
+
+struct PixState {
+    long ch;              // K-tile (64-pixel chunk) index
+    int n[2], ho[2], wo[2];
+};
+
+__global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int kt_n = a.K / 256, ct_n = a.C / 256, RS = a.R * a.S;
+    const int combos = kt_n * ct_n * RS;
+    const long bid = blockIdx.x;
+    int split, combo;
+    if (a.splits % 8 == 0) {
+        const long xcd = bid & 7, j = bid >> 3;
+        combo = (int)(j % combos);
+        split = (int)((j / combos) * 8 + xcd);
+    } else {
+        combo = (int)(bid % combos);
+        split = (int)(bid / combos);
+    }
+    const int ct = combo % ct_n;
+    const int kt = (combo / ct_n) % kt_n;
+    const int rs = combo / (ct_n * kt_n);
+    const int r = rs / a.S, s = rs - r * a.S;
+    const int k0 = kt * 256, c0 = ct * 256;
+    const long nchunks = (a.P + WP - 1) / WP;
+    const long ch0 = (long)split * a.chunks_per_split;
+    const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
+    const int nk = ch1 > ch0 ? (int)(ch1 - ch0) : 0;
+
+    // loader geometry: piece q = i*512 + tid -> pixel row q >> 4 (0..63) of the K-tile, 16-byte slot q & 15
+    int lrow[2], lslot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        lrow[i] = q >> 4;
+        lslot[i] = (q & 15) ^ (((lrow[i] & 3) << 2) | (((lrow[i] >> 3) & 1) << 1));
+    }
+    const int adv_h = WP / a.Wo, adv_w = WP - adv_h * a.Wo;     // 64 pixels = adv_h rows + adv_w columns
+    auto init_state = [&](PixState& st, long ch) {
+        st.ch = ch;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long p = ch * WP + lrow[i];
+            st.wo[i] = (int)(p % a.Wo);
+            const long t = p / a.Wo;
+            st.ho[i] = (int)(t % a.Ho);
+            st.n[i] = (int)(t / a.Ho);
+        }
+    };
+    auto advance = [&](PixState& st) {
+        st.ch++;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st.wo[i] += adv_w;
+            st.ho[i] += adv_h;
+            if (st.wo[i] >= a.Wo) { st.wo[i] -= a.Wo; ++st.ho[i]; }
+            while (st.ho[i] >= a.Ho) { st.ho[i] -= a.Ho; ++st.n[i]; }
+        }
+    };
+    auto stage_dy = [&](int h, const PixState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long p = st.ch * WP + lrow[i];
+            const unsigned short* src = (st.ch < ch1 && p < a.P)
+                                            ? a.dy + (size_t)p * a.K + k0 + h * 128 + lslot[i] * 8 : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+    auto stage_x = [&](int h, const PixState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long p = st.ch * WP + lrow[i];
+            const int hi = st.ho[i] * a.stride - a.pad + r * a.dil, wi = st.wo[i] * a.stride - a.pad + s * a.dil;
+            const bool ok = st.ch < ch1 && p < a.P && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned short* src =
+                ok ? a.x + (((size_t)st.n[i] * a.H + hi) * a.W + wi) * a.C + c0 + h * 128 + lslot[i] * 8 : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+
+    f32x4v acc[2][2][2][4];        // [x half][x tile][dy half][dy tile]
+#pragma unroll
+    for (int x0 = 0; x0 < 2; ++x0)
+#pragma unroll
+        for (int x1 = 0; x1 < 2; ++x1)
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 df[4][2], xf[2][2];
+    auto read_dy = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) df[it][ks] = tr_frag16(base, ks * 32, wr * 64 + it * 16, lane);
+    };
+    auto read_x = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xf[jt][ks] = tr_frag16(base, ks * 32, wc * 32 + jt * 16, lane);
+    };
+#define OADG_WQUADRANT(XH, DH)                                                                               \
+    do {                                                                                                     \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+            _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                                 \
+                _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
+                    acc[XH][jt][DH][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[jt][ks], df[it][ks],    \
+                                                                                  acc[XH][jt][DH][it], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+    } while (0)
+
+    PixState s1, s2;
+    init_state(s1, ch0);
+    stage_dy(0, s1, 0);
+    stage_x(0, s1, 0);
+    stage_x(1, s1, 0);
+    stage_dy(1, s1, 0);
+    advance(s1);
+    stage_dy(0, s1, 1);
+    stage_x(1, s1, 1);
+    s2 = s1;
+    advance(s2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        read_x(0, buf);
+        read_dy(0, buf);
+        stage_dy(1, s1, buf ^ 1);
+        OADG_WQUADRANT(0, 0);
+        read_x(1, buf);
+        stage_x(0, s1, buf ^ 1);
+        OADG_WQUADRANT(1, 0);
+        read_dy(1, buf);
+        stage_dy(0, s2, buf);
+        OADG_WQUADRANT(1, 1);
+        read_x(0, buf);
+        stage_x(1, s2, buf);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        OADG_WQUADRANT(0, 1);
+        s1 = s2;
+        advance(s2);
+    }
+#undef OADG_WQUADRANT
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // partial tile: D rows = x channels (4 consecutive per lane), columns = dy channels
+    float* out = a.part + (size_t)split * a.K * RS * a.C;
+    const int fr = lane & 15, cq = lane >> 4;
+#pragma unroll
+    for (int xh = 0; xh < 2; ++xh)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int c = c0 + xh * 128 + wc * 32 + jt * 16 + 4 * cq;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int k = k0 + dh * 128 + wr * 64 + it * 16 + fr;
+                    *reinterpret_cast<f32x4v*>(out + ((size_t)k * RS + rs) * a.C + c) = acc[xh][jt][dh][it];
+                }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long n, float* __restrict__ dw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -712,7 +917,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     dw[i] = s;
 }
 
+bool wgrad_use256(long P, int K, int C, int RS) {
+    return K % 256 == 0 && C % 256 == 0 && (P + WP - 1) / WP >= 64;
+}
+
 int wgrad_splits(long P, int K, int C, int RS) {
+    if (wgrad_use256(P, K, C, RS)) {
+        // one workgroup per CU: aim at ~2 rounds of 256 workgroups, at least 8 K-tiles each
+        const long tiles = (long)(K / 256) * (C / 256) * RS;
+        const long nchunks = (P + WP - 1) / WP;
+        long s = (512 + tiles - 1) / tiles;
+        if (s > nchunks / 8) s = nchunks / 8;
+        if (s >= 8) s = s / 8 * 8;
+        if (s < 1) s = 1;
+        if (s > 256) s = 256;
+        return (int)s;
+    }
     const long tiles = (long)(K / 128) * (C / 128) * RS;
     const long nchunks = (P + WP - 1) / WP;
     long s = (1024 + tiles - 1) / tiles;
@@ -749,9 +969,21 @@ extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float*
     a.chunks_per_split = (int)((nchunks + a.splits - 1) / a.splits);
     const size_t need = (size_t)a.splits * K * R * S * C * sizeof(float);
     if (workspace_bytes < need) return OADG_ESIZE;
-    const long blocks = (long)a.splits * (K / 128) * (C / 128) * R * S;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 2 * WSTAGE, st, a);
+    if (wgrad_use256(a.P, K, C, R * S)) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad256_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const long blocks = (long)a.splits * (K / 256) * (C / 256) * R * S;
+        hipLaunchKernelGGL(conv_wgrad256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES, st, a);
+    } else {
+        const long blocks = (long)a.splits * (K / 128) * (C / 128) * R * S;
+        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 2 * WSTAGE, st, a);
+    }
     OADG_LAUNCH_CHECK();
     const long n = (long)K * R * S * C;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,

@@ -12,7 +12,7 @@ from ._lib import check, ptr, stream_ptr
 _ZEROS = {}
 # The hand-written weight-gradient kernel is correct (tests/test_hip_conv.py) but at 0.8-1.0x of MIOpen's on the
 # large-pixel-count layers (tools/bench_conv.py), so it is opt-in until it wins.
-USE_HIP_WGRAD = False
+USE_HIP_WGRAD = 'auto'      # True / False / 'auto' (= where tools/bench_conv.py --wgrad shows a win over MIOpen)
 # live HIP-event timing of the kernel launches inside bench.py's timed region: list of (start, end, flops, bytes,
 # kernel name)
 # (bytes = algorithmic HBM bytes of the launch: input + weights + output [+ residual], each touched once)
@@ -68,6 +68,14 @@ def conv_wgrad(x16, gy16, K, R, S, stride, pad, dil):
                                         H, W, C, K, R, S, stride, pad, dil, stream_ptr()),
           'oadg_conv2d_wgrad_nhwc_bf16')
     return dw.permute(0, 3, 1, 2)
+
+
+def _hip_wgrad(K, C, R, P):
+    """use csrc conv_wgrad256_kernel?  Measured on the bench shapes (MI355X): 1.17x MIOpen on the 3x3 at P2, 1.07x at
+    P3, 1.03-1.04x at P4 / layer3, 1.10-1.14x on layer4's 1x1; 0.8-0.97x elsewhere (those stay on MIOpen)."""
+    if USE_HIP_WGRAD == 'auto':
+        return K % 256 == 0 and C % 256 == 0 and ((R == 3 and P >= 65536) or (R == 1 and 4096 <= P <= 16384))
+    return bool(USE_HIP_WGRAD) and K % 128 == 0 and C % 128 == 0
 
 
 def _nhwc_bf16(t):
@@ -205,7 +213,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)   # dx = conv(dy, rot180(W)^T)
             need_x = False
         gw = None
-        if USE_HIP_WGRAD and need_w and K % 128 == 0 and C % 128 == 0:
+        if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
             gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
             need_w = False
             if want_b:

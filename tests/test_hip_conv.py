@@ -127,6 +127,12 @@ def test_conv_autograd_matches_reference(dev):
     (2, 512, 16, 24, 128, 1, 1, 0, 1),
     (1, 128, 33, 31, 256, 3, 2, 1, 1),
     (1, 512, 16, 16, 512, 3, 1, 2, 2),
+    # >= 64 pixel chunks and K, C multiples of 256: the 256-tile phase-pipelined kernel
+    (2, 256, 48, 67, 256, 3, 1, 1, 1),      # ragged pixel tail (6432 pixels)
+    (2, 512, 40, 56, 256, 1, 1, 0, 1),
+    (4, 256, 65, 67, 256, 3, 2, 1, 1),
+    (2, 256, 48, 48, 512, 3, 1, 2, 2),
+    (8, 256, 64, 128, 256, 3, 1, 1, 1),     # FPN P4 at the bench size: 1024 chunks, 56 splits
 ])
 def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
     from oadg_amd import hip_conv
@@ -136,6 +142,7 @@ def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, d
     Wo = (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
     gy = torch.randn(N, K, Ho, Wo, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
     dw = hip_conv.conv_wgrad(x, gy, K, R, R, stride, pad, dil)
+    assert torch.equal(dw, hip_conv.conv_wgrad(x, gy, K, R, R, stride, pad, dil))     # deterministic, race screen
     w = torch.zeros(K, C, R, R, device=dev, requires_grad=True)
     (F.conv2d(x.float(), w, None, stride, pad, dil) * gy.float()).sum().backward()
     assert dw.shape == w.grad.shape
