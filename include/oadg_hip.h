@@ -227,6 +227,38 @@ int oadg_max_iou_assign(const float* boxes, long box_stride, const unsigned char
                         int64_t* labels, int* counts, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RandomSampler selection for a batch (mmdet/core/bbox/samplers/random_sampler.py:32-82, base_sampler.py:38-103).
+ * The permutation is drawn on the host (global CPU generator, oadg_host_randperm_prefix); a job asks for the
+ * candidates of given RANKS among nonzero(gt_inds > 0) (mode 0) or nonzero(gt_inds == 0) (mode 1) of one image.
+ * ranks (ascending, so the output is the reference's sorted index list) live in ranks_dev[rank_off .. +k);
+ * all != 0 selects every candidate (k = candidate count, no ranks read).  Output: out[out_off .. +k) int64.
+ */
+typedef struct oadg_select_job {
+    const void* gt_inds;   /* [n] int64, device */
+    long n;
+    int mode;
+    int k;
+    int all;
+    int rank_off;
+    long out_off;
+} oadg_select_job;
+size_t oadg_sample_select_workspace_bytes(int jobs, long max_n);
+int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, const int* ranks_dev, int64_t* out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* AnchorHead._get_targets_single for all images at once (mmdet/models/dense_heads/anchor_head.py:201-297, the
+ * branch with every anchor inside the image, + DeltaXYWHBBoxCoder.encode delta_xywh_bbox_coder.py:119-180).
+ * jobs_dev / sel: the job table and output of oadg_sample_select, job 2b = positives and 2b+1 = negatives of
+ * image b over the shared anchors [A][4]; gt_inds [B][A] from oadg_max_iou_assign; gts [B][Gmax][4];
+ * gt_labels NULL = RPN (positives get label 0).  Outputs labels [B][A] (fill_label elsewhere), label_weights
+ * [B][A], bbox_targets / bbox_weights [B][A][4]; means4 / stds4 are HOST pointers.  max_k = largest k of a job. */
+int oadg_anchor_targets(const float* anchors, const float* gts, const int64_t* gt_inds, const int64_t* gt_labels,
+                        const oadg_select_job* jobs_dev, const int64_t* sel, int B, int A, int Gmax, int max_k,
+                        int64_t fill_label, float pos_weight, const float* means4, const float* stds4,
+                        int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58
  * state624/left/next are the generator's engine words (in/out); out [k] int64.

@@ -7,6 +7,7 @@ import time
 
 import numpy as np
 import torch
+from torch.profiler import record_function as _rf
 import torch.distributed as dist
 
 from .detectors import integrate_data
@@ -116,8 +117,10 @@ class TrainEngine:
     def step(self, data):
         self.optimizer.zero_grad(set_to_none=True)
         (loss, log_vars), n = self.forward_losses(data)
-        loss.backward()
-        self.optimizer.step()
+        with _rf('sec:backward'):
+            loss.backward()
+        with _rf('sec:optimizer'):
+            self.optimizer.step()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
 
 

@@ -208,11 +208,14 @@ class MaxIoUAssigner:
                                          nbytes, _lib.ptr(gt_inds), _lib.ptr(max_ov), _lib.ptr(labels),
                                          _lib.ptr(counts), _lib.stream_ptr()), 'oadg_max_iou_assign')
         res = []
+        batch = dict(gt_inds=gt_inds, gts=gts, gt_labels=gl, Gmax=Gmax, boxes=bx if shared else None)
         for i in range(B):
             lab = None
             if with_labels:
                 lab = labels[i] if labels is not None else gt_inds.new_full((N,), -1)
-            res.append(AssignResult(counts_host[i], gt_inds[i], max_ov[i], labels=lab))
+            ar = AssignResult(counts_host[i], gt_inds[i], max_ov[i], labels=lab)
+            ar.batch = batch            # the whole-batch tensors, for the fused target kernel
+            res.append(ar)
         return res, counts
 
     def assign_wrt_overlaps(self, overlaps, gt_labels=None):
@@ -255,22 +258,46 @@ class MaxIoUAssigner:
 
 # ----------------------------------------------------------------------------------------------- sample
 class SamplingResult:
-    """sampling_result.py."""
+    """sampling_result.py.  The gathered views (pos_bboxes, ...) are produced on first use: the RPN's fused
+    target kernel never needs them."""
 
     def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
         self.pos_inds, self.neg_inds = pos_inds, neg_inds
-        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
-        self.pos_is_gt = gt_flags[pos_inds]
+        self._src = (bboxes, gt_bboxes, assign_result, gt_flags)
         self.num_gts = gt_bboxes.shape[0]
-        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
-        if gt_bboxes.numel() == 0:
-            assert self.pos_assigned_gt_inds.numel() == 0
-            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
-        else:
-            if len(gt_bboxes.shape) < 2:
-                gt_bboxes = gt_bboxes.view(-1, 4)
-            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds.long(), :]
-        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+        self._cache = {}
+
+    def _get(self, name):
+        c = self._cache
+        if name not in c:
+            bboxes, gt_bboxes, ar, gt_flags = self._src
+            if name == 'pos_bboxes':
+                c[name] = bboxes[self.pos_inds]
+            elif name == 'neg_bboxes':
+                c[name] = bboxes[self.neg_inds]
+            elif name == 'pos_is_gt':
+                c[name] = gt_flags[self.pos_inds]
+            elif name == 'pos_assigned_gt_inds':
+                c[name] = ar.gt_inds[self.pos_inds] - 1
+            elif name == 'pos_gt_bboxes':
+                if gt_bboxes.numel() == 0:
+                    assert self.pos_assigned_gt_inds.numel() == 0
+                    c[name] = torch.empty_like(gt_bboxes).view(-1, 4)
+                else:
+                    g = gt_bboxes.view(-1, 4) if len(gt_bboxes.shape) < 2 else gt_bboxes
+                    c[name] = g[self.pos_assigned_gt_inds.long(), :]
+            elif name == 'pos_gt_labels':
+                c[name] = ar.labels[self.pos_inds] if ar.labels is not None else None
+            else:
+                raise AttributeError(name)
+        return c[name]
+
+    pos_bboxes = property(lambda self: self._get('pos_bboxes'))
+    neg_bboxes = property(lambda self: self._get('neg_bboxes'))
+    pos_is_gt = property(lambda self: self._get('pos_is_gt'))
+    pos_assigned_gt_inds = property(lambda self: self._get('pos_assigned_gt_inds'))
+    pos_gt_bboxes = property(lambda self: self._get('pos_gt_bboxes'))
+    pos_gt_labels = property(lambda self: self._get('pos_gt_labels'))
 
     @property
     def bboxes(self):
@@ -327,6 +354,10 @@ def _pinned_to(t_cpu, device):
     return t_cpu.pin_memory().to(device, non_blocking=True)
 
 
+_JOB_DTYPE = np.dtype([('gt_inds', np.uint64), ('n', np.int64), ('mode', np.int32), ('k', np.int32),
+                       ('all', np.int32), ('rank_off', np.int32), ('out_off', np.int64)])      # oadg_select_job
+
+
 class PendingSampling:
     """RandomSampler.sample for a list of images, split in two so that the single device->host read never
     stalls the stream: :func:`sample_many_begin` enqueues the candidate masks and an asynchronous copy of the
@@ -353,41 +384,87 @@ class PendingSampling:
         else:
             self.counts = counts_dev
 
-    def finish(self):
-        if self.results is not None:
-            return self.results
-        if self.event is not None:
-            self.event.synchronize()
+    def _plan(self):
+        """Host side of the draw, image by image in the reference's order (positives, then negatives):
+        [(k_pos, ranks_pos | None, k_neg, ranks_neg | None)]; ``None`` = every candidate."""
         sampler = self.sampler
         counts = self.counts.tolist() if isinstance(self.counts, torch.Tensor) else self.counts
         if self.added_pos is not None:
             counts = [(c[0] + a, c[1]) for c, a in zip(counts, self.added_pos)]
         num_pos_exp = int(sampler.num * sampler.pos_fraction)
-        results = []
-        for i, ((ar, bboxes, gt_flags, pos_mask, neg_mask), (n_pos, n_neg)) in enumerate(zip(self.prepared, counts)):
-            dev = bboxes.device
-
-            def choose(mask, n_cand, n_exp):
-                if n_cand <= n_exp:
-                    k, sel = n_cand, mask
-                else:
-                    k = n_exp
-                    perm = _pinned_to(randperm_prefix(n_cand, n_exp), dev)       # random_sampler.py:58
-                    flags = torch.zeros(mask.numel() + 1, dtype=torch.bool, device=dev)
-                    flags.index_fill_(0, perm, True)   # (flags[perm] = True blocks the host, see dense_heads)
-                    rank = torch.cumsum(mask, 0) - 1
-                    sel = mask & flags[rank.clamp(min=0)]
-                if k == 0:
-                    return torch.zeros((0,), dtype=torch.long, device=dev), 0
-                return torch.nonzero_static(sel, size=k).squeeze(1), k
-            pos_inds, k_pos = choose(pos_mask, n_pos, num_pos_exp)
+        plan = []
+        for n_pos, n_neg in counts:
+            if n_pos <= num_pos_exp:
+                k_pos, r_pos = n_pos, None
+            else:
+                k_pos, r_pos = num_pos_exp, randperm_prefix(n_pos, num_pos_exp)      # random_sampler.py:58
             n_neg_exp = sampler.num - k_pos
             if sampler.neg_pos_ub >= 0:
                 n_neg_exp = min(n_neg_exp, int(sampler.neg_pos_ub * max(1, k_pos)))
-            neg_inds, _ = choose(neg_mask, n_neg, n_neg_exp)
-            results.append(SamplingResult(pos_inds, neg_inds, bboxes, self.gt_bboxes_list[i], ar, gt_flags))
-        self.results = results
-        return results
+            if n_neg <= n_neg_exp:
+                k_neg, r_neg = n_neg, None
+            else:
+                k_neg, r_neg = n_neg_exp, randperm_prefix(n_neg, n_neg_exp)
+            plan.append((k_pos, r_pos, k_neg, r_neg))
+        return plan
+
+    def _select_device(self, plan, dev):
+        """Locate the planned candidates with csrc/targets.hip (two launches for the whole batch)."""
+        from .. import _lib
+        nj = 2 * len(plan)
+        jobs = np.zeros(nj, dtype=_JOB_DTYPE)
+        ranks, out_off, max_n = [], 0, 0
+        for i, (k_pos, r_pos, k_neg, r_neg) in enumerate(plan):
+            gi = self.prepared[i][0].gt_inds
+            assert gi.is_contiguous() and gi.dtype == torch.long
+            for j, (k, r) in enumerate(((k_pos, r_pos), (k_neg, r_neg))):
+                jb = jobs[2 * i + j]
+                jb['gt_inds'], jb['n'], jb['mode'], jb['k'] = gi.data_ptr(), gi.numel(), j, k
+                jb['all'], jb['rank_off'], jb['out_off'] = int(r is None), sum(len(x) for x in ranks), out_off
+                if r is not None:
+                    ranks.append(np.sort(r.numpy()).astype(np.int32))
+                out_off += k
+            max_n = max(max_n, gi.numel())
+        rk = np.concatenate(ranks) if ranks else np.zeros(1, np.int32)
+        blob = np.concatenate([jobs.view(np.uint8), rk.view(np.uint8)])
+        blob_dev = _pinned_to(torch.from_numpy(blob), dev)
+        jobs_dev = blob_dev[:jobs.nbytes]
+        ranks_dev = blob_dev[jobs.nbytes:]
+        sel = torch.empty(max(out_off, 1), dtype=torch.long, device=dev)
+        L = _lib.lib()
+        nbytes = L.oadg_sample_select_workspace_bytes(nj, max_n)
+        ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        _lib.check(L.oadg_sample_select(_lib.ptr(jobs_dev), nj, max_n, _lib.ptr(ranks_dev), _lib.ptr(sel),
+                                        _lib.ptr(ws), nbytes, _lib.stream_ptr()), 'oadg_sample_select')
+        self.device_select = dict(jobs_dev=jobs_dev, sel=sel, jobs=jobs, blob=blob_dev,
+                                  max_k=int(jobs['k'].max()) if nj else 0)
+        return [(sel[int(jobs[2 * i]['out_off']):int(jobs[2 * i]['out_off']) + plan[i][0]],
+                 sel[int(jobs[2 * i + 1]['out_off']):int(jobs[2 * i + 1]['out_off']) + plan[i][2]])
+                for i in range(len(plan))]
+
+    def finish(self):
+        if self.results is not None:
+            return self.results
+        if self.event is not None:
+            self.event.synchronize()
+        plan = self._plan()
+        dev = self.prepared[0][1].device if self.prepared else None
+        if dev is not None and dev.type == 'cuda':
+            picked = self._select_device(plan, dev)
+        else:
+            picked = []
+            for (ar, bboxes, gt_flags, pos_mask, neg_mask), (k_pos, r_pos, k_neg, r_neg) in zip(self.prepared, plan):
+                def choose(mask, k, perm):
+                    if k == 0:
+                        return torch.zeros((0,), dtype=torch.long, device=mask.device)
+                    if perm is None:
+                        return torch.nonzero(mask, as_tuple=False).squeeze(1)
+                    cand = torch.nonzero(mask, as_tuple=False).squeeze(1)
+                    return cand[perm.to(cand.device)].unique()
+                picked.append((choose(pos_mask(), k_pos, r_pos), choose(neg_mask(), k_neg, r_neg)))
+        self.results = [SamplingResult(p, n, prep[1], self.gt_bboxes_list[i], prep[0], prep[2])
+                        for i, (prep, (p, n)) in enumerate(zip(self.prepared, picked))]
+        return self.results
 
 
 def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None, counts=None):
@@ -410,11 +487,11 @@ def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_l
             added.append(int(gtb.shape[0]))          # every added gt is a positive candidate (assign_result.py)
         else:
             added.append(0)
-        prepared.append((ar, bboxes, gt_flags, ar.gt_inds > 0, ar.gt_inds == 0))
+        prepared.append((ar, bboxes, gt_flags, (lambda a_=ar: a_.gt_inds > 0), (lambda a_=ar: a_.gt_inds == 0)))
     if not prepared:
         counts = None
     elif counts is None:
-        counts = torch.stack([torch.stack([p[3].sum(), p[4].sum()]) for p in prepared])
+        counts = torch.stack([torch.stack([p[3]().sum(), p[4]().sum()]) for p in prepared])
         added = None                                  # the masks already contain the added gts
     return PendingSampling(sampler, prepared, gt_bboxes_list, counts, added)
 

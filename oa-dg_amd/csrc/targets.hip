@@ -1,0 +1,195 @@
+// Sampler selection and anchor targets for a whole batch (integer / index work, bit-exact):
+//   oadg_sample_select  - RandomSampler: locate the candidates with the ranks the host drew
+//       (mmdet/core/bbox/samplers/random_sampler.py:32-82: candidates = nonzero(gt_inds > 0) resp. (== 0) in
+//        ascending order, chosen = candidates[perm[:num]], then .unique() = sorted)
+//   oadg_anchor_targets - AnchorHead._get_targets_single for all images (anchor_head.py:201-297 with
+//        DeltaXYWHBBoxCoder.encode, delta_xywh_bbox_coder.py:119-180 incl. the fork's zero-size guard :152-160)
+#include "common.h"
+#include "../../include/oadg_hip.h"
+
+namespace {
+
+constexpr int SEL_CHUNK = 1024;        // candidates are counted per 1024-element chunk
+constexpr int SEL_MAX_CHUNKS = 8192;   // 8.4 M boxes per job
+
+__device__ __forceinline__ bool is_cand(long long v, int mode) { return mode == 0 ? v > 0 : v == 0; }
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const oadg_select_job* __restrict__ jobs, int* __restrict__ cnt,
+                                                        int max_chunks) {
+    const oadg_select_job jb = jobs[blockIdx.y];
+    const long base = (long)blockIdx.x * SEL_CHUNK;
+    if (base >= jb.n) return;
+    const long long* v = (const long long*)jb.gt_inds;
+    int c = 0;
+    for (int i = threadIdx.x; i < SEL_CHUNK; i += 256) {
+        const long n = base + i;
+        c += (n < jb.n && is_cand(v[n], jb.mode)) ? 1 : 0;
+    }
+    __shared__ int red[4];
+    c = wave_sum_i(c);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[(long)blockIdx.y * max_chunks + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one workgroup per job: exclusive scan of the chunk counts in LDS, then one wave per requested rank
+__global__ __launch_bounds__(256) void sel_locate_kernel(const oadg_select_job* __restrict__ jobs,
+                                                         const int* __restrict__ cnt, const int* __restrict__ ranks,
+                                                         long long* __restrict__ out, int max_chunks) {
+    __shared__ int pre[SEL_MAX_CHUNKS + 1];
+    __shared__ int carry;
+    const oadg_select_job jb = jobs[blockIdx.x];
+    if (jb.k <= 0) return;
+    const int nch = (int)((jb.n + SEL_CHUNK - 1) / SEL_CHUNK);
+    const int* c = cnt + (long)blockIdx.x * max_chunks;
+    if (threadIdx.x == 0) {          // chunk counts are few (<= 8192): a serial prefix is a few microseconds
+        int s = 0;
+        for (int i = 0; i < nch; ++i) { pre[i] = s; s += c[i]; }
+        pre[nch] = s;
+        carry = s;
+    }
+    __syncthreads();
+    const long long* v = (const long long*)jb.gt_inds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < jb.k; i += 4) {
+        const int r = jb.all ? i : ranks[jb.rank_off + i];
+        if (r >= carry) continue;                      // cannot happen with consistent counts
+        int lo = 0, hi = nch;                          // largest b with pre[b] <= r
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= r) lo = mid; else hi = mid;
+        }
+        int need = r - pre[lo];                        // rank inside the chunk
+        const long base = (long)lo * SEL_CHUNK;
+        for (int j = 0; j < SEL_CHUNK; j += 64) {
+            const long n = base + j + lane;
+            const bool m = n < jb.n && is_cand(v[n], jb.mode);
+            const unsigned long long bal = __ballot(m);
+            const int pc = __popcll(bal);
+            if (need < pc) {
+                // position of the need-th set bit
+                const int before = __popcll(bal & ((1ull << lane) - 1ull));
+                if (m && before == need) out[jb.out_off + i] = n;
+                break;
+            }
+            need -= pc;
+        }
+    }
+}
+
+struct TargetArgs {
+    const float* anchors;          // [A][4]
+    const float* gts;              // [B][Gmax][4]
+    const long long* gt_inds;      // [B][A]
+    const long long* gt_labels;    // [B][Gmax] or null (RPN: positives get label 0)
+    const oadg_select_job* jobs;   // [2B]: job 2b = positives of image b, 2b+1 = negatives
+    const long long* sel;          // selected indices (oadg_sample_select output)
+    long long* labels;             // [B][A]
+    float* label_weights;          // [B][A]
+    float* bbox_targets;           // [B][A][4]
+    float* bbox_weights;           // [B][A][4]
+    int B, A, Gmax;
+    long long fill_label;
+    float pos_weight;
+    float mean[4], stdv[4];
+};
+
+__global__ __launch_bounds__(256) void targets_fill_kernel(TargetArgs a) {
+    const long total = (long)a.B * a.A;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        a.labels[i] = a.fill_label;
+        a.label_weights[i] = 0.f;
+        reinterpret_cast<float4*>(a.bbox_targets)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(a.bbox_weights)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// bbox2delta of one pair, operation for operation as the tensor expression in core/bbox.py
+__device__ __forceinline__ float4 encode_delta(const float4 p, const float4 g, const float* mean, const float* stdv) {
+    const float px = (p.x + p.z) * 0.5f, py = (p.y + p.w) * 0.5f;
+    float pw = p.z - p.x, ph = p.w - p.y;
+    float gx = (g.x + g.z) * 0.5f, gy = (g.y + g.w) * 0.5f;
+    float gw = g.z - g.x, gh = g.w - g.y;
+    const bool nx = pw == 0.f, ny = ph == 0.f;
+    if (nx) { pw = 1e-6f; gw = 1e-6f; gx = px; }
+    if (ny) { ph = 1e-6f; gh = 1e-6f; }
+    if (nx && ny) gy = py;
+    float4 d;
+    d.x = ((gx - px) / pw - mean[0]) / stdv[0];
+    d.y = ((gy - py) / ph - mean[1]) / stdv[1];
+    d.z = (logf(gw / pw) - mean[2]) / stdv[2];
+    d.w = (logf(gh / ph) - mean[3]) / stdv[3];
+    return d;
+}
+
+__global__ __launch_bounds__(256) void targets_scatter_kernel(TargetArgs a) {
+    const int job = blockIdx.y;
+    const oadg_select_job jb = a.jobs[job];
+    const int b = job >> 1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < jb.k; i += gridDim.x * 256) {
+        const long long n = a.sel[jb.out_off + i];
+        const long o = (long)b * a.A + n;
+        if ((job & 1) == 0) {
+            const long long gi = a.gt_inds[o] - 1;
+            const float4 p = reinterpret_cast<const float4*>(a.anchors)[n];
+            const float4 g = reinterpret_cast<const float4*>(a.gts)[(long)b * a.Gmax + gi];
+            reinterpret_cast<float4*>(a.bbox_targets)[o] = encode_delta(p, g, a.mean, a.stdv);
+            reinterpret_cast<float4*>(a.bbox_weights)[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+            a.labels[o] = a.gt_labels ? a.gt_labels[(long)b * a.Gmax + gi] : 0;
+            a.label_weights[o] = a.pos_weight <= 0.f ? 1.f : a.pos_weight;
+        } else {
+            a.label_weights[o] = 1.f;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t oadg_sample_select_workspace_bytes(int jobs, long max_n) {
+    if (jobs < 1 || max_n < 0) return 0;
+    const long ch = (max_n + SEL_CHUNK - 1) / SEL_CHUNK;
+    return (size_t)jobs * (size_t)(ch > 0 ? ch : 1) * sizeof(int);
+}
+
+extern "C" int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, const int* ranks_dev,
+                                  int64_t* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!jobs_dev || jobs < 1 || max_n < 0 || !out || !workspace) return OADG_EARG;
+    const long ch = (max_n + SEL_CHUNK - 1) / SEL_CHUNK;
+    if (ch > SEL_MAX_CHUNKS) return OADG_EARG;
+    if (workspace_bytes < oadg_sample_select_workspace_bytes(jobs, max_n)) return OADG_ESIZE;
+    if (max_n == 0) return OADG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sel_count_kernel, dim3((unsigned)ch, jobs), dim3(256), 0, st, jobs_dev, (int*)workspace, (int)ch);
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sel_locate_kernel, dim3(jobs), dim3(256), 0, st, jobs_dev, (const int*)workspace, ranks_dev,
+                       (long long*)out, (int)ch);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+extern "C" int oadg_anchor_targets(const float* anchors, const float* gts, const int64_t* gt_inds,
+                                   const int64_t* gt_labels, const oadg_select_job* jobs_dev, const int64_t* sel,
+                                   int B, int A, int Gmax, int max_k, int64_t fill_label, float pos_weight,
+                                   const float* means4, const float* stds4, int64_t* labels, float* label_weights,
+                                   float* bbox_targets, float* bbox_weights, void* stream) {
+    if (!anchors || !gt_inds || !jobs_dev || !sel || !labels || !label_weights || !bbox_targets || !bbox_weights ||
+        !means4 || !stds4)
+        return OADG_EARG;
+    if (B < 1 || A < 1 || Gmax < 0 || max_k < 0 || (Gmax > 0 && !gts)) return OADG_EARG;
+    TargetArgs a;
+    a.anchors = anchors; a.gts = gts; a.gt_inds = (const long long*)gt_inds; a.gt_labels = (const long long*)gt_labels;
+    a.jobs = jobs_dev; a.sel = (const long long*)sel; a.labels = (long long*)labels; a.label_weights = label_weights;
+    a.bbox_targets = bbox_targets; a.bbox_weights = bbox_weights; a.B = B; a.A = A; a.Gmax = Gmax;
+    a.fill_label = fill_label; a.pos_weight = pos_weight;
+    for (int i = 0; i < 4; ++i) { a.mean[i] = means4[i]; a.stdv[i] = stds4[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)B * A;
+    const int fb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(targets_fill_kernel, dim3(fb), dim3(256), 0, st, a);
+    OADG_LAUNCH_CHECK();
+    if (max_k > 0) {
+        hipLaunchKernelGGL(targets_scatter_kernel, dim3((max_k + 255) / 256, 2 * B), dim3(256), 0, st, a);
+        OADG_LAUNCH_CHECK();
+    }
+    return OADG_OK;
+}

@@ -5,6 +5,7 @@ proposal NMS is the batched HIP NMS (one launch for all images instead of one mm
 import copy
 
 import torch
+from torch.profiler import record_function as _rf
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -127,6 +128,9 @@ class AnchorHead(nn.Module):
         self._pending_targets = None
         if fast and pending is not None and pending[0] == (num_imgs, tuple(num_level_anchors)):
             srs = pending[1].finish()       # assigned at the start of the step (begin_targets)
+            fused = self._fused_targets(pending[1], srs, num_level_anchors, gt_labels_list, unmap_outputs)
+            if fused is not None:
+                return fused
         elif fast:   # one host read for the whole batch instead of ~6 per image
             ars = [self._assign_inside(concat_anchors[i], concat_flags[i], gt_bboxes_list[i], img_metas[i],
                                        None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]
@@ -145,6 +149,42 @@ class AnchorHead(nn.Module):
                 images_to_levels(all_label_weights, num_level_anchors),
                 images_to_levels(all_bbox_targets, num_level_anchors),
                 images_to_levels(all_bbox_weights, num_level_anchors), num_total_pos, num_total_neg)
+
+    def _fused_targets(self, pend, srs, num_level_anchors, gt_labels_list, unmap_outputs):
+        """anchor_head.py:201-297 for the whole batch in two launches (csrc/targets.hip oadg_anchor_targets) when
+        the assignment and the selection were done by the batch kernels over shared, all-inside anchors."""
+        from . import _lib
+        sel = getattr(pend, 'device_select', None)
+        batch = getattr(pend.prepared[0][0], 'batch', None) if pend.prepared else None
+        if sel is None or batch is None or batch['boxes'] is None or not unmap_outputs or self.reg_decoded_bbox or \
+                not (self._all_anchors_valid and self.train_cfg.allowed_border < 0) or \
+                not (gt_labels_list is None or all(l is None for l in gt_labels_list)):
+            return None
+        anchors, gt_inds = batch['boxes'], batch['gt_inds']
+        B, A = gt_inds.shape
+        dev = anchors.device
+        labels = torch.empty((B, A), dtype=torch.long, device=dev)
+        label_weights = torch.empty((B, A), dtype=torch.float32, device=dev)
+        bbox_targets = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        bbox_weights = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+        import ctypes
+        f4 = ctypes.c_float * 4
+        means, stds = f4(*self.bbox_coder.means), f4(*self.bbox_coder.stds)
+        L = _lib.lib()
+        _lib.check(L.oadg_anchor_targets(_lib.ptr(anchors), _lib.ptr(batch['gts']), _lib.ptr(gt_inds), None,
+                                         _lib.ptr(sel['jobs_dev']), _lib.ptr(sel['sel']), B, A, batch['Gmax'],
+                                         sel['max_k'], self.num_classes, float(self.train_cfg.pos_weight),
+                                         ctypes.cast(means, ctypes.c_void_p), ctypes.cast(stds, ctypes.c_void_p),
+                                         _lib.ptr(labels), _lib.ptr(label_weights), _lib.ptr(bbox_targets),
+                                         _lib.ptr(bbox_weights), _lib.stream_ptr()), 'oadg_anchor_targets')
+        num_total_pos = sum(max(r.pos_inds.numel(), 1) for r in srs)
+        num_total_neg = sum(max(r.neg_inds.numel(), 1) for r in srs)
+        out, start = [[], [], [], []], 0
+        for n in num_level_anchors:              # images_to_levels: [B, n_level(, 4)] per level
+            for lst, t in zip(out, (labels, label_weights, bbox_targets, bbox_weights)):
+                lst.append(t[:, start:start + n])
+            start += n
+        return out[0], out[1], out[2], out[3], num_total_pos, num_total_neg
 
     def _assign_inside(self, flat_anchors, valid_flags, gt_bboxes, img_meta, gt_labels=None):
         """Assignment over the anchors the reference keeps (anchor_inside_flags, anchor/utils.py:19-43) without
@@ -208,9 +248,10 @@ class AnchorHead(nn.Module):
         device = cls_scores[0].device
         anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
-        targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
-                                   gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
-                                   label_channels=label_channels)
+        with _rf('sec:rpn_get_targets'):
+            targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
+                                       gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
+                                       label_channels=label_channels)
         if targets is None:
             return None
         self.rpn_targets = targets
@@ -228,16 +269,19 @@ class AnchorHead(nn.Module):
                       **kwargs):
         """base_dense_head.py:302-342.  ``num_proposal_imgs`` limits proposal generation to the first images
         (the contrastive RoI head only consumes the view-1 lists, contrastive_roi_head.py:85-95)."""
-        outs = self(x)
+        with _rf('sec:rpn_head_convs'):
+            outs = self(x)
         # proposals are enqueued before the loss so that the RoI head's host read (candidate counts) only
         # waits for the NMS, while the device is still busy with the RPN loss kernels
         proposal_list = None
         if proposal_cfg is not None:
-            proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
-                                            num_imgs=num_proposal_imgs, padded=padded_proposals)
+            with _rf('sec:rpn_get_bboxes'):
+                proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
+                                                num_imgs=num_proposal_imgs, padded=padded_proposals)
         if after_proposals is not None:
             after_proposals(proposal_list)      # e.g. the RoI head's assignment + asynchronous count read
-        losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        with _rf('sec:rpn_loss'):
+            losses = self.loss(*outs, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
         if proposal_cfg is None:
             return losses
         return losses, proposal_list

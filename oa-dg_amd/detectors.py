@@ -5,6 +5,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+from torch.profiler import record_function as _rf
 
 from .core import bbox_overlaps_np
 from .core.bbox import _pinned_to
@@ -177,8 +178,10 @@ class TwoStageDetector(BaseDetector):
         # of the RPN and of the RoI head) are asynchronous copies followed by an event; each is waited for only
         # after more device work has been enqueued behind it, so the stream never drains.
         if self.with_rpn and gt_bboxes_ignore is None and hasattr(self.rpn_head, 'begin_targets'):
-            self.rpn_head.begin_targets(img.shape[2:], gt_bboxes, img_metas, img.device)
-        x = self.extract_feat(img)
+            with _rf('sec:rpn_begin_targets'):
+                self.rpn_head.begin_targets(img.shape[2:], gt_bboxes, img_metas, img.device)
+        with _rf('sec:backbone_fpn'):
+            x = self.extract_feat(img)
         losses = dict()
         pending = {}
         if self.with_rpn:
@@ -188,8 +191,9 @@ class TwoStageDetector(BaseDetector):
 
             def after_proposals(props):
                 if gt_bboxes_ignore is None and hasattr(self.roi_head, 'begin_sampling'):
-                    pending['roi'] = self.roi_head.begin_sampling(props, gt_bboxes, gt_labels, len(img_metas),
-                                                                  **kwargs)
+                    with _rf('sec:roi_begin_sampling'):
+                        pending['roi'] = self.roi_head.begin_sampling(props, gt_bboxes, gt_labels, len(img_metas),
+                                                                      **kwargs)
             rpn_losses, proposal_list = self.rpn_head.forward_train(
                 x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
                 proposal_cfg=proposal_cfg, num_proposal_imgs=n_prop, padded_proposals=True,
@@ -201,7 +205,8 @@ class TwoStageDetector(BaseDetector):
             host_gts = [m.get('gt_bboxes_np') for m in img_metas]
             if all(g is not None for g in host_gts):
                 kwargs['img_metas_host'] = host_gts
-            kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
+            with _rf('sec:random_proposals'):
+                kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
             kwargs.pop('img_metas_host', None)
         losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
                                                   gt_bboxes_ignore, gt_masks,

@@ -4,6 +4,7 @@ RoI feature extraction is one HIP launch over the whole pyramid (level mapping i
 reference's per-level nonzero/gather/scatter loop; every pyramid level is therefore always in the autograd
 graph (the reference needs a dummy-graph trick for that, single_level_roi_extractor.py:136-145)."""
 import torch
+from torch.profiler import record_function as _rf
 import torch.nn as nn
 
 from . import hip_ops
@@ -364,7 +365,8 @@ class StandardRoIHead(BaseRoIHead):
         if gt_bboxes_ignore is None:
             gt_bboxes_ignore = [None] * num_imgs
         if pending_sampling is not None and hasattr(pending_sampling, 'finish'):
-            first = pending_sampling.finish()
+            with _rf('sec:roi_sampling_finish'):
+                first = pending_sampling.finish()
             sampling_results = list(first)
             if 'num_views' in kwargs:
                 sampling_results = []
@@ -408,19 +410,22 @@ class ContrastiveRoIHead(StandardRoIHead):
 
     def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
                             gt_instance_inds=None, **kwargs):
-        rois = bbox2roi([r.bboxes for r in sampling_results])
-        res = self._bbox_forward(x, rois)
-        self._last_rois = [rois.detach()]
-        if 'random_proposal_list' in kwargs:
-            rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
-            res2 = self._bbox_forward(x, rois2)
-            res['cont_feats'] = torch.cat([res['cont_feats'], res2['cont_feats']], dim=0)
-            self._last_rois.append(rois2.detach())
-        targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
-                                                           self.train_cfg)
-        self.bbox_targets = targets
-        num_sampled, pos_rows = self._host_counts(sampling_results)
-        res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], res['cont_feats'], rois,
-                                                 *targets, num_sampled=num_sampled, pos_rows=pos_rows,
-                                                 **kwargs))
+        with _rf('sec:roi_bbox_forward'):
+            rois = bbox2roi([r.bboxes for r in sampling_results])
+            res = self._bbox_forward(x, rois)
+            self._last_rois = [rois.detach()]
+            if 'random_proposal_list' in kwargs:
+                rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
+                res2 = self._bbox_forward(x, rois2)
+                res['cont_feats'] = torch.cat([res['cont_feats'], res2['cont_feats']], dim=0)
+                self._last_rois.append(rois2.detach())
+        with _rf('sec:roi_targets'):
+            targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
+                                                               self.train_cfg)
+            self.bbox_targets = targets
+            num_sampled, pos_rows = self._host_counts(sampling_results)
+        with _rf('sec:roi_loss'):
+            res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], res['cont_feats'], rois,
+                                                     *targets, num_sampled=num_sampled, pos_rows=pos_rows,
+                                                     **kwargs))
         return res

@@ -69,3 +69,48 @@ def test_assign_many_rpn_scale(dev):
         assert torch.equal(ars[i].gt_inds, ref.gt_inds)
         assert torch.equal(ars[i].max_overlaps, ref.max_overlaps)
         assert ars[i].labels is None
+
+
+def test_fused_rpn_targets_equal_reference_order(dev):
+    """begin_targets (batch assign) + device selection + fused anchor targets against the reference order of
+    operations (anchor_inside_flags, assign, sample, encode, unmap - anchor_head.py:201-297) on the GPU: every
+    output tensor bit-identical, the CPU generator consumed identically.  Anchor count > 4096 per sampler draw so
+    that the O(k) randperm replay is exercised as well."""
+    import numpy as np
+    from oadg_amd.config import ConfigDict
+    from oadg_amd.dense_heads import RPNHead
+    train_cfg = ConfigDict(
+        assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3,
+                      match_low_quality=True, ignore_iof_thr=-1),
+        sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False),
+        allowed_border=-1, pos_weight=-1, debug=False)
+    strides, H, W = [4, 8, 16, 32], 192, 320
+    head = RPNHead(in_channels=8, feat_channels=8,
+                   anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=strides),
+                   loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                   loss_bbox=dict(type='L1Loss', loss_weight=1.0), train_cfg=train_cfg).to(dev)
+    rs = np.random.RandomState(7)
+    sizes = [(int(np.ceil(H / s)), int(np.ceil(W / s))) for s in strides]
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3)) for _ in range(4)]
+    gts = []
+    for n in (9, 4, 0, 30):
+        c = rs.uniform([20, 20], [W - 20, H - 20], (n, 2))
+        wh = rs.uniform(12, 120, (n, 2))
+        gts.append(torch.tensor(np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32), device=dev))
+    out = {}
+    for mode in ('reference', 'fused'):
+        head.reference_order_targets = mode == 'reference'
+        head._pending_targets = None
+        torch.manual_seed(11)
+        if mode == 'fused':
+            head.begin_targets((H, W), gts, metas, dev)
+            assert head._pending_targets is not None
+        anchors, flags = head.get_anchors(sizes, metas, device=dev)
+        out[mode] = head.get_targets(anchors, flags, gts, metas)
+        out[mode + '_rng'] = torch.rand(1).item()
+    a, b = out['reference'], out['fused']
+    assert a[4:] == b[4:], (a[4:], b[4:])
+    for la, lb in zip(a[:4], b[:4]):
+        for x, y in zip(la, lb):
+            assert x.shape == y.shape and torch.equal(x, y)
+    assert out['reference_rng'] == out['fused_rng']

@@ -67,6 +67,21 @@ def main():
         print('kernels < 10 us on the main stream, per step:')
         for nm, (c, t) in sorted(small.items(), key=lambda kv: -kv[1][1])[:28]:
             print(f'  {c / 2:6.0f} x  {t / 2e3:6.3f} ms  {nm}')
+        # launches and device time per annotated section (launch API calls inside the section's host interval;
+        # the backward section covers the autograd thread's launches)
+        secs = [e for e in ev if e.get('cat') == 'user_annotation' and e['name'].startswith('sec:')]
+        launches = sorted((e['ts'], e['args'].get('correlation')) for e in ev
+                          if e.get('cat') in ('cuda_runtime', 'cuda_driver') and 'aunch' in e['name'])
+        kdur = {e['args'].get('correlation'): e['dur'] for e in ks}
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for sct in secs:
+            for ts, corr in launches:
+                if sct['ts'] <= ts <= sct['ts'] + sct['dur']:
+                    agg[sct['name']][0] += 1
+                    agg[sct['name']][1] += kdur.get(corr, 0.0)
+        print('sections (per step): launches, device ms')
+        for nm, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            print(f'  {nm:28s} {c / 2:7.0f} {t / 2e3:8.2f}')
         # idle gaps on the busiest stream
         main = max(per.values(), key=lambda l: sum(b - a for a, b, _ in l))
         main.sort()
