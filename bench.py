@@ -56,6 +56,8 @@ def parse():
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline-thread', type=int, default=1,
+                    help='1: the data pipeline host code runs in a worker thread (DataLoader-worker analogue)')
     ap.add_argument('--conv', default='mfma', choices=['mfma', 'miopen'],
                     help='mfma: hand-written implicit-GEMM kernels where they apply; miopen: torch.conv2d only')
     return ap.parse_args()
@@ -159,12 +161,16 @@ def main():
     # a side stream right after the step of batch i.  Every timed step contains one pipeline pass (OA-Mix +
     # Normalize/Pad of 4 images) and one train step; the batch for the first timed step is produced by the last
     # warm-up step and the last timed step produces one more batch, so K pipeline passes run inside the region.
-    state = {'next': pipe.prefetch(*batches[0])}
+    wseed = None if a.pipeline_thread == 0 else 1000 + rank     # worker thread with its own numpy stream
+    state = {'next': pipe.prefetch(*batches[0], worker_seed=wseed)}
 
     def step(i):
         data = state['next'].get()
+        if wseed is not None:        # the worker enqueues batch i+1 while this thread runs step i
+            state['next'] = pipe.prefetch(*batches[(i + 1) % nb], worker_seed=wseed)
         out = engine.step(data)
-        state['next'] = pipe.prefetch(*batches[(i + 1) % nb])
+        if wseed is None:
+            state['next'] = pipe.prefetch(*batches[(i + 1) % nb])
         return out
 
     for i in range(a.warmup):

@@ -84,21 +84,40 @@ class DevicePipeline:
         assert self.norm is not None, 'the pipeline needs a Normalize step'
         self.dtype = dtype
 
-    def prefetch(self, imgs_u8, gt_bboxes, gt_labels):
+    def prefetch(self, imgs_u8, gt_bboxes, gt_labels, worker_seed=None):
         """Enqueue the whole pipeline for one batch on a side stream and return a handle (``.get()``).
 
         This is the device-side analogue of the reference's DataLoader workers (``workers_per_gpu`` processes
         with prefetching, configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes.py:27): augmentation of
         batch i+1 overlaps the training step of batch i.  The inputs must already be complete on the device
-        (resident batches); OA-Mix's small host reads only wait on this stream."""
+        (resident batches); OA-Mix's small host reads only wait on this stream.
+
+        ``worker_seed`` not None: the host side of the pipeline (OA-Mix's draws and ~1000 launches, ~10 ms) runs
+        in a worker THREAD with its own ``RandomState(worker_seed)`` stream - a DataLoader worker likewise owns a
+        private numpy stream - so it also overlaps the step's host work; None keeps it in the caller's thread on
+        the global numpy stream (bit-reproducible against the oracle with a single ``np.random.seed``)."""
         if getattr(self, '_stream', None) is None:
             self._stream = torch.cuda.Stream(device=imgs_u8.device)
             self._stream.wait_stream(torch.cuda.current_stream())
+        if worker_seed is None:
+            return _Prefetched(*self._run_on_side_stream(imgs_u8, gt_bboxes, gt_labels))
+        if getattr(self, '_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            from .oa_mix import use_random_state
+            dev, rs = imgs_u8.device, np.random.RandomState(worker_seed)
+
+            def init():
+                torch.cuda.set_device(dev)
+                use_random_state(rs)
+            self._pool = ThreadPoolExecutor(1, thread_name_prefix='oadg-pipeline', initializer=init)
+        return _PrefetchedFuture(self._pool.submit(self._run_on_side_stream, imgs_u8, gt_bboxes, gt_labels))
+
+    def _run_on_side_stream(self, imgs_u8, gt_bboxes, gt_labels):
         with torch.cuda.stream(self._stream):
             out = self(imgs_u8, gt_bboxes, gt_labels)
             evt = torch.cuda.Event()
             evt.record()
-        return _Prefetched(out, evt)
+        return out, evt
 
     def __call__(self, imgs_u8, gt_bboxes, gt_labels):
         """imgs_u8: uint8 [N,H,W,3] cuda tensor (BGR bytes); gt_bboxes: list of float32 [n_i,4] numpy arrays;
@@ -150,6 +169,16 @@ class DevicePipeline:
             out['multilevel_boxes'] = ml
             out['oamix_boxes'] = oa
         return {k: v for k, v in out.items() if k in self.keys or k == 'img_metas'}
+
+
+class _PrefetchedFuture:
+    """A batch whose pipeline is being enqueued by the worker thread."""
+
+    def __init__(self, future):
+        self.future = future
+
+    def get(self):
+        return _Prefetched(*self.future.result()).get()
 
 
 class _Prefetched:

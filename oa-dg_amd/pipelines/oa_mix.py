@@ -13,6 +13,26 @@ import ctypes
 import math
 
 import numpy as np
+
+
+class _ActiveRandomState:
+    """The random stream OA-Mix draws from: numpy's GLOBAL RandomState (``np.random.*``, like the reference, so a
+    seeded run replays it draw for draw) unless the calling thread installed its own with :func:`use_random_state`
+    (the pipeline's prefetch worker does, exactly like a DataLoader worker process owns a private stream)."""
+
+    def __getattr__(self, name):
+        return getattr(getattr(_TLS, 'rs', None) or np.random.mtrand._rand, name)
+
+
+import threading  # noqa: E402
+
+_TLS = threading.local()
+rng = _ActiveRandomState()
+
+
+def use_random_state(rs):
+    """Route this thread's OA-Mix draws to ``rs`` (a ``np.random.RandomState``); ``None`` = the global stream."""
+    _TLS.rs = rs
 import torch
 
 from .. import _lib
@@ -33,7 +53,7 @@ MIX_TARGET_DTYPE = np.dtype([('fg_index', '<i4'), ('rect', '<i4', (4,)), ('m_oa'
 
 
 def sample_level(n):            # augmix.py:60-61
-    return np.random.uniform(low=0.1, high=n)
+    return rng.uniform(low=0.1, high=n)
 
 
 def int_parameter(level, maxval):   # augmix.py:32-43
@@ -73,13 +93,13 @@ def geo_matrix(kind, severity, img_size, center=None, size_for_level=None):
     """The affine matrix one geometric leaf draws (augmix.py:83-188), in the dtype cv2 receives it."""
     if kind == 'rotate':
         deg = int_parameter(sample_level(severity), 30)
-        if np.random.uniform() > 0.5:
+        if rng.uniform() > 0.5:
             deg = -deg
         c = center if center is not None else (img_size[0] / 2, img_size[1] / 2)
         return rotation_matrix(c, deg)
     if kind in ('shear_x', 'shear_y'):
         lvl = float_parameter(sample_level(severity), 0.3)
-        if np.random.uniform() > 0.5:
+        if rng.uniform() > 0.5:
             lvl = -lvl
         if kind == 'shear_x':
             tx = 0 if center is None else -lvl * center[1]
@@ -89,7 +109,7 @@ def geo_matrix(kind, severity, img_size, center=None, size_for_level=None):
     ax = 0 if kind == 'translate_x' else 1
     maxval = img_size[ax] if size_for_level is None else size_for_level[ax]
     lvl = int_parameter(sample_level(severity), maxval / 3)
-    if np.random.random() > 0.5:
+    if rng.random() > 0.5:
         lvl = -lvl
     return np.float32([[1, 0, -lvl], [0, 1, 0]]) if ax == 0 else np.float32([[1, 0, 0], [0, 1, -lvl]])
 
@@ -212,13 +232,13 @@ class OAMix:
                         fg_scores=None, max_iters=50, eps=1e-6):
         """get_random_regions (oa_mix.py:122-184) without the H x W x 3 masks."""
         boxes, scores = [], []
-        target = np.random.randint(*num_bboxes) if isinstance(num_bboxes, tuple) else num_bboxes
+        target = rng.randint(*num_bboxes) if isinstance(num_bboxes, tuple) else num_bboxes
         for _ in range(max_iters):
             if len(boxes) >= target:
                 break
-            x1, y1 = np.random.randint(0, W), np.random.randint(0, H)
-            _scale = np.random.uniform(*scale) * H * W
-            _ratio = np.random.uniform(*ratio)
+            x1, y1 = rng.randint(0, W), rng.randint(0, H)
+            _scale = rng.uniform(*scale) * H * W
+            _ratio = rng.uniform(*ratio)
             bw, bh = int(np.sqrt(_scale / _ratio)), int(np.sqrt(_scale * _ratio))
             if x1 + bw > W or y1 + bh > H:
                 continue
@@ -249,7 +269,7 @@ class OAMix:
 
     def _aug(self, st, src, step):
         """aug (oa_mix.py:264-279): draw the op, draw its parameters, return the region-op descriptor."""
-        name = self.aug_list[np.random.choice(len(self.aug_list))]
+        name = self.aug_list[rng.choice(len(self.aug_list))]
         if self.trace is not None:
             self.trace.append(name)
         op = RegionOp()
@@ -263,8 +283,8 @@ class OAMix:
         elif name == 'solarize':
             op.kind, op.param = OP_SOLARIZE, 256 - int_parameter(sample_level(self.severity), 256)
         elif name == 'invert':
-            tx = 1 if np.random.random() > 0.5 else -1
-            ty = 1 if np.random.random() > 0.5 else -1
+            tx = 1 if rng.random() > 0.5 else -1
+            ty = 1 if rng.random() > 0.5 else -1
             op.kind = OP_WARP_NEG
             op.minv[:] = invert_affine(np.float32([[1, 0, tx], [0, 1, ty]]))
         elif name in ('color', 'contrast', 'brightness', 'sharpness'):
@@ -282,7 +302,7 @@ class OAMix:
         else:
             scope, kind = name.split('_only_')
             if kind.endswith('_xy'):
-                kind = kind[:-2] + ('x' if np.random.rand() < 0.5 else 'y')
+                kind = kind[:-2] + ('x' if rng.rand() < 0.5 else 'y')
             if scope == 'bg':
                 op.kind = OP_BG_WARP
                 op.minv[:] = invert_affine(geo_matrix(kind, self.severity, (W, H)))
@@ -322,13 +342,13 @@ class OAMix:
         L = _lib.lib()
         H, W = st.H, st.W
         b = self._buffers(st)
-        ws = np.float32(np.random.dirichlet([self.aug_prob_coeff] * self.mixture_width))
+        ws = np.float32(rng.dirichlet([self.aug_prob_coeff] * self.mixture_width))
         rboxes = self._random_regions(H, W, self.random_box_scale, self.random_box_ratio, (1, 3))
         self._history['random_box_list'] = np.stack(rboxes, axis=0)
         assert len(rboxes) <= 2
         rects = (ctypes.c_int * 8)(*[int(v) for bx in rboxes for v in bx], *([0] * (8 - 4 * len(rboxes))))
         for i in range(self.mixture_width):
-            depth = self.mixture_depth if self.mixture_depth > 0 else np.random.randint(1, 4)
+            depth = self.mixture_depth if self.mixture_depth > 0 else rng.randint(1, 4)
             cur = st.img
             for d in range(depth):
                 step = dict(n_tmp=0, luts_for=None)
@@ -356,11 +376,11 @@ class OAMix:
         for bx, sc in zip(rb, rs):
             targets.append((-1, tuple(int(v) for v in bx), sc))
         # object_aware_mixing (oa_mix.py:281-309)
-        m = np.random.beta(self.aug_prob_coeff, self.aug_prob_coeff)
+        m = rng.beta(self.aug_prob_coeff, self.aug_prob_coeff)
         tg = np.zeros((len(targets),), MIX_TARGET_DTYPE)
         for t, (idx, rect, score) in enumerate(targets):
             hi = 0.5 if score <= self.score_thresh else 1.0
-            tg[t] = (idx, rect, np.float32(np.random.uniform(0.0, hi)))
+            tg[t] = (idx, rect, np.float32(rng.uniform(0.0, hi)))
         tg_dev = _upload(tg.view(np.uint8).reshape(-1), st.img.device) if len(targets) else None
         mean = stdinv = None
         to_rgb, dt, Hp, Wp = 0, 0, H, W
