@@ -174,6 +174,16 @@ int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const
 int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int dil, int relu, int variant, void* stream);
+/* data-gradient form with the producer's epilogue backward fused in: y = (conv(x, w) [+ residual]) * (mask > 0)
+ * (mask [N,Ho,Wo,K] bf16 = the ReLU output the gradient flows into; torch threshold_backward) and
+ * colsum_part [oadg_conv2d_pixel_tiles][K] = per-pixel-tile column sums of the stored y = partial bias / BN-shift
+ * gradients of the producer (sum them with oadg_colsum_reduce).  mask / colsum_part may be NULL. */
+int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                             const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                             int dil, int relu, int variant, const void* mask, float* colsum_part, void* stream);
+long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                             int variant);
+int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream);
 /* the variant (1 or 2) variant 0 resolves to for a problem; 0 = shape not covered */
 int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);

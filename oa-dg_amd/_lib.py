@@ -39,6 +39,9 @@ SIGNATURES = {
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_conv2d_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 11 + [vp]),
     'oadg_conv2d_auto_variant': (ci, [ci] * 10),
+    'oadg_conv2d_nhwc_bf16_ex': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp, vp, vp]),
+    'oadg_conv2d_pixel_tiles': (cl, [ci] * 11),
+    'oadg_colsum_reduce': (ci, [vp, cl, ci, vp, vp]),
     'oadg_conv2d_nhwc_bf16_variant': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp]),
     'oadg_conv2d_wgrad_workspace_bytes': (cs, [ci] * 7),
     'oadg_conv2d_wgrad_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, cs] + [ci] * 10 + [vp]),

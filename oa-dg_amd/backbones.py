@@ -3,6 +3,7 @@ mmdet/models/utils/res_layer.py).  Frozen stem + stage 1, BN always in eval mode
 import torch.nn as nn
 from torch.nn.modules.batchnorm import _BatchNorm
 
+from . import hip_conv
 from .layers import Conv2d, build_norm_layer, constant_init, conv_bn, kaiming_init
 from .registry import BACKBONES
 
@@ -29,6 +30,21 @@ class Bottleneck(nn.Module):
         identity = x
         if self.downsample is not None:
             identity = conv_bn(x, self.downsample[0], self.downsample[1])
+        # GradTokens (hip_conv): the backward of each fused bias+ReLU epilogue - mask, bias gradient, and for the
+        # block input the identity-path gradient add - is folded into the data-gradient kernel of the tensor's only
+        # consumer.  t_in rides on x when the previous block produced it for this block alone.
+        t_in = getattr(x, '_oadg_token', None) if self.downsample is None else None
+        if hip_conv.tokens_ok(x, self.conv1, self.conv2, self.conv3) and not (self.bn1.training or self.bn2.training
+                                                                              or self.bn3.training):
+            t_a, t_b, t_out = hip_conv.GradToken(), hip_conv.GradToken(), hip_conv.GradToken()
+            if not x.requires_grad:
+                t_in = None
+            out = conv_bn(x, self.conv1, self.bn1, relu=True, in_token=t_in, out_token=t_a)
+            out = conv_bn(out, self.conv2, self.bn2, relu=True, in_token=t_a, out_token=t_b)
+            out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity, in_token=t_b, out_token=t_out,
+                          res_token=t_in)
+            out._oadg_token = t_out
+            return out
         out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)   # relu(bn3(conv3) + identity)
@@ -112,6 +128,8 @@ class ResNet(nn.Module):
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)
             if i in self.out_indices:
+                if hasattr(x, '_oadg_token'):
+                    x._oadg_token = None        # a stage output has other consumers (the neck): no hand-off
                 outs.append(x)
         return tuple(outs)
 

@@ -30,9 +30,42 @@ struct ConvArgs {
     const unsigned short* res;    // [N,Ho,Wo,K] bf16 residual or null
     unsigned short* y;            // [N,Ho,Wo,K] bf16
     const unsigned short* zeros;  // >= 16 bytes of zeros (source of padding / tail rows)
+    const unsigned short* mask;   // [N,Ho,Wo,K] bf16 or null: y *= (mask > 0)  (ReLU backward of the tensor y feeds)
+    float* colsum;                // [pixel tiles][K] fp32 partial column sums of the stored y, or null
     int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil, relu;
     long M;
 };
+
+// Last step of both epilogues for one 16-byte piece (8 channels of a pixel): residual add, ReLU, ReLU-backward
+// mask, bf16 rounding, and the running column sums of what is stored.
+__device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, size_t off, float* csum) {
+    if (a.res || a.mask) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((unsigned short)v[e]);
+        if (a.res) {
+            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f[e] += bf16_to_f32((unsigned short)rv[e]);
+                if (a.relu) f[e] = fmaxf(f[e], 0.f);
+            }
+        }
+        if (a.mask) {
+            const bf16x8 mv = *reinterpret_cast<const bf16x8*>(a.mask + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!(bf16_to_f32((unsigned short)mv[e]) > 0.f)) f[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16(f[e]);
+    }
+    if (a.colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[e] += bf16_to_f32((unsigned short)v[e]);
+    }
+    return v;
+}
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -175,24 +208,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         }
     }
     __syncthreads();
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < (BM * BN / 8) / 256; ++it) {
         const int q = it * 256 + tid;
-        const int row = q >> 4, sg = q & 15;
+        const int row = q >> 4, sg = q & 15;           // sg = tid & 15 for every piece of this thread
         const long m = m0 + row;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * BN + sg * 8);
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        if (a.res) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, off, csum);
+    }
+    if (a.colsum) {       // 16 threads share a channel slot: combine through the idle second LDS stage
+        float* red = reinterpret_cast<float*>(smem + STAGE_BYTES);      // [16][128]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf16_to_f32((unsigned short)v[e]) + bf16_to_f32((unsigned short)rv[e]);
-                if (a.relu) f = fmaxf(f, 0.f);
-                v[e] = (short)f32_to_bf16(f);
-            }
+        for (int e = 0; e < 8; ++e) red[(tid >> 4) * BN + (tid & 15) * 8 + e] = csum[e];
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * BN + tid];
+            a.colsum[(size_t)mt * a.K + k0 + tid] = t;
         }
-        *reinterpret_cast<bf16x8*>(a.y + off) = v;
     }
 }
 
@@ -442,24 +479,28 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
             }
     }
     __syncthreads();
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int it = 0; it < (TM * TN / 8) / 512; ++it) {
         const int q = it * 512 + tid;
-        const int p = q >> 5, sg = q & 31;
+        const int p = q >> 5, sg = q & 31;             // sg = tid & 31 for every piece of this thread
         const long m = m0 + p;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        if (a.res) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, off, csum);
+    }
+    if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
+        float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float f = bf16_to_f32((unsigned short)v[e]) + bf16_to_f32((unsigned short)rv[e]);
-                if (a.relu) f = fmaxf(f, 0.f);
-                v[e] = (short)f32_to_bf16(f);
-            }
+        for (int e = 0; e < 8; ++e) red[(tid >> 5) * TN + (tid & 31) * 8 + e] = csum[e];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * TN + tid];
+            a.colsum[(size_t)mt * a.K + k0 + tid] = t;
         }
-        *reinterpret_cast<bf16x8*>(a.y + off) = v;
     }
 }
 
@@ -475,7 +516,7 @@ int auto_variant(long M, int H, int W, int C, int K) {
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
-                void* stream) {
+                void* stream, const void* mask = nullptr, float* colsum_part = nullptr) {
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % BN != 0) return OADG_EARG;   // other shapes stay on the library path
@@ -483,6 +524,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
+    a.mask = (const unsigned short*)mask; a.colsum = colsum_part;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
     a.relu = relu;
     a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
@@ -495,14 +537,14 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)conv_igemm256_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
         const long m_tiles = (a.M + TM - 1) / TM;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / TN);
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        hipLaunchKernelGGL(conv_igemm256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES,
+        hipLaunchKernelGGL(conv_igemm256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
                            (hipStream_t)stream, a);
     } else {
         const long m_tiles = (a.M + BM - 1) / BM;
@@ -529,6 +571,27 @@ extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R
     const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return 0;
     return auto_variant((long)N * Ho * Wo, H, W, C, K);
+}
+
+// Data-gradient form with the backward of the producer's epilogue fused in:  y = (conv(x, w) [+ residual]) * (mask > 0)
+// and colsum_part[tile][k] = per-pixel-tile column sums of the stored y (reduce with oadg_colsum_reduce; rows =
+// oadg_conv2d_pixel_tiles).  mask / colsum_part may be NULL.
+extern "C" int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual,
+                                        void* y, const void* zeros16, int N, int H, int W, int C, int K, int R, int S,
+                                        int stride, int pad, int dil, int relu, int variant, const void* mask,
+                                        float* colsum_part, void* stream) {
+    return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, variant, stream,
+                       mask, colsum_part);
+}
+
+// rows of the colsum_part buffer for a problem / variant (0 = automatic)
+extern "C" long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                                        int variant) {
+    if (variant == 0) variant = oadg_conv2d_auto_variant(N, H, W, C, K, R, S, stride, pad, dil);
+    if (variant == 0) return 0;
+    const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    const long M = (long)N * Ho * Wo;
+    return variant == 2 ? (M + TM - 1) / TM : (M + BM - 1) / BM;
 }
 
 // same, with the kernel variant chosen by the caller: 0 = automatic, 1 = 128 x 128 tile, 2 = 256 x 256 tile

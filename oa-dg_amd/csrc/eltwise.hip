@@ -279,3 +279,12 @@ extern "C" int oadg_fpn_topdown_bwd(const void* g, void* dtop, int N, int H, int
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
+
+// out[k] = sum_r part[r][k] in a fixed order (deterministic): the second stage of every column-sum producer
+extern "C" int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream) {
+    if (!part || !out || rows < 1 || K < 1 || rows > 0x7fffffffL) return OADG_EARG;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((K + 15) / 16), dim3(256), 0, (hipStream_t)stream, part, out, (int)rows,
+                       K);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}

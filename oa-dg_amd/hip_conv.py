@@ -32,8 +32,10 @@ def supported(x, weight, stride, padding, dilation):
             padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
 
 
-def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0):
-    """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last."""
+def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False):
+    """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last.
+    ``mask`` (same shape as y): y *= (mask > 0); ``want_colsum``: also return sum of the stored y over (N,H,W)
+    (fp32 [K], deterministic) - the two together are the backward of a producer's bias + ReLU epilogue."""
     L = _lib.lib()
     N, C, H, W = x.shape
     K, _, R, S = w.shape
@@ -43,9 +45,13 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0):
     if TIMERS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(L.oadg_conv2d_nhwc_bf16_variant(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N,
-                                          H, W, C, K, R, S, stride, pad, dil, int(bool(relu)), int(variant),
-                                          stream_ptr()),
+    part = None
+    if want_colsum:
+        rows = L.oadg_conv2d_pixel_tiles(N, H, W, C, K, R, S, stride, pad, dil, int(variant))
+        part = torch.empty((rows, K), dtype=torch.float32, device=x.device)
+    check(L.oadg_conv2d_nhwc_bf16_ex(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N,
+                                     H, W, C, K, R, S, stride, pad, dil, int(bool(relu)), int(variant), ptr(mask),
+                                     ptr(part), stream_ptr()),
           'oadg_conv2d_nhwc_bf16')
     if TIMERS is not None:
         e1.record()
@@ -53,6 +59,10 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0):
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
                        2.0 * (N * H * W * C + K * C * R * S + N * Ho * Wo * K * (2 if residual is not None else 1)),
                        'conv_igemm256_kernel' if v == 2 else 'conv_igemm_kernel'))
+    if want_colsum:
+        cs = torch.empty((K,), dtype=torch.float32, device=x.device)
+        check(L.oadg_colsum_reduce(ptr(part), part.shape[0], K, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
+        return y, cs
     return y
 
 
@@ -178,28 +188,48 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
     return out
 
 
+class GradToken:
+    """Hand-off between the backward passes of two convolutions around one post-ReLU tensor t = relu(P(...)) whose
+    ONLY consumers are a convolution C (and, optionally, the identity path of the block C opens):
+    C's data-gradient kernel adds the identity-path gradient (``extra``, deposited by the block's last conv), applies
+    the ReLU mask (t > 0) and reduces the bias gradient in its epilogue, so P neither masks nor reduces again.
+    ``grad_ptr`` identifies the tensor C returned: if autograd delivers anything else to P (an unexpected extra
+    consumer), P falls back to masking itself - masking twice is harmless, skipping it would not be."""
+    __slots__ = ('extra', 'colsum', 'grad_ptr')
+
+    def __init__(self):
+        self.extra = self.colsum = self.grad_ptr = None
+
+
 class _Conv2dMFMA(torch.autograd.Function):
-    """y = [relu]( conv(x, wf) + bias [+ residual] ) in one kernel, on prepared bf16 weights; backward = ReLU mask
-    (one element-wise pass), stride-1 data gradient on the same kernel with ``wt``, weight/bias gradients through
-    aten (MIOpen) unless USE_HIP_WGRAD."""
+    """y = [relu]( conv(x, wf) + bias [+ residual] ) in one kernel, on prepared bf16 weights.  Backward: ReLU mask +
+    bias gradient in one pass (or taken over by the consumer through ``out_token``), stride-1 data gradient on the
+    same kernel with ``wt`` (+ the producer's mask / bias gradient / identity gradient through ``in_token``),
+    weight gradient by csrc conv_wgrad256_kernel where it beats MIOpen, else aten (MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu):
+    def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu, in_token, out_token, res_token):
         x16 = _nhwc_bf16(x)
         r16 = _nhwc_bf16(residual) if residual is not None else None
         y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu)
         ctx.save_for_backward(x16, wf, wt, y if relu else None)
         ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, residual.dtype if residual is not None else None)
+        ctx.tokens = (in_token, out_token, res_token)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x16, wf, wt, y = ctx.saved_tensors
         stride, pad, dil, has_bias, xdt, rdt = ctx.cfg
+        in_token, out_token, res_token = ctx.tokens
         K, C, R, S = wf.shape
         want_b = has_bias and ctx.needs_input_grad[2]
         gb = None
-        if (y is not None or want_b) and gy.dtype in (torch.bfloat16, torch.float32) and K % 8 == 0 and \
+        if out_token is not None and out_token.grad_ptr is not None and out_token.grad_ptr == gy.data_ptr() and \
+                gy.dtype == torch.bfloat16 and gy.is_contiguous(memory_format=torch.channels_last):
+            gb = out_token.colsum if want_b else None     # masked and reduced by the consumer's dgrad epilogue
+            want_b = False
+        elif (y is not None or want_b) and gy.dtype in (torch.bfloat16, torch.float32) and K % 8 == 0 and \
                 gy.is_contiguous(memory_format=torch.channels_last):
             gy, gb = relu_bias_bwd(gy, y, want_b)            # mask + cast + bias gradient: one pass over dy
             want_b = False
@@ -207,10 +237,22 @@ class _Conv2dMFMA(torch.autograd.Function):
             gy = _nhwc_bf16(gy)
             if y is not None:
                 gy = torch.ops.aten.threshold_backward(gy, y, 0)
+        if out_token is not None:
+            out_token.grad_ptr = out_token.colsum = None
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gx = None
+        extra = None
+        if in_token is not None:
+            extra, in_token.extra = in_token.extra, None
         if need_x and wt is not None:
-            gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)   # dx = conv(dy, rot180(W)^T)
+            # dx = conv(dy, rot180(W)^T) [+ identity gradient] [* (x > 0), column sums -> producer's bias gradient]
+            if in_token is not None:
+                gx, in_token.colsum = conv_forward(gy, wt, None, extra, 1, dil * (R - 1) - pad, dil, False,
+                                                   mask=x16, want_colsum=True)
+                in_token.grad_ptr = gx.data_ptr()
+                extra = None
+            else:
+                gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)
             need_x = False
         gw = None
         if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
@@ -229,8 +271,15 @@ class _Conv2dMFMA(torch.autograd.Function):
                 gw = outs[1]
             if outs[2] is not None:
                 gb = outs[2].float()
-        gres = gy.to(rdt) if (rdt is not None and ctx.needs_input_grad[3]) else None
-        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None
+        if gx is not None and extra is not None:      # library data gradient: the identity gradient is added here
+            gx = gx + extra.to(gx.dtype)
+        gres = None
+        if rdt is not None and ctx.needs_input_grad[3]:
+            if res_token is not None:
+                res_token.extra = gy                  # folded into the block's first conv's data gradient
+            else:
+                gres = gy.to(rdt)
+        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None, None, None, None
 
 
 def _norm3(stride, padding, dilation):
@@ -243,26 +292,48 @@ def _applies(x, weight, stride, padding, dilation):
         (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())     # fp32 parity runs keep fp32 arithmetic
 
 
-def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None, owner=None):
+def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None, owner=None, in_token=None,
+           out_token=None, res_token=None):
     """layers.conv2d implementation hook: returns None for shapes the kernel does not cover."""
     stride, padding, dilation = _norm3(stride, padding, dilation)
     if not _applies(x, weight, stride, padding, dilation):
         return None
     K, C, R, S = weight.shape
     wf, b, wt = prepared(weight, None, bias, _wt_useful(x, K, C, stride[0], padding[0], dilation[0], R), owner)
-    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu))
+    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu), in_token,
+                             out_token, res_token)
 
 
-def conv_bn(x, conv, bn, relu=False, residual=None):
+def conv_bn(x, conv, bn, relu=False, residual=None, in_token=None, out_token=None, res_token=None):
     """layers.conv_bn implementation hook (eval-mode BN folded by the preparation kernel)."""
     stride, padding, dilation = _norm3(conv.stride, conv.padding, conv.dilation)
     if bn.training or conv.bias is not None or not _applies(x, conv.weight, stride, padding, dilation):
         return None
     K, C, R, S = conv.weight.shape
     wf, b, wt = prepared(conv.weight, bn, None, _wt_useful(x, K, C, stride[0], padding[0], dilation[0], R), conv)
-    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu))
+    return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu), in_token,
+                             out_token, res_token)
+
+
+ENABLED = False
+
+
+def tokens_ok(x, *convs):
+    """may GradTokens be threaded through these convolutions of input x?  (all of them on the MFMA path, bf16/autocast,
+    eval-mode BN folded, gradients flowing)"""
+    if not (ENABLED and x.is_cuda and torch.is_grad_enabled()):
+        return False
+    for c in convs:
+        st, pd, dl = _norm3(c.stride, c.padding, c.dilation)
+        K, C, R, S = c.weight.shape
+        if c.bias is not None or C % 64 or K % 128 or st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1] or \
+                c.weight.shape[2] != c.weight.shape[3] or not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
+            return False
+    return True
 
 
 def enable(on=True):
+    global ENABLED
+    ENABLED = bool(on)
     from . import layers
     layers.set_conv_impl(conv2d if on else None, conv_bn if on else None)

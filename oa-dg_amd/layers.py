@@ -45,16 +45,17 @@ class Conv2d(nn.Conv2d):
 FOLD_EVAL_BN = True
 
 
-def conv_bn(x, conv, bn, relu=False, residual=None):
+def conv_bn(x, conv, bn, relu=False, residual=None, **tokens):
     """[relu]( bn(conv(x)) [+ residual] ) for a BatchNorm in eval mode, folded into the convolution; falls back
-    to the module-by-module form otherwise."""
+    to the module-by-module form otherwise.  ``tokens`` (in_token / out_token / res_token, hip_conv.GradToken) only
+    reach the MFMA implementation; callers create them after hip_conv.tokens_ok()."""
     if not FOLD_EVAL_BN or bn.training or conv.bias is not None:
         y = bn(conv(x))
         if residual is not None:
             y = y + residual
         return F.relu(y, inplace=True) if relu else y
     if _CONV_BN_IMPL is not None and x.is_cuda:
-        y = _CONV_BN_IMPL(x, conv, bn, relu, residual)
+        y = _CONV_BN_IMPL(x, conv, bn, relu, residual, **tokens)
         if y is not None:
             return y
     frozen = not (conv.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad)

@@ -232,3 +232,65 @@ def test_fpn_topdown_matches_torch(dev, N, C, H, W, Ht, Wt):
     assert torch.equal(out, ref.bfloat16())
     assert torch.equal(lat.grad, g)
     assert torch.equal(top.grad, tf.grad.bfloat16())
+
+
+def test_grad_tokens_fold_relu_and_identity_backward(dev, monkeypatch):
+    """Three bottlenecks with GradTokens (mask / bias gradient / identity add inside the data-gradient epilogues)
+    against the same blocks with every epilogue backward as a standalone pass: same gradients up to one bf16
+    rounding per tensor, and the dgrad-epilogue options against torch directly."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import make_res_layer
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(0)
+        layer = make_res_layer(512, 128, 3, 1, 1, 'pytorch', dict(type='BN', requires_grad=True)).to(dev)
+        layer.eval()                       # norm_eval: frozen statistics, trainable affine
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+                torch.nn.init.normal_(m.bias, 0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.2)
+        g = torch.Generator(device=dev).manual_seed(1)
+        x0 = torch.randn(2, 512, 24, 40, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(2, 512, 24, 40, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        res = {}
+        for mode in ('tokens', 'plain'):
+            if mode == 'plain':
+                monkeypatch.setattr(hip_conv, 'tokens_ok', lambda *a, **k: False)
+            layer.zero_grad(set_to_none=True)
+            x = torch.relu(x0).clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = layer(x)
+            y.backward(gy)
+            res[mode] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in layer.named_parameters()})
+        assert torch.equal(res['tokens'][0], res['plain'][0])
+        def close(a, b, what):
+            d = (a - b).abs()
+            assert d.max().item() <= 3e-2 * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
+            assert d.mean().item() <= 5e-3 * b.abs().mean().item() + 1e-7, (what, d.mean().item(), b.abs().mean().item())
+        close(res['tokens'][1], res['plain'][1], 'x.grad')
+        for n in res['plain'][2]:
+            close(res['tokens'][2][n], res['plain'][2][n], n)
+    finally:
+        hip_conv.enable(False)
+
+
+def test_conv_dgrad_epilogue_mask_and_colsum(dev):
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(2)
+    for variant, (N, C, H, W, K) in ((1, (2, 128, 20, 28, 128)), (2, (2, 128, 40, 56, 256)), (2, (1, 64, 19, 23, 512))):
+        x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(K, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5).bfloat16().contiguous(
+            memory_format=torch.channels_last)
+        res = torch.randn(N, K, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        mask = torch.relu(torch.randn(N, K, H, W, device=dev, generator=g)).bfloat16().contiguous(
+            memory_format=torch.channels_last)
+        y, cs = hip_conv.conv_forward(x, w, None, res, 1, 1, 1, False, variant=variant, mask=mask, want_colsum=True)
+        plain = hip_conv.conv_forward(x, w, None, None, 1, 1, 1, False, variant=variant)
+        ref = ((plain.float() + res.float()) * (mask > 0)).bfloat16()
+        assert torch.equal(y, ref)
+        rs = ref.double().sum((0, 2, 3))
+        assert (cs.double() - rs).abs().max().item() <= 1e-5 * ref.double().abs().sum((0, 2, 3)).max().item()
+        y2, cs2 = hip_conv.conv_forward(x, w, None, res, 1, 1, 1, False, variant=variant, mask=mask, want_colsum=True)
+        assert torch.equal(cs, cs2) and torch.equal(y, y2)
