@@ -57,7 +57,8 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         e1.record()
         v = variant or L.oadg_conv2d_auto_variant(N, H, W, C, K, R, S, stride, pad, dil)
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
-                       2.0 * (N * H * W * C + K * C * R * S + N * Ho * Wo * K * (2 if residual is not None else 1)),
+                       2.0 * (N * H * W * C + K * C * R * S +
+                              N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None))),
                        'conv_igemm256_kernel' if v == 2 else 'conv_igemm_kernel'))
     if want_colsum:
         cs = torch.empty((K,), dtype=torch.float32, device=x.device)
