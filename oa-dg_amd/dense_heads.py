@@ -287,6 +287,27 @@ class AnchorHead(nn.Module):
         return losses, proposal_list
 
 
+class _SplitHeads(torch.autograd.Function):
+    """(y[:, :a], y[:, a:a+b]) of a channel-padded NHWC map; the backward writes the two gradients into one zeroed
+    padded map (3 launches instead of autograd's two zero-fills, two copies and an add)."""
+
+    @staticmethod
+    def forward(ctx, y, a, b):
+        ctx.meta = (tuple(y.shape), y.dtype, a, b)
+        return y[:, :a], y[:, a:a + b]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        shape, dt, a, b = ctx.meta
+        g = torch.empty(shape, dtype=dt, device=(ga if ga is not None else gb).device,
+                        memory_format=torch.channels_last).zero_()
+        if ga is not None:
+            g[:, :a].copy_(ga)
+        if gb is not None:
+            g[:, a:a + b].copy_(gb)
+        return g, None, None
+
+
 @HEADS.register_module()
 class RPNHead(AnchorHead):
     """rpn_head.py:17-235."""
@@ -309,6 +330,24 @@ class RPNHead(AnchorHead):
 
     def forward_single(self, x):
         c = self.rpn_conv
+        from . import hip_conv
+        n_cls, n_reg = self.rpn_cls.out_channels, self.rpn_reg.out_channels
+        if hip_conv.ENABLED and x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) and \
+                n_cls + n_reg <= 128 and self.feat_channels % 64 == 0 and torch.is_grad_enabled():
+            # rpn_cls and rpn_reg (3 + 12 output channels, rpn_head.py:56-59) as ONE 1x1 convolution on the MFMA
+            # kernel, output channels zero-padded to its 128-channel tile: one pass over the 256-channel feature map
+            # instead of two library convolutions forward and four backward, and - through the GradToken - the ReLU
+            # mask and the bias gradient of rpn_conv come out of that convolution's data-gradient epilogue.
+            tok = hip_conv.GradToken()
+            x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok)
+            if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
+                pad = 128 - n_cls - n_reg
+                w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight,
+                               self.rpn_cls.weight.new_zeros((pad,) + tuple(self.rpn_cls.weight.shape[1:]))])
+                b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, self.rpn_cls.bias.new_zeros(pad)])
+                y = conv2d(x, w, b, 1, 0, 1, in_token=tok)
+                return _SplitHeads.apply(y, n_cls, n_reg)
+            return self.rpn_cls(x), self.rpn_reg(x)
         x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True)   # relu(rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)
 

@@ -17,10 +17,11 @@ def set_conv_impl(fn, fn_bn=None):
     _CONV_IMPL, _CONV_BN_IMPL = fn, fn_bn
 
 
-def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None):
-    """[relu]( conv2d(x, weight, bias) [+ residual] ): fused in the MFMA kernel's epilogue when it applies."""
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, residual=None, **tokens):
+    """[relu]( conv2d(x, weight, bias) [+ residual] ): fused in the MFMA kernel's epilogue when it applies.
+    ``tokens``: hip_conv.GradToken hand-offs, only seen by the MFMA implementation."""
     if _CONV_IMPL is not None and x.is_cuda:
-        y = _CONV_IMPL(x, weight, bias, stride, padding, dilation, relu, residual)
+        y = _CONV_IMPL(x, weight, bias, stride, padding, dilation, relu, residual, **tokens)
         if y is not None:
             return y
     y = F.conv2d(x, weight, bias, stride, padding, dilation)
