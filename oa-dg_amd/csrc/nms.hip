@@ -10,8 +10,9 @@
 //
 // Two kernels, no host round trip (mmcv copies the bit matrix to the host for the greedy scan):
 //   1. nms_mask_kernel : 64x64 tiles of the upper triangle -> one 64-bit suppression word per (row, tile)
-//   2. nms_scan_kernel : one wave per image walks the rows in order; the `removed` bit set lives in
-//      registers (lane l owns words l, l+64, ...), the current word is tracked in an SGPR-uniform value.
+//   2. nms_scan_kernel : one wave per image walks the rows in order, 64 at a time; the `removed` bit set lives in
+//      registers (lane l owns words l, l+64, ...), the within-chunk dependency chain runs on v_readlane of the
+//      chunk's diagonal block, the off-diagonal updates are independent loads.
 #include "common.h"
 
 namespace {
@@ -76,17 +77,44 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
         const unsigned hi = __shfl((unsigned)(mine >> 32), cw & 63, 64);
         unsigned long long cur = ((unsigned long long)hi << 32) | lo;
         const int nb = min(64, M - cw * 64);
-        for (int bit = 0; bit < nb && nkeep < max_keep; ++bit) {
+        // The serial part of the greedy scan stays inside the chunk and inside registers: lane l holds the diagonal
+        // word of row cw*64 + l (which boxes of this chunk row l suppresses); walking the 64 bits needs one
+        // v_readlane pair per kept box instead of a dependent global load.
+        const int myrow = cw * 64 + lane;
+        const unsigned long long diag = lane < nb ? mk[(size_t)myrow * words + cw] : 0ull;
+        unsigned long long kept = 0ull;
+        int nk = nkeep;
+        for (int bit = 0; bit < nb && nk < max_keep; ++bit) {
             if ((cur >> bit) & 1ull) continue;
-            const int i = cw * 64 + bit;
-            if (lane == 0) out[nkeep] = i;
-            ++nkeep;
-            const unsigned long long* row = mk + (size_t)i * words;
-            cur |= row[cw];  // wave-uniform address: rows only hold words >= own chunk
+            kept |= 1ull << bit;
+            ++nk;
+            const unsigned dlo = __builtin_amdgcn_readlane((int)(unsigned)diag, bit);
+            const unsigned dhi = __builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), bit);
+            cur |= ((unsigned long long)dhi << 32) | dlo;
+        }
+        if ((kept >> lane) & 1ull) out[nkeep + __popcll(kept & ((1ull << lane) - 1ull))] = myrow;
+        nkeep = nk;
+        // the kept rows' words right of the diagonal: independent loads, no serial dependency
+        // (8 rows per round so that the loads of a round are in flight together)
+        unsigned long long todo = kept;
+        while (todo) {
+            int bits[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                bits[u] = todo ? __ffsll((long long)todo) - 1 : -1;
+                todo &= todo - 1ull;
+            }
 #pragma unroll
             for (int s = 0; s < MAX_WORDS_PER_LANE; ++s) {
                 const int w = lane + 64 * s;
-                if (w > cw && w < nchunks) removed[s] |= row[w];
+                if (w > cw && w < nchunks) {
+                    unsigned long long v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        v[u] = bits[u] >= 0 ? mk[(size_t)(cw * 64 + bits[u]) * words + w] : 0ull;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) removed[s] |= v[u];
+                }
             }
         }
     }
