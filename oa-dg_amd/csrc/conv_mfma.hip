@@ -74,16 +74,21 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
+// TBN = 128: 4 waves as 2 x 2, 64 x 64 outputs per wave.  TBN = 64 (layers with K % 128 != 0, e.g. the 64-channel
+// convolutions of ResNet's first stage): 4 waves as 4 x 1, 32 x 64 outputs per wave.
+template <int TBN>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WN = TBN / 64, WM = 4 / WN, AF = BM / WM / 32, NBP = TBN * 8 / 256;
+    constexpr int TSTAGE = (BM + TBN) * BK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     // block -> (m tile, n tile): the K/BN column blocks of one pixel tile are adjacent (shared A through L2)
     // Workgroup b is dispatched to XCD b % 8 (observed; used for speed only).  Each XCD gets a CONTIGUOUS range
     // of pixel tiles (and all K/BN column tiles of a pixel tile back to back), so the halo rows that neighbouring
     // tiles of a 3x3 convolution share, and the A rows the column tiles share, are served by that XCD's L2
     // instead of being fetched through the fabric once per XCD.
-    const int n_tiles = a.K / BN;
+    const int n_tiles = a.K / TBN;
     const long m_tiles = (a.M + BM - 1) / BM;
     const long bid = blockIdx.x;
     long mt;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (j / n_tiles >= per || mt >= m_tiles) return;     // padding of the last XCD range
     }
     const long m0 = mt * BM;
-    const int k0 = nt * BN;
+    const int k0 = nt * TBN;
 
     // ---- loader geometry: piece q = i*256 + tid -> row = q >> 3 (0..127), slot = q & 7
     const int cpc = a.C / BK;                 // 64-channel chunks per filter tap
@@ -123,13 +128,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             a_base[i] = nullptr;
             a_hi0[i] = a_wi0[i] = 0;
         }
-        b_base[i] = a.w + (size_t)(k0 + row) * a.R * a.S * a.C;
+        b_base[i] = a.w + (size_t)(k0 + (row < TBN ? row : 0)) * a.R * a.S * a.C;
     }
 
     auto stage = [&](int kc, int buf) {
         const int rs = kc / cpc, c0 = (kc - rs * cpc) * BK;
         const int r = rs / a.S, s = rs - r * a.S;
-        unsigned char* sa = smem + buf * STAGE_BYTES;
+        unsigned char* sa = smem + buf * TSTAGE;
         unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -139,15 +144,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             glds16(src, sa + i * 4096 + wave * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NBP; ++i) {
             const unsigned short* src = b_base[i] + (size_t)rs * a.C + c0 + seg[i] * 8;
             glds16(src, sb + i * 4096 + wave * 1024);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[AF][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < AF; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -161,15 +166,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     for (int kc = 0; kc < nchunks; ++kc) {
         const int cur = kc & 1;
         if (kc + 1 < nchunks) stage(kc + 1, cur ^ 1);
-        const unsigned char* sa = smem + cur * STAGE_BYTES;
+        const unsigned char* sa = smem + cur * TSTAGE;
         const unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int sg = kk * 2 + lh;
-            bf16x8 fa[2], fb[2];
+            bf16x8 fa[AF], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = wm * 64 + i * 32 + l31;
+            for (int i = 0; i < AF; ++i) {
+                const int row = wm * (AF * 32) + i * 32 + l31;
                 fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
                 fb[j] = *reinterpret_cast<const bf16x8*>(sb + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < AF; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
@@ -191,43 +196,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // each 32x32 sub-tile.  bias is added in fp32, the tile is staged as bf16 [128 pixels][128 channels] in the
     // (now idle) LDS stages, then written with 16-byte stores: 16 lanes cover the 256 contiguous bytes of one
     // pixel's channels.  Residual add and ReLU happen on the way out (fp32).
-    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);      // 32 KiB
+    unsigned short* tile = reinterpret_cast<unsigned short*>(smem);      // [128][TBN] bf16 <= 32 KiB
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = wn * 64 + j * 32 + l31;
         const float bv = a.bias ? a.bias[k0 + col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AF; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = wm * (AF * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 float v = acc[i][j][r] + bv;
                 if (a.relu && !a.res) v = fmaxf(v, 0.f);
-                tile[row * BN + col] = f32_to_bf16(v);
+                tile[row * TBN + col] = f32_to_bf16(v);
             }
         }
     }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int SPR = TBN / 8;                       // 16-byte slots per tile row
 #pragma unroll
-    for (int it = 0; it < (BM * BN / 8) / 256; ++it) {
+    for (int it = 0; it < (BM * TBN / 8) / 256; ++it) {
         const int q = it * 256 + tid;
-        const int row = q >> 4, sg = q & 15;           // sg = tid & 15 for every piece of this thread
+        const int row = q / SPR, sg = q % SPR;         // sg = tid % SPR for every piece of this thread
         const long m = m0 + row;
         if (m >= a.M) continue;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * BN + sg * 8);
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
         *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, off, csum);
     }
-    if (a.colsum) {       // 16 threads share a channel slot: combine through the idle second LDS stage
-        float* red = reinterpret_cast<float*>(smem + STAGE_BYTES);      // [16][128]
+    if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
+        float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid >> 4) * BN + (tid & 15) * 8 + e] = csum[e];
+        for (int e = 0; e < 8; ++e) red[(tid / SPR) * TBN + (tid % SPR) * 8 + e] = csum[e];
         __syncthreads();
-        if (tid < BN) {
+        if (tid < TBN) {
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) t += red[g * BN + tid];
+            for (int g = 0; g < 256 / SPR; ++g) t += red[g * TBN + tid];
             a.colsum[(size_t)mt * a.K + k0 + tid] = t;
         }
     }
@@ -519,7 +525,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
                 void* stream, const void* mask = nullptr, float* colsum_part = nullptr) {
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
-    if (C % BK != 0 || K % BN != 0) return OADG_EARG;   // other shapes stay on the library path
+    if (C % BK != 0 || K % 64 != 0) return OADG_EARG;   // other shapes stay on the library path
     if (variant < 0 || variant > 2 || (variant == 2 && K % TN != 0)) return OADG_EARG;
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
@@ -548,10 +554,15 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
                            (hipStream_t)stream, a);
     } else {
         const long m_tiles = (a.M + BM - 1) / BM;
-        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / BN);      // 8 equal XCD ranges (the kernel drops the padding)
+        const int tbn = K % BN == 0 ? BN : 64;
+        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / tbn);     // 8 equal XCD ranges (the kernel drops the padding)
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream,
-                           a);
+        if (tbn == BN)
+            hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
+                               (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
+                               (hipStream_t)stream, a);
     }
     OADG_LAUNCH_CHECK();
     return OADG_OK;
@@ -567,7 +578,7 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
 // which kernel the automatic choice takes for a problem (1 or 2; 0 for unsupported shapes) - for profiling
 extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return 0;
-    if (C % BK != 0 || K % BN != 0) return 0;
+    if (C % BK != 0 || K % 64 != 0) return 0;
     const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return 0;
     return auto_variant((long)N * Ho * Wo, H, W, C, K);

@@ -28,7 +28,7 @@ def _zeros(device):
 
 def supported(x, weight, stride, padding, dilation):
     K, C, R, S = weight.shape
-    return (x.is_cuda and x.dim() == 4 and C % 64 == 0 and K % 128 == 0 and stride[0] == stride[1] and
+    return (x.is_cuda and x.dim() == 4 and C % 64 == 0 and K % 64 == 0 and stride[0] == stride[1] and
             padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
 
 
@@ -161,7 +161,7 @@ class _PrepWeights(torch.autograd.Function):
 
 
 def _wt_useful(x, K, C, stride, pad, dil, R):
-    return bool(x.requires_grad and stride == 1 and dil * (R - 1) - pad >= 0 and K % 64 == 0 and C % 128 == 0)
+    return bool(x.requires_grad and stride == 1 and dil * (R - 1) - pad >= 0 and K % 64 == 0 and C % 64 == 0)
 
 
 def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
@@ -327,7 +327,7 @@ def tokens_ok(x, *convs):
     for c in convs:
         st, pd, dl = _norm3(c.stride, c.padding, c.dilation)
         K, C, R, S = c.weight.shape
-        if c.bias is not None or C % 64 or K % 128 or st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1] or \
+        if c.bias is not None or C % 64 or K % 64 or st[0] != st[1] or pd[0] != pd[1] or dl[0] != dl[1] or \
                 c.weight.shape[2] != c.weight.shape[3] or not (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
             return False
     return True

@@ -23,6 +23,9 @@ def _ref(x, w, b, stride, pad, dil, res=None, relu=False):
     (1, 128, 33, 31, 128, 3, 2, 1, 1),      # stride-2 3x3
     (1, 512, 16, 16, 512, 3, 1, 2, 2),      # dilated (DC5)
     (1, 256, 14, 18, 1024, 1, 2, 0, 1),     # stride-2 1x1 downsample
+    (2, 64, 20, 28, 64, 3, 1, 1, 1),        # 64 output channels: the 128 x 64 tile (ResNet stage 1)
+    (1, 256, 17, 23, 64, 1, 1, 0, 1),
+    (1, 64, 19, 21, 192, 1, 1, 0, 1),       # K = 3 x 64
 ])
 def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
     from oadg_amd import hip_conv
@@ -38,7 +41,7 @@ def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad,
     assert err <= 8e-3 * ref.abs().max().item(), err
     # asymmetric check against transposes: a single non-zero weight tap / channel
     w2 = torch.zeros_like(w)
-    w2[3, 5, R - 1, 0] = 1.0
+    w2[K - 3, 5, R - 1, 0] = 1.0
     y2 = hip_conv.conv_forward(x, w2, None, None, stride, pad, dil, False)
     assert torch.equal(y2.float(), _ref(x, w2, None, stride, pad, dil).bfloat16().float())
 
@@ -279,7 +282,8 @@ def test_grad_tokens_fold_relu_and_identity_backward(dev, monkeypatch):
 def test_conv_dgrad_epilogue_mask_and_colsum(dev):
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(2)
-    for variant, (N, C, H, W, K) in ((1, (2, 128, 20, 28, 128)), (2, (2, 128, 40, 56, 256)), (2, (1, 64, 19, 23, 512))):
+    for variant, (N, C, H, W, K) in ((1, (2, 128, 20, 28, 128)), (2, (2, 128, 40, 56, 256)), (2, (1, 64, 19, 23, 512)),
+                                      (1, (2, 128, 21, 27, 64))):
         x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(K, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5).bfloat16().contiguous(
             memory_format=torch.channels_last)
