@@ -528,8 +528,9 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     gw = gt[..., 2] - gt[..., 0]
     gh = gt[..., 3] - gt[..., 1]
     # fork guard against zero-size proposals (:152-160), written without boolean indexing (which reads the
-    # mask count back to the host).  The reference's last line is ``gy[nan_x] = py[nan_y]``: with equal masks
-    # (the only case in which that statement is well-formed and meaningful) it is the line below.
+    # mask count back to the host).  Its last line is ``gy[nan_x] = py[nan_y]``: a POSITIONAL pairing - the k-th
+    # zero-width row receives py of the k-th zero-height row (the reference raises when the two counts differ; here
+    # the surplus rows read the next rows in order).  Reproduced through ranks instead of compaction.
     nan_x, nan_y = (pw == 0), (ph == 0)
     tiny = pw.new_full((), 1e-6)
     pw = torch.where(nan_x, tiny, pw)
@@ -537,7 +538,12 @@ def bbox2delta(proposals, gt, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
     gw = torch.where(nan_x, tiny, gw)
     gh = torch.where(nan_y, tiny, gh)
     gx = torch.where(nan_x, px, gx)
-    gy = torch.where(nan_x & nan_y, py, gy)
+    flat_x, flat_y = nan_x.reshape(-1), nan_y.reshape(-1)
+    if flat_x.numel() > 0:
+        rank = (torch.cumsum(flat_x, 0) - 1).clamp(min=0)
+        order_y = torch.sort((~flat_y).to(torch.uint8), stable=True)[1]          # zero-height rows first, in order
+        src = order_y[rank].reshape(nan_x.shape)
+        gy = torch.where(nan_x, py.reshape(-1)[src], gy)
     deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
     means = _const(means, deltas).unsqueeze(0)
     stds = _const(stds, deltas).unsqueeze(0)

@@ -104,7 +104,10 @@ __global__ __launch_bounds__(256) void targets_fill_kernel(TargetArgs a) {
     }
 }
 
-// bbox2delta of one pair, operation for operation as the tensor expression in core/bbox.py
+// bbox2delta of one pair, operation for operation as the tensor expression in core/bbox.py.  The fork's guard for
+// zero-size proposals pairs rows positionally (gy[nan_x] = py[nan_y], delta_xywh_bbox_coder.py:160); anchors from
+// AnchorGenerator never have a zero side, so the row-wise form below (exact when a row is degenerate in both
+// dimensions or in none) is what this kernel needs.
 __device__ __forceinline__ float4 encode_delta(const float4 p, const float4 g, const float* mean, const float* stdv) {
     const float px = (p.x + p.z) * 0.5f, py = (p.y + p.w) * 0.5f;
     float pw = p.z - p.x, ph = p.w - p.y;
