@@ -95,6 +95,7 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     det = build_detector(cfg.model)
     det.init_weights()
     det.train()
+    det.local_log_vars = True        # a CPU side model: never joins the (RCCL) process group's reductions
     opt = build_optimizer(det, cfg.optimizer)
     mean = np.array([123.675, 116.28, 103.53], np.float32)
     stdinv = (1.0 / np.array([58.395, 57.12, 57.375], np.float64)).astype(np.float32)
@@ -127,7 +128,8 @@ def cpu_baseline(cfg, seconds_budget=30.0):
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    distributed = world > 1
+    # OADG_BENCH_FORCE_DDP=1 (with torch.distributed.run --nproc-per-node 1): exercise the DDP / RCCL path on one GPU
+    distributed = world > 1 or os.environ.get('OADG_BENCH_FORCE_DDP') == '1'
     import oadg_amd
     from oadg_amd import Config, build_detector, hip_ops
     from oadg_amd.apis import TrainEngine, build_optimizer, init_dist, set_random_seed
@@ -164,7 +166,12 @@ def main():
     wseed = None if a.pipeline_thread == 0 else 1000 + rank     # worker thread with its own numpy stream
     state = {'next': pipe.prefetch(*batches[0], worker_seed=wseed)}
 
+    reuse = os.environ.get('OADG_BENCH_DIAG_REUSE_BATCH') == '1'   # diagnostic only: how much does the concurrent
+    fixed = state['next'].get() if reuse else None                  # pipeline cost the step?  (INVALID as a result)
+
     def step(i):
+        if reuse:
+            return engine.step(fixed)
         data = state['next'].get()
         if wseed is not None:        # the worker enqueues batch i+1 while this thread runs step i
             state['next'] = pipe.prefetch(*batches[(i + 1) % nb], worker_seed=wseed)
@@ -173,6 +180,12 @@ def main():
             state['next'] = pipe.prefetch(*batches[(i + 1) % nb])
         return out
 
+    # torch DDP instruments its first 10 iterations (Logger.set_runtime_stats_and_log synchronises on timing events
+    # in _pre_forward: ~6 ms of host stall per step, measured); a long training run pays that once, so the
+    # distributed bench primes past it before the W warm-up steps instead of timing it.
+    priming = max(0, 11 - a.warmup) if engine.ddp is not None else 0      # (torch DDP is opt-in: OADG_USE_TORCH_DDP=1)
+    for i in range(priming):
+        step(i)
     for i in range(a.warmup):
         out = step(i)
     hip_ops.TIMERS = {'roi_align_bwd': []}
@@ -245,7 +258,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '
                                f'{a.batch} img/GPU x 2 views, {a.height}x{a.width}, 20 boxes/img, SGD step',
-                   'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'final_loss': round(loss, 4),
+                   'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'priming_steps': priming, 'final_loss': round(loss, 4),
                    'conv': a.conv},
         'roofline': roof,
     }

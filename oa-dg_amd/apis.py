@@ -87,6 +87,83 @@ class StepLrSchedule:
             g['lr'] = lr
 
 
+class FlatGradReducer:
+    """Data-parallel gradient averaging for one process per GPU over RCCL (torch.distributed, backend 'nccl'), in
+    place of torch DDP's per-parameter reducer (3.5 ms of host work per step here: ~160 parameters, each copied into
+    a bucket and bookkept from an autograd hook, plus DDP's forward pre/post passes):
+
+    * parameters are grouped, in reverse registration order (~ the order their gradients become ready), into a few
+      buckets of one flat fp32 buffer;
+    * a post-accumulate hook per parameter only counts down; the hook that completes a bucket packs its gradients
+      into the flat slice with ONE ``torch.cat(out=...)`` launch and starts an asynchronous ``all_reduce(AVG)`` on
+      it - the RoI-head FC weights (the largest tensors, first to be ready) reduce while the backbone is still in
+      its backward pass;
+    * ``finish()`` (before ``optimizer.step()``) makes the compute stream wait for the reductions and re-points each
+      ``param.grad`` at its slice of the reduced buffer.  Parameters that received no gradient contribute zeros.
+
+    xGMI is point-to-point (7 links per GPU), so a ring all-reduce moves 2(N-1)/N of the 166 MB per GPU: a handful
+    of large buckets keeps each collective bandwidth-bound rather than latency-bound."""
+
+    def __init__(self, module, bucket_mb=64, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        params = [p for p in module.parameters() if p.requires_grad][::-1]
+        for t in list(module.parameters()) + list(module.buffers()):       # identical replicas (DDP does the same)
+            dist.broadcast(t.data, src=0, group=group)
+        self.params = params
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets, cur, size, off = [], [], 0, 0
+        limit = bucket_mb * (1 << 20) // 4
+        for p in params:
+            cur.append(p)
+            size += p.numel()
+            if size >= limit:
+                self.buckets.append(dict(params=cur, start=off, end=off + size))
+                off, cur, size = off + size, [], 0
+        if cur:
+            self.buckets.append(dict(params=cur, start=off, end=off + size))
+        self.bucket_of, self.views = {}, {}
+        for b in self.buckets:
+            o = b['start']
+            for p in b['params']:
+                self.bucket_of[p] = b
+                self.views[p] = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            b['pending'], b['work'] = len(b['params']), None
+        self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in params]
+
+    def _ready(self, p):
+        b = self.bucket_of[p]
+        b['pending'] -= 1
+        if b['pending'] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        flat = self.flat[b['start']:b['end']]
+        parts = [(p.grad if p.grad is not None else self.views[p].zero_()).reshape(-1).float() for p in b['params']]
+        torch.cat(parts, out=flat)
+        b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
+                                    group=self.group, async_op=True)
+
+    def _has_avg(self):
+        return dist.get_backend(self.group) == 'nccl'
+
+    def finish(self):
+        """call after loss.backward(): all gradients averaged over the ranks, ``param.grad`` = slices of one buffer"""
+        for b in self.buckets:
+            if b['work'] is None:                    # some parameter of the bucket had no gradient this step
+                self._launch(b)
+        for b in self.buckets:
+            b['work'].wait()
+            if not self._has_avg():
+                self.flat[b['start']:b['end']].div_(self.world)
+            b['work'], b['pending'] = None, len(b['params'])
+        for p in self.params:
+            p.grad = self.views[p]
+
+
 class TrainEngine:
     """model.train_step + backward + optimizer step for one process/GPU (the runner's hot loop,
     SURVEY.md 3.1): OptimizerHook semantics = zero_grad, loss.backward(), (no grad clip), step."""
@@ -96,13 +173,17 @@ class TrainEngine:
         self.module = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
-        self.ddp = None
-        if distributed:
+        self.ddp = self.reducer = None
+        if distributed and os.environ.get('OADG_USE_TORCH_DDP') != '1':
+            self.reducer = FlatGradReducer(model, bucket_mb=int(os.environ.get('OADG_BUCKET_MB', 64)))
+        elif distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
             dev = next(model.parameters()).device
             self.ddp = DDP(model, device_ids=[dev.index] if dev.type == 'cuda' else None,
                            broadcast_buffers=False, find_unused_parameters=find_unused_parameters,
-                           bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+                           bucket_cap_mb=int(os.environ.get('OADG_DDP_BUCKET_MB', bucket_cap_mb)),
+                           gradient_as_bucket_view=os.environ.get('OADG_DDP_BUCKET_VIEW', '1') == '1',
+                           static_graph=os.environ.get('OADG_DDP_STATIC', '0') == '1')
 
     def forward_losses(self, data):
         data = integrate_data(data, self.module.train_cfg)
@@ -119,6 +200,8 @@ class TrainEngine:
         (loss, log_vars), n = self.forward_losses(data)
         with _rf('sec:backward'):
             loss.backward()
+            if self.reducer is not None:
+                self.reducer.finish()
         with _rf('sec:optimizer'):
             self.optimizer.step()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)

@@ -88,7 +88,7 @@ class BaseDetector(nn.Module):
         log_vars['loss'] = loss
         names = list(log_vars.keys())
         packed = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
-        distributed = dist.is_available() and dist.is_initialized()
+        distributed = dist.is_available() and dist.is_initialized() and not getattr(self, 'local_log_vars', False)
         if distributed:
             # base.py:258-265 checks that every rank logs the same variables; the count rides in the same
             # all-reduce and is verified without a per-step host synchronisation (see _check_log_count)

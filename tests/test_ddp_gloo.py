@@ -12,7 +12,8 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, torch_ddp=False):
+    os.environ['OADG_USE_TORCH_DDP'] = '1' if torch_ddp else '0'
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
@@ -50,12 +51,17 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+_RESULTS = {}
+
+
 @pytest.mark.timeout(600)
-def test_two_rank_data_parallel_step():
+@pytest.mark.parametrize('torch_ddp', [False, True])
+def test_two_rank_data_parallel_step(torch_ddp):
+    """torch_ddp=False: apis.FlatGradReducer (the default); True: torch DDP.  Both must agree with each other."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if torch_ddp else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, torch_ddp)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=540) for _ in procs], key=lambda r: r[0])
@@ -71,3 +77,7 @@ def test_two_rank_data_parallel_step():
     for k in lv0:                      # log vars are the cross-rank means (base.py:270-275)
         assert abs(lv0[k] - lv1[k]) <= 1e-6 * max(1.0, abs(lv0[k])), k
     assert abs(lv0['loss'] - 0.5 * (l0 + l1)) <= 1e-5 * abs(lv0['loss'])
+    _RESULTS[torch_ddp] = (g0, p0)
+    if len(_RESULTS) == 2:             # the lean reducer and torch DDP average to the same gradients / parameters
+        assert np.allclose(_RESULTS[False][0], _RESULTS[True][0], rtol=1e-6, atol=1e-9)
+        assert np.allclose(_RESULTS[False][1], _RESULTS[True][1], rtol=1e-6, atol=1e-9)

@@ -23,7 +23,12 @@ def main():
     det.init_weights()
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     det.log_vars_on_host = False
-    eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
+    ddp = os.environ.get('OADG_FORCE_DDP') == '1'
+    if ddp:
+        from oadg_amd.apis import init_dist
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        init_dist('pytorch', backend='nccl')
+    eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=ddp, amp_dtype=torch.bfloat16)
     ds = SyntheticCityscapes(device=dev)
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
     batches = [ds.batch(range(i * 4, i * 4 + 4)) for i in range(3)]
