@@ -38,13 +38,13 @@ struct ConvArgs {
 
 // Last step of both epilogues for one 16-byte piece (8 channels of a pixel): residual add, ReLU, ReLU-backward
 // mask, bf16 rounding, and the running column sums of what is stored.
-__device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, size_t off, float* csum) {
+__device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, const bf16x8 rv, const bf16x8 mv,
+                                               float* csum) {
     if (a.res || a.mask) {
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((unsigned short)v[e]);
         if (a.res) {
-            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 f[e] += bf16_to_f32((unsigned short)rv[e]);
@@ -52,7 +52,6 @@ __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, size
             }
         }
         if (a.mask) {
-            const bf16x8 mv = *reinterpret_cast<const bf16x8*>(a.mask + off);
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (!(bf16_to_f32((unsigned short)mv[e]) > 0.f)) f[e] = 0.f;
@@ -212,18 +211,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             }
         }
     }
+    // The residual / mask pieces this thread will combine are requested BEFORE the barrier, all at once: the
+    // accumulators are dead by now, so the registers are free and every load of the epilogue is in flight together.
+    constexpr int SPR = TBN / 8;                       // 16-byte slots per tile row
+    constexpr int NPIECE = (BM * TBN / 8) / 256;
+    bf16x8 rv[NPIECE], mv[NPIECE];
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int q = it * 256 + tid;
+        const long m = m0 + q / SPR;
+        const size_t off = (size_t)m * a.K + k0 + (q % SPR) * 8;
+        rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr int SPR = TBN / 8;                       // 16-byte slots per tile row
 #pragma unroll
-    for (int it = 0; it < (BM * TBN / 8) / 256; ++it) {
+    for (int it = 0; it < NPIECE; ++it) {
         const int q = it * 256 + tid;
         const int row = q / SPR, sg = q % SPR;         // sg = tid % SPR for every piece of this thread
         const long m = m0 + row;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, off, csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, rv[it], mv[it], csum);
     }
     if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
         float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN]
@@ -484,17 +495,29 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
                     }
             }
     }
+    // residual / mask pieces requested before the barrier, all 16 (x2) loads of the thread in flight together: the
+    // 128 accumulator registers are dead once the C image is written
+    constexpr int NPIECE = (TM * TN / 8) / 512;
+    bf16x8 rv[NPIECE], mv[NPIECE];
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int q = it * 512 + tid;
+        const long m = m0 + (q >> 5);
+        const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
+        rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int it = 0; it < (TM * TN / 8) / 512; ++it) {
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
         const int q = it * 512 + tid;
         const int p = q >> 5, sg = q & 31;             // sg = tid & 31 for every piece of this thread
         const long m = m0 + p;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, off, csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, rv[it], mv[it], csum);
     }
     if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
         float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
