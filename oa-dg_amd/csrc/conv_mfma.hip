@@ -919,20 +919,48 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
 #pragma unroll
                 for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+    // fragment addresses: for a lane the swizzle term and the channel term do not depend on the k-step or on which
+    // 4-pixel half of the fragment is read (those only add multiples of 4 rows), so one byte offset per 16-channel
+    // tile is precomputed and every ds_read_b64_tr_b16 is base + immediate
+    int dyoff[4], xoff[2];
+    {
+        const int s16 = lane & 15, q4 = lane >> 4;
+        const int row = q4 * 8 + (s16 >> 2);
+        const int sw = ((row & 3) << 2) | (((row >> 3) & 1) << 1);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int chan = wr * 64 + it * 16 + (s16 & 3) * 4;
+            dyoff[it] = row * 256 + (((chan >> 3) ^ sw) << 4) + (chan & 7) * 2;
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int chan = wc * 32 + jt * 16 + (s16 & 3) * 4;
+            xoff[jt] = row * 256 + (((chan >> 3) ^ sw) << 4) + (chan & 7) * 2;
+        }
+    }
+    auto frag = [&](const unsigned char* half, int off, int ks) {
+        bf16x8 out;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(half + off + (ks * 32 + u * 4) * 256));
+            out[u * 4 + 0] = r[0]; out[u * 4 + 1] = r[1]; out[u * 4 + 2] = r[2]; out[u * 4 + 3] = r[3];
+        }
+        return out;
+    };
     bf16x8 df[4][2], xf[2][2];
     auto read_dy = [&](int h, int buf) {
         const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
 #pragma unroll
         for (int it = 0; it < 4; ++it)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) df[it][ks] = tr_frag16(base, ks * 32, wr * 64 + it * 16, lane);
+            for (int ks = 0; ks < 2; ++ks) df[it][ks] = frag(base, dyoff[it], ks);
     };
     auto read_x = [&](int h, int buf) {
         const unsigned char* base = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[jt][ks] = tr_frag16(base, ks * 32, wc * 32 + jt * 16, lane);
+            for (int ks = 0; ks < 2; ++ks) xf[jt][ks] = frag(base, xoff[jt], ks);
     };
 #define OADG_WQUADRANT(XH, DH)                                                                               \
     do {                                                                                                     \
