@@ -87,6 +87,11 @@ class StepLrSchedule:
             g['lr'] = lr
 
 
+def _join_side_streams():
+    from . import hip_conv
+    hip_conv.join_wgrad_streams()
+
+
 class FlatGradReducer:
     """Data-parallel gradient averaging for one process per GPU over RCCL (torch.distributed, backend 'nccl'), in
     place of torch DDP's per-parameter reducer (3.5 ms of host work per step here: ~160 parameters, each copied into
@@ -141,6 +146,7 @@ class FlatGradReducer:
             self._launch(b)
 
     def _launch(self, b):
+        _join_side_streams()          # weight gradients are produced on hip_conv's side stream
         flat = self.flat[b['start']:b['end']]
         parts = [(p.grad if p.grad is not None else self.views[p].zero_()).reshape(-1).float() for p in b['params']]
         torch.cat(parts, out=flat)
@@ -174,6 +180,11 @@ class TrainEngine:
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
         self.ddp = self.reducer = None
+        from . import hip_conv
+        # EXPERIMENTAL, off by default: weight gradients beside the data-gradient chain on a side stream (-1.4 ms per
+        # step measured, but tools/probe/side_debug2.py still shows a cross-stream race in some weight gradients)
+        hip_conv.WGRAD_SIDE_STREAM = os.environ.get('OADG_WGRAD_STREAM', '0') == '1' and \
+            not (distributed and os.environ.get('OADG_USE_TORCH_DDP') == '1')
         if distributed and os.environ.get('OADG_USE_TORCH_DDP') != '1':
             self.reducer = FlatGradReducer(model, bucket_mb=int(os.environ.get('OADG_BUCKET_MB', 64)))
         elif distributed:
@@ -200,6 +211,7 @@ class TrainEngine:
         (loss, log_vars), n = self.forward_losses(data)
         with _rf('sec:backward'):
             loss.backward()
+            _join_side_streams()
             if self.reducer is not None:
                 self.reducer.finish()
         with _rf('sec:optimizer'):

@@ -4,6 +4,9 @@ convolution implementation of :mod:`oadg_amd.layers`.
 Forward and the stride-1 data gradient run on the hand-written kernel; the weight/bias gradients (a GEMM reduced
 over the pixel dimension) still go through ``aten.convolution_backward`` (MIOpen) this round.
 """
+import contextlib
+import os
+
 import torch
 
 from . import _lib
@@ -121,6 +124,7 @@ class _PrepWeights(torch.autograd.Function):
     def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt):
         L = _lib.lib()
         K, C, R, S = w.shape
+        leaf = all(t is None or t.grad_fn is None for t in (w, gamma, beta, bias_in))
         w = w.detach().float().contiguous()
         dev = w.device
         wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
@@ -136,6 +140,7 @@ class _PrepWeights(torch.autograd.Function):
               'oadg_prep_conv_weights')
         ctx.save_for_backward(w, scale, m_, v_)
         ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S)
+        ctx.leaf_inputs = leaf      # False: autograd ops (not AccumulateGrad) consume the gradients next
         outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
         ctx.mark_non_differentiable(outs[2])
         return outs
@@ -147,13 +152,28 @@ class _PrepWeights(torch.autograd.Function):
         L = _lib.lib()
         dw = dgamma = dbeta = dbias_in = None
         gb = gbias.float().contiguous() if (gbias is not None and gbias.numel()) else None
-        if gwf is not None:
+        side = wgrad_stream(w.device) if (WGRAD_SIDE_STREAM and gwf is not None and w.is_cuda) else None
+        if side is not None:          # the weight gradient was produced on the side stream: stay there
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)     # (gbias comes from the main stream)
+            for t_ in (gb, gwf, w, scale, mean, var):      # read on the side stream after this node has returned
+                if t_ is not None:
+                    t_.record_stream(side)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+          if gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
                                                R, S, ptr(dw), ptr(dgamma), stream_ptr()),
                   'oadg_prep_conv_weights_bwd')
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            for t_ in (dw, dgamma):                  # allocated on the side stream, consumed on this one later
+                if t_ is not None:
+                    t_.record_stream(cur)
+            if not ctx.leaf_inputs:
+                cur.wait_stream(side)                # autograd ops (not AccumulateGrad) consume dw next
         if has_bn:
             dbeta = gb
         elif has_bias_in:
@@ -188,6 +208,29 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
     if key is not None:
         cache_on._prepared = (key, out)
     return out
+
+
+# Weight gradients on a side stream: only under a driver that joins the streams before gradients are read
+# (apis.TrainEngine does; plain autograd users keep everything on the current stream)
+WGRAD_SIDE_STREAM = False
+_SIDE = {}
+
+
+def wgrad_stream(device):
+    """the stream weight gradients (and their weight-sized post-processing) run on, beside the data-gradient chain"""
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_streams():
+    """make the current stream wait for every weight gradient in flight (before the optimizer / the all-reduce)"""
+    if not _SIDE:
+        return
+    cur = torch.cuda.current_stream()
+    for st in _SIDE.values():
+        cur.wait_stream(st)
 
 
 class GradToken:
@@ -257,22 +300,36 @@ class _Conv2dMFMA(torch.autograd.Function):
                 gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)
             need_x = False
         gw = None
-        if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
-            gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
-            need_w = False
-            if want_b:
-                gb = gy.float().sum((0, 2, 3))
-                want_b = False
-        if need_x or need_w or want_b:
-            outs = torch.ops.aten.convolution_backward(
-                gy, x16, wf, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
-                1, [need_x, need_w, want_b])
-            if gx is None:
-                gx = outs[0]
-            if outs[1] is not None:
-                gw = outs[1]
-            if outs[2] is not None:
-                gb = outs[2].float()
+        side = wgrad_stream(gy.device) if (WGRAD_SIDE_STREAM and need_w and not need_x) else None
+        if side is not None:
+            # the weight gradient is independent of the data-gradient chain: it runs on a side stream (as does the
+            # weight-sized prep backward that consumes it) and is joined before the optimizer / all-reduce
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            gy.record_stream(side)
+            x16.record_stream(side)
+            ctx_mgr = torch.cuda.stream(side)
+        else:
+            ctx_mgr = contextlib.nullcontext()
+        with ctx_mgr:
+            if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
+                gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
+                need_w = False
+                if want_b:
+                    gb = gy.float().sum((0, 2, 3))
+                    want_b = False
+            if need_x or need_w or want_b:
+                outs = torch.ops.aten.convolution_backward(
+                    gy, x16, wf, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
+                    1, [need_x, need_w, want_b])
+                if gx is None:
+                    gx = outs[0]
+                if outs[1] is not None:
+                    gw = outs[1]
+                if outs[2] is not None:
+                    gb = outs[2].float()
+        if side is not None and gw is not None:
+            gw._oadg_side = True
         if gx is not None and extra is not None:      # library data gradient: the identity gradient is added here
             gx = gx + extra.to(gx.dtype)
         gres = None
