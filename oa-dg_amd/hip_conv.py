@@ -328,8 +328,9 @@ class _Conv2dMFMA(torch.autograd.Function):
                     gw = outs[1]
                 if outs[2] is not None:
                     gb = outs[2].float()
-        if side is not None and gw is not None:
-            gw._oadg_side = True
+        if side is not None and gw is not None and gw.dtype != wf.dtype:
+            with torch.cuda.stream(side):        # autograd would cast to wf's dtype on the CURRENT stream otherwise
+                gw = gw.to(wf.dtype)
         if gx is not None and extra is not None:      # library data gradient: the identity gradient is added here
             gx = gx + extra.to(gx.dtype)
         gres = None
