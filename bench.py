@@ -245,7 +245,7 @@ def main():
                 e = shp.setdefault((t[4],) + t[5], [0, 0.0, 0.0, 0.0])
                 e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]; e[3] += t[3]
             for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1]):
-                print(f'{k_[0][11:]:14s} N{k_[1]} {k_[2]}x{k_[3]} C{k_[4]} K{k_[5]} R{k_[6]} s{k_[7]} res{int(k_[8])} mask{int(k_[9])}: '
+                print(f'{k_[0][5:]:26s} N{k_[1]} {k_[2]}x{k_[3]} C{k_[4]} K{k_[5]} R{k_[6]} s{k_[7]} res{int(k_[8])} mask{int(k_[9])}: '
                       f'{e[0] / a.steps:5.1f}/step {e[1] / a.steps:6.3f} ms/step {e[2] / e[1] / 1e9:7.1f} TF/s '
                       f'{e[3] / e[1] / 1e9:6.2f} TB/s', file=sys.stderr)
     else:

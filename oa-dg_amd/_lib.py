@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int64, c_long, c_size_t, c_void_p)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'liboadg_hip.so')
+LIB_PATH = os.environ.get('OADG_HIP_LIB') or os.path.join(_HERE, 'csrc', 'liboadg_hip.so')   # (override: A/B probes)
 _lib = None
 
 vp, ci, cf, cl, cs, cd = c_void_p, c_int, c_float, c_long, c_size_t, c_double

@@ -38,9 +38,10 @@ struct ConvArgs {
 
 // Last step of both epilogues for one 16-byte piece (8 channels of a pixel): residual add, ReLU, ReLU-backward
 // mask, bf16 rounding, and the running column sums of what is stored.
+template <bool POST>
 __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, const bf16x8 rv, const bf16x8 mv,
                                                float* csum) {
-    if (a.res || a.mask) {
+    if (POST) {
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((unsigned short)v[e]);
@@ -75,7 +76,8 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 // TBN = 128: 4 waves as 2 x 2, 64 x 64 outputs per wave.  TBN = 64 (layers with K % 128 != 0, e.g. the 64-channel
 // convolutions of ResNet's first stage): 4 waves as 4 x 1, 32 x 64 outputs per wave.
-template <int TBN>
+// POST: the launch has a residual and/or a ReLU-backward mask operand (compiled out otherwise).
+template <int TBN, bool POST>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WN = TBN / 64, WM = 4 / WN, AF = BM / WM / 32, NBP = TBN * 8 / 256;
@@ -215,14 +217,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     // accumulators are dead by now, so the registers are free and every load of the epilogue is in flight together.
     constexpr int SPR = TBN / 8;                       // 16-byte slots per tile row
     constexpr int NPIECE = (BM * TBN / 8) / 256;
-    bf16x8 rv[NPIECE], mv[NPIECE];
+    bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
+    if (POST) {
 #pragma unroll
-    for (int it = 0; it < NPIECE; ++it) {
-        const int q = it * 256 + tid;
-        const long m = m0 + q / SPR;
-        const size_t off = (size_t)m * a.K + k0 + (q % SPR) * 8;
-        rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < NPIECE; ++it) {
+            const int q = it * 256 + tid;
+            const long m = m0 + q / SPR;
+            const size_t off = (size_t)m * a.K + k0 + (q % SPR) * 8;
+            rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    } else {
+        rv[0] = mv[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, rv[it], mv[it], csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
     }
     if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
         float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN]
@@ -280,6 +286,7 @@ struct TapState {
     int t, r, s, rs, c0;
 };
 
+template <bool POST>
 __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -313,10 +320,11 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
             const int row = q >> 3, lslot = (q & 7) ^ ((row >> 1) & 7);
             const long m = m0 + h * 128 + row;
             if (m < a.M) {
-                const int wo = (int)(m % a.Wo);
-                const long t = m / a.Wo;
-                const int ho = (int)(t % a.Ho);
-                const int n = (int)(t / a.Ho);
+                const unsigned mu = (unsigned)m;                 // M < 2^31 (checked on the host): 32-bit divisions
+                const unsigned tq = mu / (unsigned)a.Wo;
+                const int wo = (int)(mu - tq * (unsigned)a.Wo);
+                const int n = (int)(tq / (unsigned)a.Ho);
+                const int ho = (int)(tq - (unsigned)n * (unsigned)a.Ho);
                 pb[h * 2 + i] = a.x + (size_t)n * a.H * a.W * a.C + lslot * 8;
                 hi0[h * 2 + i] = ho * a.stride - a.pad;
                 wi0[h * 2 + i] = wo * a.stride - a.pad;
@@ -498,14 +506,18 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     // residual / mask pieces requested before the barrier, all 16 (x2) loads of the thread in flight together: the
     // 128 accumulator registers are dead once the C image is written
     constexpr int NPIECE = (TM * TN / 8) / 512;
-    bf16x8 rv[NPIECE], mv[NPIECE];
+    bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
+    if (POST) {
 #pragma unroll
-    for (int it = 0; it < NPIECE; ++it) {
-        const int q = it * 512 + tid;
-        const long m = m0 + (q >> 5);
-        const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
-        rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < NPIECE; ++it) {
+            const int q = it * 512 + tid;
+            const long m = m0 + (q >> 5);
+            const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
+            rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    } else {
+        rv[0] = mv[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
     }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece(a, v, rv[it], mv[it], csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
     }
     if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
         float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
@@ -540,7 +552,7 @@ namespace {
 // (tools/bench_conv.py: 920-1030 TFLOP/s vs 630-720 on the 3x3 layers; 625 vs 718 at 128 workgroups)
 int auto_variant(long M, int H, int W, int C, int K) {
     const long big = ((M + TM - 1) / TM) * (K / TN);
-    return (K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31)) ? 2 : 1;
+    return (K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31)) ? 2 : 1;
 }
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
@@ -560,31 +572,45 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
+    const bool post = residual != nullptr || mask != nullptr;
     if (variant == 0) variant = auto_variant(a.M, H, W, C, K);
-    if (variant == 2 && (long)H * W * C >= (1L << 31)) variant = 1;
+    if (variant == 2 && ((long)H * W * C >= (1L << 31) || a.M >= (1L << 31))) variant = 1;
     if (variant == 2) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm256_kernel,
+            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm256_kernel<false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
         const long m_tiles = (a.M + TM - 1) / TM;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / TN);
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        hipLaunchKernelGGL(conv_igemm256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
-                           (hipStream_t)stream, a);
+        if (post)
+            hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
+                               (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(conv_igemm256_kernel<false>, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
+                               (hipStream_t)stream, a);
     } else {
         const long m_tiles = (a.M + BM - 1) / BM;
         const int tbn = K % BN == 0 ? BN : 64;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / tbn);     // 8 equal XCD ranges (the kernel drops the padding)
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        if (tbn == BN)
-            hipLaunchKernelGGL(conv_igemm_kernel<128>, dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
+        if (tbn == BN && post)
+            hipLaunchKernelGGL((conv_igemm_kernel<128, true>), dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
+                               (hipStream_t)stream, a);
+        else if (tbn == BN)
+            hipLaunchKernelGGL((conv_igemm_kernel<128, false>), dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
+                               (hipStream_t)stream, a);
+        else if (post)
+            hipLaunchKernelGGL((conv_igemm_kernel<64, true>), dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
                                (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
+            hipLaunchKernelGGL((conv_igemm_kernel<64, false>), dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
                                (hipStream_t)stream, a);
     }
     OADG_LAUNCH_CHECK();

@@ -23,7 +23,10 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(f)):
     if r['Counter_Name'] != c:
         continue
-    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0].split('<')[0][-70:]
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+    if not k.startswith('conv_'):              # our conv kernels keep their template arguments (one row each)
+        k = k.split('<')[0]
+    k = k[-70:]
     agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
 rows = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda t: -t[1])[:25]
 json.dump([dict(kernel=k, counter=c, total=t, dispatches=n, per_dispatch=t / max(n, 1)) for k, t, n in rows],
