@@ -170,7 +170,8 @@ int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const
 /* weight gradient of the same convolution: dw [K,R,S,C] fp32 = sum over output pixels of dy (x) x@tap
  * (transposing LDS reads + split-K partials in `workspace`, summed in fixed order).  C % 128 == 0, K % 128 == 0. */
 /* same contract; `variant` picks the kernel: 0 automatic (what oadg_conv2d_nhwc_bf16 does), 1 = 128x128x64 tile
- * (4 waves, two 32 KiB LDS stages), 2 = 256x256x64 tile (8 waves, 128 KiB LDS, phase-pipelined; needs K % 256 == 0) */
+ * (4 waves, two 32 KiB LDS stages, 2 workgroups per CU), 2 = 256x256x64 tile (8 waves, 128 KiB LDS,
+ * phase-pipelined; needs K % 256 == 0), 3 = 128-tile with ONE LDS stage at 4 workgroups per CU */
 int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int dil, int relu, int variant, void* stream);
@@ -184,7 +185,7 @@ int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, co
 long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                              int variant);
 int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream);
-/* the variant (1 or 2) variant 0 resolves to for a problem; 0 = shape not covered */
+/* the variant (2 or 3) variant 0 resolves to for a problem; 0 = shape not covered */
 int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);
 int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,

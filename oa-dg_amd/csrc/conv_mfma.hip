@@ -21,7 +21,6 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
 
 struct ConvArgs {
     const unsigned short* x;      // [N,H,W,C] bf16
@@ -77,8 +76,11 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // TBN = 128: 4 waves as 2 x 2, 64 x 64 outputs per wave.  TBN = 64 (layers with K % 128 != 0, e.g. the 64-channel
 // convolutions of ResNet's first stage): 4 waves as 4 x 1, 32 x 64 outputs per wave.
 // POST: the launch has a residual and/or a ReLU-backward mask operand (compiled out otherwise).
-template <int TBN, bool POST>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+// NST = 2: two LDS stages (next chunk loads while this one computes), 2 workgroups per CU.  NST = 1: one stage
+// (32 KiB + 8 KiB), 4 workgroups per CU - for short reductions (1x1 convolutions with C <= 256) the latencies of a
+// workgroup (first HBM fetch, epilogue) are covered by the other three instead of by its own pipeline.
+template <int TBN, bool POST, int NST>
+__global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WN = TBN / 64, WM = 4 / WN, AF = BM / WM / 32, NBP = TBN * 8 / 256;
     constexpr int TSTAGE = (BM + TBN) * BK * 2;
@@ -165,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
     const int l31 = lane & 31, lh = lane >> 5;
     for (int kc = 0; kc < nchunks; ++kc) {
-        const int cur = kc & 1;
-        if (kc + 1 < nchunks) stage(kc + 1, cur ^ 1);
+        const int cur = NST == 2 ? (kc & 1) : 0;
+        if (NST == 2 && kc + 1 < nchunks) stage(kc + 1, cur ^ 1);
         const unsigned char* sa = smem + cur * TSTAGE;
         const unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
@@ -188,6 +190,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (NST == 1) {
+            __syncthreads();                           // every wave is done reading the single stage
+            if (kc + 1 < nchunks) stage(kc + 1, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
         *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
     }
     if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
-        float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN]
+        float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN] (8 KiB behind stage 0)
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[(tid / SPR) * TBN + (tid % SPR) * 8 + e] = csum[e];
         __syncthreads();
@@ -548,11 +554,16 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 }  // namespace
 
 namespace {
-// the 256 x 256 tile runs one workgroup per CU: it wins as soon as there is one for every CU
-// (tools/bench_conv.py: 920-1030 TFLOP/s vs 630-720 on the 3x3 layers; 625 vs 718 at 128 workgroups)
-int auto_variant(long M, int H, int W, int C, int K) {
+// Automatic kernel choice (tools/bench_conv.py, MI355X):
+//  - the 256 x 256 phase-pipelined tile (variant 2) when there is a workgroup for every CU and the reduction is long
+//    enough to amortise its one-workgroup-per-CU prologue/epilogue: 920-1080 TFLOP/s on the 3x3 layers;
+//  - otherwise the single-stage 128-tile kernel at 4 workgroups per CU (variant 3): 1.15-1.4x the 256-tile kernel on
+//    the 1x1 layers with C <= 256, 850 TFLOP/s even on 3x3 (the two-stage variant 1: 710) - it is never slower than
+//    the two-stage kernel, which stays selectable for comparison.
+int auto_variant(long M, int H, int W, int C, int K, int nchunks) {
     const long big = ((M + TM - 1) / TM) * (K / TN);
-    return (K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31)) ? 2 : 1;
+    const bool ok256 = K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
+    return (ok256 && nchunks >= 12) ? 2 : 3;
 }
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
@@ -561,7 +572,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % 64 != 0) return OADG_EARG;   // other shapes stay on the library path
-    if (variant < 0 || variant > 2 || (variant == 2 && K % TN != 0)) return OADG_EARG;
+    if (variant < 0 || variant > 3 || (variant == 2 && K % TN != 0)) return OADG_EARG;
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
@@ -573,7 +584,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
     const bool post = residual != nullptr || mask != nullptr;
-    if (variant == 0) variant = auto_variant(a.M, H, W, C, K);
+    if (variant == 0) variant = auto_variant(a.M, H, W, C, K, R * S * (C / BK));
     if (variant == 2 && ((long)H * W * C >= (1L << 31) || a.M >= (1L << 31))) variant = 1;
     if (variant == 2) {
         static bool attr_set = false;
@@ -600,18 +611,19 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
         const int tbn = K % BN == 0 ? BN : 64;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / tbn);     // 8 equal XCD ranges (the kernel drops the padding)
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        if (tbn == BN && post)
-            hipLaunchKernelGGL((conv_igemm_kernel<128, true>), dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
-                               (hipStream_t)stream, a);
-        else if (tbn == BN)
-            hipLaunchKernelGGL((conv_igemm_kernel<128, false>), dim3((unsigned)blocks), dim3(256), 2 * STAGE_BYTES,
-                               (hipStream_t)stream, a);
-        else if (post)
-            hipLaunchKernelGGL((conv_igemm_kernel<64, true>), dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
-                               (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL((conv_igemm_kernel<64, false>), dim3((unsigned)blocks), dim3(256), 2 * (BM + 64) * BK * 2,
-                               (hipStream_t)stream, a);
+        const bool one = variant == 3;
+        const unsigned lds2 = 2 * (BM + tbn) * BK * 2, lds1 = (BM + tbn) * BK * 2 + 8192;
+        hipStream_t st = (hipStream_t)stream;
+#define OADG_L128(TB, PO, NS, LDS) \
+    hipLaunchKernelGGL((conv_igemm_kernel<TB, PO, NS>), dim3((unsigned)blocks), dim3(256), LDS, st, a)
+        if (tbn == BN) {
+            if (one) { if (post) OADG_L128(128, true, 1, lds1); else OADG_L128(128, false, 1, lds1); }
+            else { if (post) OADG_L128(128, true, 2, lds2); else OADG_L128(128, false, 2, lds2); }
+        } else {
+            if (one) { if (post) OADG_L128(64, true, 1, lds1); else OADG_L128(64, false, 1, lds1); }
+            else { if (post) OADG_L128(64, true, 2, lds2); else OADG_L128(64, false, 2, lds2); }
+        }
+#undef OADG_L128
     }
     OADG_LAUNCH_CHECK();
     return OADG_OK;
@@ -630,7 +642,7 @@ extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R
     if (C % BK != 0 || K % 64 != 0) return 0;
     const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return 0;
-    return auto_variant((long)N * Ho * Wo, H, W, C, K);
+    return auto_variant((long)N * Ho * Wo, H, W, C, K, R * S * (C / BK));
 }
 
 // Data-gradient form with the backward of the producer's epilogue fused in:  y = (conv(x, w) [+ residual]) * (mask > 0)

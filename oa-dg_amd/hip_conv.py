@@ -62,7 +62,8 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
                        2.0 * (N * H * W * C + K * C * R * S +
                               N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None))),
-                       ('conv_igemm256_kernel<%s>' if v == 2 else ('conv_igemm_kernel<%d, %%s>' % (128 if K % 128 == 0 else 64)))
+                       ('conv_igemm256_kernel<%s>' if v == 2 else
+                        ('conv_igemm_kernel<%d, %%s, %d>' % (128 if K % 128 == 0 else 64, 1 if v == 3 else 2)))
                        % ('true' if (residual is not None or mask is not None) else 'false'),
                        (N, H, W, C, K, R, stride, residual is not None, mask is not None)))
     if want_colsum:

@@ -34,11 +34,12 @@ def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad,
     w = (torch.randn(K, C, R, R, device=dev, generator=g) / np.sqrt(C * R * R)).bfloat16() \
         .contiguous(memory_format=torch.channels_last)
     b = torch.randn(K, device=dev, generator=g)
-    y = hip_conv.conv_forward(x, w, b, None, stride, pad, dil, False)
     ref = _ref(x, w, b, stride, pad, dil)
-    assert y.shape == ref.shape
-    err = (y.float() - ref).abs().max().item()
-    assert err <= 8e-3 * ref.abs().max().item(), err
+    for variant in (0, 1, 3):            # automatic choice, 128-tile with two LDS stages, 128-tile with one stage
+        y = hip_conv.conv_forward(x, w, b, None, stride, pad, dil, False, variant=variant)
+        assert y.shape == ref.shape
+        err = (y.float() - ref).abs().max().item()
+        assert err <= 8e-3 * ref.abs().max().item(), (variant, err)
     # asymmetric check against transposes: a single non-zero weight tap / channel
     w2 = torch.zeros_like(w)
     w2[K - 3, 5, R - 1, 0] = 1.0
@@ -283,7 +284,7 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(2)
     for variant, (N, C, H, W, K) in ((1, (2, 128, 20, 28, 128)), (2, (2, 128, 40, 56, 256)), (2, (1, 64, 19, 23, 512)),
-                                      (1, (2, 128, 21, 27, 64))):
+                                      (1, (2, 128, 21, 27, 64)), (3, (2, 128, 20, 28, 128)), (3, (2, 256, 21, 27, 64))):
         x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(K, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5).bfloat16().contiguous(
             memory_format=torch.channels_last)

@@ -52,9 +52,10 @@ def main():
         t1 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False, variant=1))
         t256 = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False, variant=2)) if K % 256 == 0 \
             else float('nan')
+        t1s = timeit(lambda: hip_conv.conv_forward(x, w, b, None, st, pad, 1, False, variant=3))
         bb = b.bfloat16()
         t2 = timeit(lambda: F.conv2d(x, w, bb, st, pad))
-        line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x | 256-tile {t256:7.3f} ms {gf / t256:7.1f} TF/s'
+        line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x | 256-tile {t256:7.3f} ms {gf / t256:7.1f} TF/s | 128-tile 1-stage {t1s:7.3f} ms {gf / t1s:7.1f} TF/s'
         if '--wgrad' in sys.argv and C % 128 == 0 and K % 128 == 0:
             gy = torch.randn(N, K, Ho, Wo, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
             t3 = timeit(lambda: hip_conv.conv_wgrad(x, gy, K, R, R, st, pad, 1))
