@@ -192,6 +192,21 @@ int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const 
                                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, int dil, void* stream);
 
+/* the weight gradient as split partials + their consumer: oadg_conv2d_wgrad_parts_nhwc_bf16 leaves
+ * workspace = [*splits][K][R*S][C] fp32; oadg_prep_conv_weights_bwd_parts sums the splits in fp32 and applies the
+ * backward of oadg_prep_conv_weights (dw [K,C,R,S], dgamma) in the same launch - no reduction kernel, no bf16 round
+ * trip of the weight gradient.  C*R*S <= 3000 (five fp32 copies of a filter in LDS). */
+int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, const void* zeros16, void* workspace,
+                                      size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
+                                      int stride, int pad, int dil, int* splits, void* stream);
+int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float* gbias, const float* w,
+                                     const float* scale, const float* mean, const float* var, float eps, int K, int C,
+                                     int R, int S, float* dw, float* dgamma, void* stream);
+
+/* probe switches for tools/bench_conv.py only: force the 128-tile weight-gradient kernel, its LDS stage count
+ * (1 / 2, else automatic) and the workgroup count the split heuristic aims at (0 = automatic) */
+void oadg_debug_wgrad(int force128, int stages, int target_blocks);
+
 /* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
  * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with
  * bias_in), fp32 [K,C,R,S] -> bf16 wf [K,R,S,C] and (optional) wt [C,R,S,K] flipped for the data gradient.

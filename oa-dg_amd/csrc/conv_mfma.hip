@@ -720,7 +720,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int pix0, i
 constexpr int WP = 64;                                  // pixels per chunk
 constexpr int WSTAGE = 2 * WP * 128 * 2;                // dy tile + x tile = 32 KiB
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+// NST as in conv_igemm_kernel: 2 LDS stages at 2 workgroups per CU, or 1 stage at 4 workgroups per CU.
+template <int NST>
+__global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -804,8 +806,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (long ch = ch0; ch < ch1; ++ch) {
-            const int cur = (int)((ch - ch0) & 1);
-            if (ch + 1 < ch1) stage(ch + 1, cur ^ 1);
+            const int cur = NST == 2 ? (int)((ch - ch0) & 1) : 0;
+            if (NST == 2 && ch + 1 < ch1) stage(ch + 1, cur ^ 1);
             const unsigned char* sa = smem + cur * WSTAGE;
             const unsigned char* sb = sa + WP * 256;
 #pragma unroll
@@ -820,6 +822,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (NST == 1) {
+                __syncthreads();
+                if (ch + 1 < ch1) stage(ch + 1, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1080,9 +1086,19 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     dw[i] = s;
 }
 
+// probe switches (oadg_debug_wgrad, tools/bench_conv.py): -1 = automatic
+int g_wgrad_force128 = 0, g_wgrad_stages = -1, g_wgrad_target = 0;
+
+// Kernel / split choice (tools/bench_conv.py --wgrad sweeps it; times vs MIOpen's igemm_wrw on MI355X):
+//  - 3x3 over >= 200k pixels, K and C multiples of 256: the 256-tile phase pipeline (1.2x at P2, 1.1x at P3);
+//  - other 3x3: 128-tile, ONE LDS stage at 4 workgroups per CU, ~1024 workgroups (1.06-1.2x);
+//  - 1x1: 128-tile, two stages, ~512 workgroups - the fp32 partial tiles (splits x K x C x 4 bytes, written and read
+//    back by the reduction) are the cost that matters there (1.15x on layer2, 1.6x on layer3 / layer4).
 bool wgrad_use256(long P, int K, int C, int RS) {
-    return K % 256 == 0 && C % 256 == 0 && (P + WP - 1) / WP >= 64;
+    if (g_wgrad_force128) return false;
+    return K % 256 == 0 && C % 256 == 0 && RS > 1 && P >= 200000;
 }
+int wgrad_stages(int RS) { return g_wgrad_stages > 0 ? g_wgrad_stages : (RS > 1 ? 1 : 2); }
 
 int wgrad_splits(long P, int K, int C, int RS) {
     if (wgrad_use256(P, K, C, RS)) {
@@ -1098,7 +1114,8 @@ int wgrad_splits(long P, int K, int C, int RS) {
     }
     const long tiles = (long)(K / 128) * (C / 128) * RS;
     const long nchunks = (P + WP - 1) / WP;
-    long s = (1024 + tiles - 1) / tiles;
+    const long target = g_wgrad_target > 0 ? g_wgrad_target : (RS > 1 ? 1024 : 512);
+    long s = (target + tiles - 1) / tiles;
     if (s > nchunks / 4) s = nchunks / 4;
     if (s >= 8) s = (s + 7) / 8 * 8;       // multiples of 8: one pixel range per XCD at a time
     if (s < 1) s = 1;
@@ -1114,11 +1131,18 @@ extern "C" size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C
     return (size_t)sp * K * R * S * C * sizeof(float);
 }
 
-// dw [K,R,S,C] fp32 (overwritten).  x [N,H,W,C] bf16, dy [N,Ho,Wo,K] bf16.  Requires C % 128 == 0, K % 128 == 0.
-extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16,
-                                           void* workspace, size_t workspace_bytes, int N, int H, int W, int C,
-                                           int K, int R, int S, int stride, int pad, int dil, void* stream) {
-    if (!x || !dy || !dw || !zeros16 || !workspace) return OADG_EARG;
+// probe switches for tools/bench_conv.py (not part of the product interface)
+extern "C" void oadg_debug_wgrad(int force128, int stages, int target_blocks) {
+    g_wgrad_force128 = force128;
+    g_wgrad_stages = stages;          // 1 / 2, anything else = automatic
+    g_wgrad_target = target_blocks;   // 0 = automatic
+}
+
+namespace {
+int wgrad_launch(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,
+                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
+                 int* splits_out, void* stream) {
+    if (!x || !dy || !zeros16 || !workspace) return OADG_EARG;
     if (C % 128 != 0 || K % 128 != 0 || N < 1 || R < 1 || S < 1) return OADG_EARG;
     WgradArgs a;
     a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.part = (float*)workspace;
@@ -1145,14 +1169,41 @@ extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float*
         hipLaunchKernelGGL(conv_wgrad256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES, st, a);
     } else {
         const long blocks = (long)a.splits * (K / 128) * (C / 128) * R * S;
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 2 * WSTAGE, st, a);
+        if (wgrad_stages(R * S) == 2)
+            hipLaunchKernelGGL(conv_wgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 2 * WSTAGE, st, a);
+        else
+            hipLaunchKernelGGL(conv_wgrad_kernel<1>, dim3((unsigned)blocks), dim3(256), WSTAGE, st, a);
     }
     OADG_LAUNCH_CHECK();
+    if (splits_out) {                 // the caller consumes the partial tiles itself (oadg_prep_conv_weights_bwd_parts)
+        *splits_out = a.splits;
+        return OADG_OK;
+    }
     const long n = (long)K * R * S * C;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        (const float*)workspace, a.splits, n, dw);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
+}
+}  // namespace
+
+// dw [K,R,S,C] fp32 (overwritten).  x [N,H,W,C] bf16, dy [N,Ho,Wo,K] bf16.  Requires C % 128 == 0, K % 128 == 0.
+extern "C" int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16,
+                                           void* workspace, size_t workspace_bytes, int N, int H, int W, int C,
+                                           int K, int R, int S, int stride, int pad, int dil, void* stream) {
+    if (!dw) return OADG_EARG;
+    return wgrad_launch(x, dy, dw, zeros16, workspace, workspace_bytes, N, H, W, C, K, R, S, stride, pad, dil, nullptr,
+                        stream);
+}
+
+// Partial tiles only: workspace = [*splits][K][R*S][C] fp32, to be summed by oadg_prep_conv_weights_bwd_parts (which
+// also applies the BN-fold chain rule and the layout change) - no separate reduction, no bf16 round trip.
+extern "C" int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, const void* zeros16, void* workspace,
+                                                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R,
+                                                 int S, int stride, int pad, int dil, int* splits, void* stream) {
+    if (!splits) return OADG_EARG;
+    return wgrad_launch(x, dy, nullptr, zeros16, workspace, workspace_bytes, N, H, W, C, K, R, S, stride, pad, dil,
+                        splits, stream);
 }
 
 // ================================================================================================ weight preparation
@@ -1226,6 +1277,69 @@ extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const 
     if (gamma && (!beta || !mean || !var)) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean, var, eps,
                        bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+namespace {
+// same as prep_weights_bwd_kernel with the weight gradient given as fp32 split partials [splits][K][R*S][C]: phase 1
+// sums the splits in (rs, c) order (coalesced reads) into LDS, phase 2 walks (c, rs) order for the coalesced dw write.
+__global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const float* __restrict__ part, int splits,
+                                                                     const float* __restrict__ gbias,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ var, float eps, int K,
+                                                                     int C, int R, int S, float* __restrict__ dw,
+                                                                     float* __restrict__ dgamma) {
+    extern __shared__ float gsum[];            // [R*S][C]
+    __shared__ float red[16];
+    const int k = blockIdx.x;
+    const int RS = R * S, n = C * RS;
+    const size_t stride = (size_t)K * n;
+    const float* p0 = part + (size_t)k * n;
+    // 1024 threads: thread group q = tid / 256 takes every 4th split, 8 loads in flight per thread (the sum order is
+    // fixed: deterministic)
+    const int q4 = threadIdx.x >> 8, t256 = threadIdx.x & 255;
+    float* gq = gsum + n;                        // [4][n] partial sums of the four split groups
+    for (int j = t256; j < n; j += 256) {
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = q4;
+        for (; sp + 28 < splits; sp += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] += p0[(size_t)(sp + 4 * u) * stride + j];
+        }
+        for (int u = 0; sp < splits; sp += 4, ++u) acc8[u] += p0[(size_t)sp * stride + j];
+        gq[q4 * n + j] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += 1024) gsum[j] = (gq[j] + gq[n + j]) + (gq[2 * n + j] + gq[3 * n + j]);
+    __syncthreads();
+    const float sc = scale ? scale[k] : 1.f;
+    const float* wk = w + (size_t)k * n;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const int rs = i % RS, c = i / RS;
+        const float g = gsum[rs * C + c];
+        dw[(size_t)k * n + i] = g * sc;
+        dot += g * wk[i];
+    }
+    if (dgamma) {
+        const float tot = block_sum(dot, red);
+        if (threadIdx.x == 0) dgamma[k] = (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
+    }
+}
+}  // namespace
+
+extern "C" int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float* gbias, const float* w,
+                                                const float* scale, const float* mean, const float* var, float eps,
+                                                int K, int C, int R, int S, float* dw, float* dgamma, void* stream) {
+    if (!part || splits < 1 || !w || !dw) return OADG_EARG;
+    if (dgamma && (!mean || !var)) return OADG_EARG;
+    const size_t lds = 5 * (size_t)C * R * S * sizeof(float);
+    if (lds > 5 * 12000) return OADG_EARG;    // callers fall back to the reduced form
+    hipLaunchKernelGGL(prep_weights_bwd_parts_kernel, dim3(K), dim3(1024), lds, (hipStream_t)stream, part, splits, gbias,
+                       w, scale, mean, var, eps, K, C, R, S, dw, dgamma);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

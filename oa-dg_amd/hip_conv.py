@@ -87,11 +87,48 @@ def conv_wgrad(x16, gy16, K, R, S, stride, pad, dil):
     return dw.permute(0, 3, 1, 2)
 
 
+def conv_wgrad_parts(x16, gy16, K, R, S, stride, pad, dil):
+    """(workspace, splits): the weight gradient of y = conv(x, W) as fp32 split partials [splits][K][R*S][C]; summed
+    (with the BN-fold chain rule) by _PrepWeights.backward through oadg_prep_conv_weights_bwd_parts."""
+    import ctypes
+    L = _lib.lib()
+    N, C, H, W = x16.shape
+    Ho, Wo = gy16.shape[2], gy16.shape[3]
+    nbytes = L.oadg_conv2d_wgrad_workspace_bytes(N, Ho, Wo, C, K, R, S)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x16.device)
+    splits = ctypes.c_int(0)
+    check(L.oadg_conv2d_wgrad_parts_nhwc_bf16(ptr(x16), ptr(gy16), ptr(_zeros(x16.device)), ptr(ws), nbytes, N, H, W,
+                                              C, K, R, S, stride, pad, dil, ctypes.byref(splits), stream_ptr()),
+          'oadg_conv2d_wgrad_parts_nhwc_bf16')
+    return ws, splits.value
+
+
+class WeightGradToken:
+    """Hand-off of a weight gradient from the convolution's backward to the backward of its weight preparation
+    (one prepared weight <-> one convolution call; weights used by several calls, e.g. the RPN conv shared by the
+    pyramid levels, take the reduced path because autograd has to add their gradients)."""
+    __slots__ = ('uses', 'parts')
+
+    def __init__(self):
+        self.uses, self.parts = 0, None
+
+
+_ZERO_SCALARS = {}
+
+
+def _dummy_grad(like):
+    key = (like.device, like.dtype)
+    z = _ZERO_SCALARS.get(key)
+    if z is None:
+        z = _ZERO_SCALARS[key] = torch.zeros((), dtype=like.dtype, device=like.device)
+    return z.expand(like.shape)
+
+
 def _hip_wgrad(K, C, R, P):
-    """use csrc conv_wgrad256_kernel?  Measured on the bench shapes (MI355X): 1.17x MIOpen on the 3x3 at P2, 1.07x at
-    P3, 1.03-1.04x at P4 / layer3, 1.10-1.14x on layer4's 1x1; 0.8-0.97x elsewhere (those stay on MIOpen)."""
+    """use the csrc weight-gradient kernels?  With the per-shape kernel / split choice of conv_mfma.hip they match or
+    beat MIOpen's igemm_wrw on every layer with K and C multiples of 128 (tools/bench_conv.py --wgrad: 1.0-1.6x)."""
     if USE_HIP_WGRAD == 'auto':
-        return K % 256 == 0 and C % 256 == 0 and ((R == 3 and P >= 65536) or (R == 1 and 4096 <= P <= 16384))
+        return K % 128 == 0 and C % 128 == 0
     return bool(USE_HIP_WGRAD) and K % 128 == 0 and C % 128 == 0
 
 
@@ -123,7 +160,7 @@ class _PrepWeights(torch.autograd.Function):
     and casts; the backward is one launch as well."""
 
     @staticmethod
-    def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt):
+    def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt, wtoken=None):
         L = _lib.lib()
         K, C, R, S = w.shape
         leaf = all(t is None or t.grad_fn is None for t in (w, gamma, beta, bias_in))
@@ -143,6 +180,7 @@ class _PrepWeights(torch.autograd.Function):
         ctx.save_for_backward(w, scale, m_, v_)
         ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S)
         ctx.leaf_inputs = leaf      # False: autograd ops (not AccumulateGrad) consume the gradients next
+        ctx.wtoken = wtoken
         outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
         ctx.mark_non_differentiable(outs[2])
         return outs
@@ -162,7 +200,17 @@ class _PrepWeights(torch.autograd.Function):
                 if t_ is not None:
                     t_.record_stream(side)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-          if gwf is not None:
+          tok = ctx.wtoken
+          parts = None
+          if tok is not None and tok.parts is not None:
+            parts, tok.parts = tok.parts, None
+          if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
+            dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
+            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb), ptr(w), ptr(scale), ptr(mean),
+                                                     ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), stream_ptr()),
+                  'oadg_prep_conv_weights_bwd_parts')
+          elif gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
@@ -180,7 +228,7 @@ class _PrepWeights(torch.autograd.Function):
             dbeta = gb
         elif has_bias_in:
             dbias_in = gb
-        return dw, dgamma, dbeta, None, None, None, dbias_in, None
+        return dw, dgamma, dbeta, None, None, None, dbias_in, None, None
 
 
 def _wt_useful(x, K, C, stride, pad, dil, R):
@@ -200,12 +248,15 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
         c = getattr(cache_on, '_prepared', None)
         if c is not None and c[0] == key:
             return c[1]
+    tok = None if frozen else WeightGradToken()
     if bn is not None:
         out = _PrepWeights.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None,
-                                 want_wt)
+                                 want_wt, tok)
     else:
-        out = _PrepWeights.apply(conv_weight, None, None, None, None, 0.0, bias_in, want_wt)
+        out = _PrepWeights.apply(conv_weight, None, None, None, None, 0.0, bias_in, want_wt, tok)
     wf, bias, wt = out
+    if tok is not None:
+        wf._oadg_wtoken = tok
     out = (wf, bias if bias.numel() else None, wt if wt.numel() else None)
     if key is not None:
         cache_on._prepared = (key, out)
@@ -262,6 +313,9 @@ class _Conv2dMFMA(torch.autograd.Function):
         ctx.save_for_backward(x16, wf, wt, y if relu else None)
         ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, residual.dtype if residual is not None else None)
         ctx.tokens = (in_token, out_token, res_token)
+        ctx.wtoken = getattr(wf, '_oadg_wtoken', None)
+        if ctx.wtoken is not None:
+            ctx.wtoken.uses += 1
         return y
 
     @staticmethod
@@ -315,7 +369,12 @@ class _Conv2dMFMA(torch.autograd.Function):
             ctx_mgr = contextlib.nullcontext()
         with ctx_mgr:
             if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
-                gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
+                wtok = ctx.wtoken
+                if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000 and side is None:
+                    wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
+                    gw = _dummy_grad(wf)          # the real gradient rides on the token (fp32 partials)
+                else:
+                    gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
                 need_w = False
                 if want_b:
                     gb = gy.float().sum((0, 2, 3))
