@@ -269,8 +269,8 @@ typedef struct oadg_select_job {
     long out_off;
 } oadg_select_job;
 size_t oadg_sample_select_workspace_bytes(int jobs, long max_n);
-int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, const int* ranks_dev, int64_t* out,
-                       void* workspace, size_t workspace_bytes, void* stream);
+int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, int max_k, const int* ranks_dev,
+                       int64_t* out, void* workspace, size_t workspace_bytes, void* stream);   /* max_k = largest k */
 
 /* AnchorHead._get_targets_single for all images at once (mmdet/models/dense_heads/anchor_head.py:201-297, the
  * branch with every anchor inside the image, + DeltaXYWHBBoxCoder.encode delta_xywh_bbox_coder.py:119-180).

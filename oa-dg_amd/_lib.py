@@ -58,7 +58,7 @@ SIGNATURES = {
     'oadg_max_iou_assign': (ci, [vp, cl, vp, vp, vp, vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, ctypes.c_size_t, vp, vp, vp,
                                  vp, vp]),
     'oadg_sample_select_workspace_bytes': (ctypes.c_size_t, [ci, cl]),
-    'oadg_sample_select': (ci, [vp, ci, cl, vp, vp, vp, ctypes.c_size_t, vp]),
+    'oadg_sample_select': (ci, [vp, ci, cl, ci, vp, vp, vp, ctypes.c_size_t, vp]),
     'oadg_anchor_targets': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),

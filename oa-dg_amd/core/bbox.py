@@ -434,7 +434,8 @@ class PendingSampling:
         L = _lib.lib()
         nbytes = L.oadg_sample_select_workspace_bytes(nj, max_n)
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=dev)
-        _lib.check(L.oadg_sample_select(_lib.ptr(jobs_dev), nj, max_n, _lib.ptr(ranks_dev), _lib.ptr(sel),
+        _lib.check(L.oadg_sample_select(_lib.ptr(jobs_dev), nj, max_n, int(jobs['k'].max()) if nj else 0,
+                                        _lib.ptr(ranks_dev), _lib.ptr(sel),
                                         _lib.ptr(ws), nbytes, _lib.stream_ptr()), 'oadg_sample_select')
         self.device_select = dict(jobs_dev=jobs_dev, sel=sel, jobs=jobs, blob=blob_dev,
                                   max_k=int(jobs['k'].max()) if nj else 0)

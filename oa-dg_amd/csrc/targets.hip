@@ -32,26 +32,44 @@ __global__ __launch_bounds__(256) void sel_count_kernel(const oadg_select_job* _
     if (threadIdx.x == 0) cnt[(long)blockIdx.y * max_chunks + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// one workgroup per job: exclusive scan of the chunk counts in LDS, then one wave per requested rank
+// workgroup (x, job): exclusive scan of the job's chunk counts in LDS (every workgroup of the job repeats it: a few
+// KiB), then its four waves locate ranks 16x .. 16x+15 of the job, one rank per wave at a time
+constexpr int SEL_RANKS_PER_BLOCK = 16;
+
 __global__ __launch_bounds__(256) void sel_locate_kernel(const oadg_select_job* __restrict__ jobs,
                                                          const int* __restrict__ cnt, const int* __restrict__ ranks,
                                                          long long* __restrict__ out, int max_chunks) {
     __shared__ int pre[SEL_MAX_CHUNKS + 1];
-    __shared__ int carry;
-    const oadg_select_job jb = jobs[blockIdx.x];
-    if (jb.k <= 0) return;
+    __shared__ int wsum[4];
+    const oadg_select_job jb = jobs[blockIdx.y];
+    const int r0 = blockIdx.x * SEL_RANKS_PER_BLOCK;
+    if (r0 >= jb.k) return;
     const int nch = (int)((jb.n + SEL_CHUNK - 1) / SEL_CHUNK);
-    const int* c = cnt + (long)blockIdx.x * max_chunks;
-    if (threadIdx.x == 0) {          // chunk counts are few (<= 8192): a serial prefix is a few microseconds
-        int s = 0;
-        for (int i = 0; i < nch; ++i) { pre[i] = s; s += c[i]; }
-        pre[nch] = s;
-        carry = s;
+    const int* c = cnt + (long)blockIdx.y * max_chunks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // block-wide exclusive scan, 256 chunks per round
+    int carry = 0;
+    for (int base = 0; base < nch; base += 256) {
+        const int i = base + threadIdx.x;
+        const int v = i < nch ? c[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (i < nch) pre[i] = carry + woff + incl - v;
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) pre[nch] = carry;
     __syncthreads();
     const long long* v = (const long long*)jb.gt_inds;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < jb.k; i += 4) {
+    for (int i = r0 + wave; i < jb.k && i < r0 + SEL_RANKS_PER_BLOCK; i += 4) {
         const int r = jb.all ? i : ranks[jb.rank_off + i];
         if (r >= carry) continue;                      // cannot happen with consistent counts
         int lo = 0, hi = nch;                          // largest b with pre[b] <= r
@@ -67,7 +85,6 @@ __global__ __launch_bounds__(256) void sel_locate_kernel(const oadg_select_job* 
             const unsigned long long bal = __ballot(m);
             const int pc = __popcll(bal);
             if (need < pc) {
-                // position of the need-th set bit
                 const int before = __popcll(bal & ((1ull << lane) - 1ull));
                 if (m && before == need) out[jb.out_off + i] = n;
                 break;
@@ -154,18 +171,19 @@ extern "C" size_t oadg_sample_select_workspace_bytes(int jobs, long max_n) {
     return (size_t)jobs * (size_t)(ch > 0 ? ch : 1) * sizeof(int);
 }
 
-extern "C" int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, const int* ranks_dev,
-                                  int64_t* out, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int oadg_sample_select(const oadg_select_job* jobs_dev, int jobs, long max_n, int max_k,
+                                  const int* ranks_dev, int64_t* out, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
     if (!jobs_dev || jobs < 1 || max_n < 0 || !out || !workspace) return OADG_EARG;
     const long ch = (max_n + SEL_CHUNK - 1) / SEL_CHUNK;
     if (ch > SEL_MAX_CHUNKS) return OADG_EARG;
     if (workspace_bytes < oadg_sample_select_workspace_bytes(jobs, max_n)) return OADG_ESIZE;
-    if (max_n == 0) return OADG_OK;
+    if (max_n == 0 || max_k <= 0) return OADG_OK;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sel_count_kernel, dim3((unsigned)ch, jobs), dim3(256), 0, st, jobs_dev, (int*)workspace, (int)ch);
     OADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sel_locate_kernel, dim3(jobs), dim3(256), 0, st, jobs_dev, (const int*)workspace, ranks_dev,
-                       (long long*)out, (int)ch);
+    hipLaunchKernelGGL(sel_locate_kernel, dim3((max_k + SEL_RANKS_PER_BLOCK - 1) / SEL_RANKS_PER_BLOCK, jobs), dim3(256), 0,
+                       st, jobs_dev, (const int*)workspace, ranks_dev, (long long*)out, (int)ch);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -370,7 +370,7 @@ class _Conv2dMFMA(torch.autograd.Function):
         with ctx_mgr:
             if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
                 wtok = ctx.wtoken
-                if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000 and side is None:
+                if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
                     wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
                     gw = _dummy_grad(wf)          # the real gradient rides on the token (fp32 partials)
                 else:
