@@ -345,3 +345,32 @@ def test_rpn_head_fused_cls_reg_matches_separate_convs(dev):
     for n in res['separate'][3]:
         upstream = n.startswith('rpn_conv')
         close(res['fused'][3][n], res['separate'][3][n], n, 0.25 if upstream else 3e-2, 8e-2 if upstream else 1e-2)
+
+
+def test_shared_weight_gradients_accumulate(dev):
+    """A prepared weight used by two convolution calls (the RPN conv is shared by the pyramid levels): the
+    WeightGradToken hand-off must step aside (autograd has to add the two gradients) and the result must equal the
+    fp32 reference; a single use takes the fused partial-sum path - both are checked."""
+    from oadg_amd import hip_conv
+    hip_conv.enable(True)
+    try:
+        g = torch.Generator(device=dev).manual_seed(4)
+        conv = torch.nn.Conv2d(128, 128, 3, padding=1).to(dev)
+        xs = [torch.randn(2, 128, h, w, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+              for h, w in ((24, 40), (12, 20))]
+        gys = [torch.randn(2, 128, h, w, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+               for h, w in ((24, 40), (12, 20))]
+        for uses in (2, 1):
+            conv.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                wf, b, wt = hip_conv.prepared(conv.weight, None, conv.bias, False)
+                ys = [hip_conv._Conv2dMFMA.apply(x, wf, b, None, wt, 1, 1, 1, False, None, None, None) for x in xs[:uses]]
+            torch.autograd.backward(ys, gys[:uses])
+            w32 = conv.weight.detach().bfloat16().float().requires_grad_(True)
+            b32 = conv.bias.detach().clone().requires_grad_(True)
+            refs = [F.conv2d(x.float(), w32, b32, 1, 1) for x in xs[:uses]]
+            torch.autograd.backward(refs, [gy.float() for gy in gys[:uses]])
+            for got, ref in ((conv.weight.grad, w32.grad), (conv.bias.grad, b32.grad)):
+                assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item(), uses
+    finally:
+        hip_conv.enable(False)
