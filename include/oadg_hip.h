@@ -156,6 +156,16 @@ int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_hos
                          int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Geometric pipeline steps in front of OA-Mix on uint8 HWC images
+ *   oadg_resize_bilinear_u8  Resize._resize_img  mmdet/datasets/pipelines/transforms.py:210-239
+ *                            (mmcv.imrescale / imresize -> cv2.resize INTER_LINEAR, 8-bit fixed-point path)
+ *   oadg_flip_u8             RandomFlip.__call__ transforms.py:452-457 (mmcv.imflip); direction 1 horizontal,
+ *                            2 vertical, 3 diagonal; src != dst
+ */
+int oadg_resize_bilinear_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int Hn, int Wn, void* stream);
+int oadg_flip_u8(const uint8_t* src, int H, int W, int C, uint8_t* dst, int direction, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * NHWC bf16 implicit-GEMM convolution on the MFMA cores, fused bias / residual / ReLU epilogue
  *   replaces the cuDNN convolutions of  mmdet/models/necks/fpn.py:112-129, dense_heads/rpn_head.py:54-68,
  *   backbones/resnet.py:166-205 (with the eval-mode BN of :648-657 folded into w / bias)

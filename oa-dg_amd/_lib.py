@@ -37,6 +37,8 @@ SIGNATURES = {
                                 vp, ci, ci, ci, ci, ci, vp, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
+    'oadg_resize_bilinear_u8': (ci, [vp, ci, ci, ci, vp, ci, ci, vp]),
+    'oadg_flip_u8': (ci, [vp, ci, ci, ci, vp, ci, vp]),
     'oadg_conv2d_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 11 + [vp]),
     'oadg_conv2d_auto_variant': (ci, [ci] * 10),
     'oadg_conv2d_nhwc_bf16_ex': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp, vp, vp]),

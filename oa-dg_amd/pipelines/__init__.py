@@ -2,3 +2,4 @@
 from .oa_mix import OAMix  # noqa: F401
 from .device_pipeline import (Collect, Compose, DefaultFormatBundle, DevicePipeline, Normalize, Pad,  # noqa: F401
                               SyntheticCityscapes)
+from .geometric import LoadAnnotations, LoadImageFromFile, RandomFlip, Resize  # noqa: F401

@@ -15,6 +15,7 @@ import torch
 from .. import _lib
 from .._lib import check, ptr, stream_ptr
 from ..registry import DATASETS, PIPELINES, build_from_cfg
+from .geometric import RandomFlip, Resize
 from .oa_mix import OAMix, _ImageState
 
 
@@ -74,9 +75,15 @@ class Compose:
 class DevicePipeline:
     """Batched device execution of [OAMix,] Normalize, Pad, DefaultFormatBundle, Collect."""
 
-    def __init__(self, pipeline_cfg, dtype=torch.float32):
+    def __init__(self, pipeline_cfg, dtype=torch.float32, one_scale_per_batch=False):
+        """``one_scale_per_batch``: a multi-scale Resize draws its scale once per batch instead of once per sample
+        (deviation from the reference, which pads differently sized samples in collate; the batched device pipeline and
+        the batched proposal decoding need one image shape per batch)."""
+        self.one_scale_per_batch = one_scale_per_batch
         ts = Compose(pipeline_cfg).transforms
         self.oamix = next((t for t in ts if isinstance(t, OAMix)), None)
+        self.resize = next((t for t in ts if isinstance(t, Resize)), None)
+        self.flip = next((t for t in ts if isinstance(t, RandomFlip)), None)
         self.norm = next((t for t in ts if isinstance(t, Normalize)), None)
         self.pad = next((t for t in ts if isinstance(t, Pad)), None)
         collect = next((t for t in ts if isinstance(t, Collect)), None)
@@ -123,6 +130,28 @@ class DevicePipeline:
         """imgs_u8: uint8 [N,H,W,3] cuda tensor (BGR bytes); gt_bboxes: list of float32 [n_i,4] numpy arrays;
         gt_labels: list of int64 numpy arrays.  Returns the collated dict for ``train_step``."""
         L = _lib.lib()
+        geo_meta = None
+        if self.resize is not None or (self.flip is not None and self.flip.flip_ratio):
+            # Resize / RandomFlip per sample, in the reference's order (all draws of a sample's geometric steps, then
+            # the next sample; OA-Mix draws follow below - a DataLoader worker interleaves them per sample, which is
+            # the same stream split whenever OA-Mix gets its own worker stream)
+            imgs, boxes, geo_meta = [], [], []
+            for i in range(imgs_u8.shape[0]):
+                im, bx, meta = imgs_u8[i], np.asarray(gt_bboxes[i], dtype=np.float32), {}
+                if self.resize is not None:
+                    shared = geo_meta[0]['scale'] if (self.one_scale_per_batch and geo_meta) else None
+                    im, bx, m = self.resize(im, bx, scale=shared)
+                    meta.update(m)
+                if self.flip is not None and self.flip.flip_ratio:
+                    im, bx, m = self.flip(im, bx)
+                    meta.update(m)
+                imgs.append(im)
+                boxes.append(bx)
+                geo_meta.append(meta)
+            if any(im.shape != imgs[0].shape for im in imgs):
+                raise NotImplementedError('multi-scale Resize produced different image shapes inside one batch; the '
+                                          'batched device pipeline needs one shape per batch (use one img_scale)')
+            imgs_u8, gt_bboxes = torch.stack(imgs), boxes
         N, H, W = imgs_u8.shape[:3]
         dev = imgs_u8.device
         Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
@@ -145,6 +174,9 @@ class DevicePipeline:
         out['img_metas'] = [dict(img_shape=shape, pad_shape=pshape, ori_shape=shape, scale_factor=1.0, flip=False,
                                  gt_bboxes_np=np.ascontiguousarray(gt_bboxes[i], dtype=np.float32))
                             for i in range(N)]
+        if geo_meta is not None:
+            for m, g in zip(out['img_metas'], geo_meta):
+                m.update({k: v for k, v in g.items() if k != 'img_shape'})
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).pin_memory().to(  # noqa: E731
             dev, non_blocking=True)
         out['gt_bboxes'] = [up(b, np.float32) for b in gt_bboxes]

@@ -325,3 +325,43 @@ def saliency_score(img_crop):
     """oa_mix.py:107-111: mean of uint8(saliency_map * 255)."""
     sal = spectral_residual_saliency(img_crop)
     return np.mean((sal * 255).astype('uint8'))
+
+
+def resize_u8_cv2(src, dsize):
+    """cv2.resize(src uint8 [H,W(,C)], (Wn, Hn), interpolation=INTER_LINEAR): OpenCV's 8-bit fixed-point path
+    (resize.cpp: HResizeLinear / VResizeLinear<uchar,int,short>, INTER_RESIZE_COEF_BITS = 11), restated; the HIP
+    kernel csrc/imgxform.hip follows the same text.  PARITY UNPINNED (OpenCV not installed, no reference vectors)."""
+    src = np.asarray(src)
+    assert src.dtype == np.uint8
+    Wn, Hn = int(dsize[0]), int(dsize[1])
+    H, W = src.shape[:2]
+    s3 = src.reshape(H, W, -1).astype(np.int64)
+    dx = np.arange(Wn)
+    fx = ((dx + 0.5) * (np.float64(W) / Wn) - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = (fx - sx.astype(np.float32)).astype(np.float32)
+    lo, hi = sx < 0, sx >= W - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, W - 1, sx))
+    x1 = np.minimum(sx + 1, W - 1)
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    dy = np.arange(Hn)
+    fy = ((dy + 0.5) * (np.float64(H) / Hn) - 0.5).astype(np.float32)
+    sy = np.floor(fy).astype(np.int64)
+    fy = (fy - sy.astype(np.float32)).astype(np.float32)
+    y0, y1 = np.clip(sy, 0, H - 1), np.clip(sy + 1, 0, H - 1)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+    hrow = s3[:, sx, :] * a0[None, :, None] + s3[:, x1, :] * a1[None, :, None]          # [H, Wn, C]
+    h0, h1 = hrow[y0], hrow[y1]
+    v = (((b0[:, None, None] * (h0 >> 4)) >> 16) + ((b1[:, None, None] * (h1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(v, 0, 255).astype(np.uint8)
+    return out.reshape((Hn, Wn) + src.shape[2:])
+
+
+def imrescale_size(w, h, scale):
+    """mmcv.rescale_size for a (long, short) tuple scale: (new_w, new_h) with int(x * f + 0.5), and f."""
+    max_long, max_short = max(scale), min(scale)
+    f = min(max_long / max(h, w), max_short / min(h, w))
+    return int(w * float(f) + 0.5), int(h * float(f) + 0.5), f

@@ -121,7 +121,7 @@ def main():
         dcfg = dcfg.dataset
     ds_args = {k: v for k, v in dcfg.items() if k in ('img_shape', 'num_boxes', 'num_classes', 'length', 'box_size')}
     ds = SyntheticCityscapes(seed=seed + rank, device=dev, **ds_args)
-    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32)
+    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32, one_scale_per_batch=True)
     bs = cfg.data.get('samples_per_gpu', 2)
     epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
     iters_per_epoch = len(ds) // (bs * world)
