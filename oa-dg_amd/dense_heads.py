@@ -356,6 +356,10 @@ class RPNHead(AnchorHead):
                               gt_bboxes_ignore=gt_bboxes_ignore)
         return dict(loss_rpn_cls=losses['loss_cls'], loss_rpn_bbox=losses['loss_bbox'])
 
+    def simple_test_rpn(self, x, img_metas):
+        """dense_test_mixins.py:118-133"""
+        return self.get_bboxes(*self(x), img_metas=img_metas)
+
     @torch.no_grad()
     def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, num_imgs=None, padded=False,
                    **kwargs):

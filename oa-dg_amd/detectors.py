@@ -71,7 +71,22 @@ class BaseDetector(nn.Module):
     def forward(self, img, img_metas, return_loss=True, **kwargs):
         if return_loss:
             return self.forward_train(img, img_metas, **kwargs)
-        raise NotImplementedError('inference is outside the training hot path')
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:170-212: ``imgs`` / ``img_metas`` are lists with one entry per test-time augmentation."""
+        if isinstance(imgs, torch.Tensor):
+            imgs, img_metas = [imgs], [img_metas]
+        if len(imgs) != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        for img, metas in zip(imgs, img_metas):
+            for m in metas:
+                m['batch_input_shape'] = tuple(img.size()[-2:])
+        if len(imgs) == 1:
+            if 'proposals' in kwargs:
+                kwargs['proposals'] = kwargs['proposals'][0]
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        raise NotImplementedError('aug_test (multi-scale / flip test-time augmentation) is not built')
 
     def _parse_losses(self, losses):
         """base.py:234-277.  Same keys and values; the per-variable all-reduces + .item() of the reference
@@ -212,6 +227,14 @@ class TwoStageDetector(BaseDetector):
                                                   gt_bboxes_ignore, gt_masks,
                                                   pending_sampling=pending.get('roi'), **kwargs))
         return losses
+
+    @torch.no_grad()
+    def simple_test(self, img, img_metas, proposals=None, rescale=False, **kwargs):
+        """two_stage.py:224-266 without the debug / visualisation branches."""
+        x = self.extract_feat(img)
+        self.fpn_features = x
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
 
     def get_random_proposal_list(self, img, gt_bboxes, kwargs):
         """two_stage.py:162-204, quirks kept: OA-Mix boxes are filtered against image 0's gts (:178,186);

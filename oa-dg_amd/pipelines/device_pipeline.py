@@ -58,6 +58,25 @@ class Collect:
         self.keys, self.meta_keys = keys, meta_keys
 
 
+@PIPELINES.register_module()
+class ImageToTensor:
+    def __init__(self, keys):
+        self.keys = keys
+
+
+@PIPELINES.register_module()
+class MultiScaleFlipAug:
+    """test_time_aug.py:12-121, the single-scale no-flip case the reference's test configs use
+    (``img_scale=(2048, 1024), flip=False``); it carries the scale and its inner transform list."""
+
+    def __init__(self, transforms, img_scale=None, scale_factor=None, flip=False, flip_direction='horizontal'):
+        assert (img_scale is None) ^ (scale_factor is None), 'Must have but only one variable can be set'
+        self.img_scale = img_scale if isinstance(img_scale, list) else [img_scale]
+        self.scale_factor = scale_factor
+        self.flip, self.flip_direction = flip, flip_direction
+        self.transforms = Compose(transforms)
+
+
 class Compose:
     """mmdet/datasets/pipelines/compose.py: build each transform from the PIPELINES registry."""
 
@@ -81,6 +100,9 @@ class DevicePipeline:
         the batched proposal decoding need one image shape per batch)."""
         self.one_scale_per_batch = one_scale_per_batch
         ts = Compose(pipeline_cfg).transforms
+        self.test_aug = next((t for t in ts if isinstance(t, MultiScaleFlipAug)), None)
+        if self.test_aug is not None:        # test pipeline: the transforms live inside MultiScaleFlipAug
+            ts = self.test_aug.transforms.transforms
         self.oamix = next((t for t in ts if isinstance(t, OAMix)), None)
         self.resize = next((t for t in ts if isinstance(t, Resize)), None)
         self.flip = next((t for t in ts if isinstance(t, RandomFlip)), None)
@@ -90,6 +112,38 @@ class DevicePipeline:
         self.keys = list(collect.keys) if collect else ['img', 'gt_bboxes', 'gt_labels']
         assert self.norm is not None, 'the pipeline needs a Normalize step'
         self.dtype = dtype
+
+    @torch.no_grad()
+    def test_batch(self, imgs_u8):
+        """The reference's test pipeline (MultiScaleFlipAug(img_scale, flip=False)[Resize(keep_ratio), RandomFlip,
+        Normalize, Pad, ImageToTensor, Collect]) for a resident uint8 batch: returns ``dict(img=[tensor],
+        img_metas=[[meta, ...]])`` as ``forward_test`` expects (one augmentation)."""
+        assert self.test_aug is not None and not self.test_aug.flip and len(self.test_aug.img_scale) == 1, \
+            'single-scale, no-flip testing (multi-scale / flip test-time augmentation is not built)'
+        L = _lib.lib()
+        N, H0, W0 = imgs_u8.shape[:3]
+        scale = self.test_aug.img_scale[0]
+        imgs, metas = [], []
+        for i in range(N):
+            im, meta = imgs_u8[i], dict(ori_shape=(H0, W0, 3), flip=False, flip_direction=None,
+                                        scale_factor=np.ones(4, dtype=np.float32))
+            if self.resize is not None and scale is not None:
+                im, _, m = self.resize(im, np.zeros((0, 4), np.float32), scale=scale)
+                meta.update(m)
+            imgs.append(im)
+            metas.append(meta)
+        H, W = imgs[0].shape[:2]
+        Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
+        na = self.norm.as_args()
+        mean, stdinv = (ctypes.c_float * 3)(*na['mean']), (ctypes.c_float * 3)(*na['stdinv'])
+        img = torch.empty((N, 3, Hp, Wp), dtype=self.dtype, device=imgs_u8.device, memory_format=torch.channels_last)
+        for i in range(N):
+            check(L.oadg_oamix_normalize(ptr(imgs[i].contiguous()), H, W, mean, stdinv, int(na['to_rgb']),
+                                         ctypes.c_void_p(img.data_ptr() + i * img.stride(0) * img.element_size()),
+                                         1 if self.dtype == torch.bfloat16 else 0, Hp, Wp, stream_ptr()),
+                  'oadg_oamix_normalize')
+            metas[i].update(img_shape=(H, W, 3), pad_shape=(Hp, Wp, 3))
+        return dict(img=[img], img_metas=[metas])
 
     def prefetch(self, imgs_u8, gt_bboxes, gt_labels, worker_seed=None):
         """Enqueue the whole pipeline for one batch on a side stream and return a handle (``.get()``).

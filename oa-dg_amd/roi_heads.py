@@ -3,9 +3,11 @@
 RoI feature extraction is one HIP launch over the whole pyramid (level mapping in-kernel) instead of the
 reference's per-level nonzero/gather/scatter loop; every pyramid level is therefore always in the autograd
 graph (the reference needs a dummy-graph trick for that, single_level_roi_extractor.py:136-145)."""
+import numpy as np
 import torch
 from torch.profiler import record_function as _rf
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import hip_ops
 from .core import bbox2roi, multi_apply
@@ -160,6 +162,24 @@ class BBoxHead(nn.Module):
                                               concat)[:4]
 
     # -- loss ------------------------------------------------------------------------------------------
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """bbox_head.py:468-530: softmax scores, decode per class, undo the test-time resize, multiclass NMS."""
+        from .core import multiclass_nms
+        scores = F.softmax(cls_score.float(), dim=-1) if cls_score is not None else None
+        if bbox_pred is not None:
+            bboxes = self.bbox_coder.decode(rois[..., 1:], bbox_pred.float(), max_shape=img_shape)
+        else:
+            bboxes = rois[:, 1:].clone()
+            if img_shape is not None:
+                bboxes[:, [0, 2]] = bboxes[:, [0, 2]].clamp(min=0, max=img_shape[1])
+                bboxes[:, [1, 3]] = bboxes[:, [1, 3]].clamp(min=0, max=img_shape[0])
+        if rescale and bboxes.size(0) > 0:
+            sf = torch.as_tensor(np.asarray(scale_factor, dtype=np.float32)).to(bboxes.device)
+            bboxes = (bboxes.view(bboxes.size(0), -1, 4) / sf).view(bboxes.size(0), -1)
+        if cfg is None:
+            return bboxes, scores
+        return multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms, cfg.max_per_img)
+
     def _cls_reg_losses(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
                         avg_factor, reduction_override=None, pos_rows=None):
         losses = dict()
@@ -414,6 +434,43 @@ class StandardRoIHead(BaseRoIHead):
                 sampling_results.extend(first)
         bbox_results = self._bbox_forward_train(x, sampling_results, gt_bboxes, gt_labels, img_metas, **kwargs)
         return dict(bbox_results['loss_bbox'])
+
+    @torch.no_grad()
+    def simple_test_bboxes(self, x, img_metas, proposals, rcnn_test_cfg, rescale=False):
+        """test_mixins.py:51-137"""
+        rois = bbox2roi(proposals)
+        if rois.shape[0] == 0:
+            det_bbox, det_label = rois.new_zeros(0, 5), rois.new_zeros((0,), dtype=torch.long)
+            if rcnn_test_cfg is None:
+                det_bbox, det_label = det_bbox[:, :4], rois.new_zeros((0, self.bbox_head.fc_cls.out_features))
+            return [det_bbox] * len(proposals), [det_label] * len(proposals)
+        bbox_results = self._bbox_forward(x, rois)
+        self.bbox_results = bbox_results
+        num_per_img = tuple(len(p) for p in proposals)
+        rois = rois.split(num_per_img, 0)
+        cls_score = bbox_results['cls_score'].split(num_per_img, 0)
+        bbox_pred = bbox_results['bbox_pred']
+        bbox_pred = bbox_pred.split(num_per_img, 0) if bbox_pred is not None else (None,) * len(proposals)
+        det_bboxes, det_labels = [], []
+        for i in range(len(proposals)):
+            if rois[i].shape[0] == 0:
+                det_bbox, det_label = rois[i].new_zeros(0, 5), rois[i].new_zeros((0,), dtype=torch.long)
+                if rcnn_test_cfg is None:
+                    det_bbox = det_bbox[:, :4]
+                    det_label = rois[i].new_zeros((0, self.bbox_head.fc_cls.out_features))
+            else:
+                det_bbox, det_label = self.bbox_head.get_bboxes(rois[i], cls_score[i], bbox_pred[i],
+                                                                img_metas[i]['img_shape'], img_metas[i]['scale_factor'],
+                                                                rescale=rescale, cfg=rcnn_test_cfg)
+            det_bboxes.append(det_bbox)
+            det_labels.append(det_label)
+        return det_bboxes, det_labels
+
+    def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
+        """standard_roi_head.py:392-436 (no mask branch): per image a list over classes of [k, 5] numpy arrays."""
+        from .core import bbox2result
+        det_bboxes, det_labels = self.simple_test_bboxes(x, img_metas, proposal_list, self.test_cfg, rescale=rescale)
+        return [bbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes) for i in range(len(det_bboxes))]
 
     def _bbox_forward(self, x, rois):
         feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)

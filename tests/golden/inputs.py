@@ -93,3 +93,19 @@ def model_batch(seed, n_img, h, w, n_gt=12, n_cls=8):
         oab.append(np.round(synthetic_boxes(rs, rs.randint(1, 4), h, w, 8, 60)).astype(np.int64))
     return dict(img=np.stack(img), img2=np.stack(img2), gt_bboxes=gtb, gt_labels=gtl, multilevel_boxes=mlb,
                 oamix_boxes=oab)
+
+
+def postproc_inputs(seed, n, num_classes, per_class, W=512, H=256):
+    """RoI-head outputs for multiclass_nms: clustered boxes [n, C*4 or 4] and softmax-like scores [n, C+1]."""
+    rs = np.random.RandomState(4000 + seed)
+    centers = rs.uniform([20, 20], [W - 20, H - 20], size=(max(n // 12, 1), 2))
+    c = centers[rs.randint(0, len(centers), n)] + rs.normal(0, 6, size=(n, 2))
+    wh = rs.uniform(10, 80, size=(n, 2))
+    base = np.concatenate([c - wh / 2, c + wh / 2], axis=1)
+    if per_class:
+        boxes = (base[:, None, :] + rs.normal(0, 2, size=(n, num_classes, 4))).reshape(n, -1)
+    else:
+        boxes = base
+    logits = rs.normal(0, 2.0, size=(n, num_classes + 1))
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    return boxes.astype(np.float32), (e / e.sum(1, keepdims=True)).astype(np.float32)

@@ -119,5 +119,34 @@ def main(h=256, w=512, n_img=2, seed=0):
     print('wrote', f'model_step_{h}x{w}.npz', {k: v for k, v in out.items() if k.startswith('lv_') or k.startswith('n_')})
 
 
+def main_test(h=256, w=512, n_img=2, seed=0):
+    """Inference path: reference ``TwoStageDetector.simple_test`` (two_stage.py:224-266) -> ``simple_test_rpn`` ->
+    ``StandardRoIHead.simple_test`` -> ``BBoxHead.get_bboxes`` -> ``multiclass_nms`` -> ``bbox2result`` on the same
+    seeded batch and name-seeded weights, eval mode, rescale=True with a non-trivial scale factor."""
+    det = build_reference_detector()
+    load_named(det)
+    det.eval()
+    batch = model_batch(seed, n_img, h, w)
+    img = torch.tensor(batch['img'])
+    sf = np.array([1.25, 1.25, 1.25, 1.25], dtype=np.float32)
+    metas = [dict(img_shape=(h, w, 3), pad_shape=(h, w, 3), ori_shape=(int(h / 1.25), int(w / 1.25), 3), scale_factor=sf,
+                  flip=False, ori_filename=f'{i}.png') for i in range(n_img)]
+    with torch.no_grad():
+        x = det.extract_feat(img)
+        props = det.rpn_head.simple_test_rpn(x, metas)
+        results = det.simple_test(img, metas, rescale=True)
+    out = dict(h=np.int64(h), w=np.int64(w), n_img=np.int64(n_img), seed=np.int64(seed), scale_factor=sf)
+    for i in range(n_img):
+        out[f'proposals{i}'] = props[i].numpy().copy()
+        for c, arr in enumerate(results[i]):
+            out[f'det{i}_c{c}'] = np.asarray(arr, dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, f'model_test_{h}x{w}.npz'), **out)
+    print('wrote', f'model_test_{h}x{w}.npz', [len(p) for p in props],
+          [[len(a) for a in r] for r in results])
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'test':
+        main_test()
+    else:
+        main()
