@@ -500,13 +500,20 @@ class ContrastiveRoIHead(StandardRoIHead):
                             gt_instance_inds=None, **kwargs):
         with _rf('sec:roi_bbox_forward'):
             rois = bbox2roi([r.bboxes for r in sampling_results])
-            res = self._bbox_forward(x, rois)
             self._last_rois = [rois.detach()]
             if 'random_proposal_list' in kwargs:
+                # the reference runs extractor + head a second time on the random proposals and keeps only their
+                # contrastive features (contrastive_roi_head.py:131-137); one pass over both RoI sets is the same
+                # function row for row and halves the RoIAlign backward's full-pyramid gradient traffic (one fp32
+                # scatter buffer, one cast, no accumulation add per level)
                 rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
-                res2 = self._bbox_forward(x, rois2)
-                res['cont_feats'] = torch.cat([res['cont_feats'], res2['cont_feats']], dim=0)
+                K = rois.shape[0]
+                both = self._bbox_forward(x, torch.cat([rois, rois2], dim=0))
+                res = dict(cls_score=both['cls_score'][:K], bbox_pred=both['bbox_pred'][:K],
+                           cont_feats=both['cont_feats'], bbox_feats=both['bbox_feats'][:K])
                 self._last_rois.append(rois2.detach())
+            else:
+                res = self._bbox_forward(x, rois)
         with _rf('sec:roi_targets'):
             targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
                                                                self.train_cfg)
