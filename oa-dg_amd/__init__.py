@@ -13,4 +13,4 @@ from . import registry  # noqa: F401
 from .config import Config, ConfigDict  # noqa: F401
 from .registry import (MODELS, PIPELINES, build_detector, build_from_cfg)  # noqa: F401
 # importing the modules populates the registries with the reference's type strings
-from . import core, losses, backbones, necks, dense_heads, roi_heads, detectors, pipelines  # noqa: F401,E402
+from . import core, losses, backbones, necks, dense_heads, roi_heads, detectors, pipelines, datasets  # noqa: F401,E402

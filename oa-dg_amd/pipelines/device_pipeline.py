@@ -300,7 +300,7 @@ class SyntheticCityscapes:
     boxes per image with sides U(24,400) clipped to the image, labels U{0..7}.  Seeded per (seed, index)."""
 
     def __init__(self, img_shape=(1024, 2048), num_boxes=20, num_classes=8, length=2975, pipeline=None,
-                 box_size=(24, 400), seed=0, device='cuda'):
+                 box_size=(24, 400), seed=0, device='cuda', test_mode=False):
         self.img_shape, self.num_boxes, self.num_classes = tuple(img_shape), num_boxes, num_classes
         self.length, self.box_size, self.seed, self.device = length, box_size, seed, device
         self.pipeline_cfg = pipeline

@@ -1,0 +1,117 @@
+"""COCO-format / Cityscapes dataset loading (oadg_amd/datasets.py; mmdet/datasets/{coco,cityscapes}.py): a tiny
+dataset written to disk - annotation filtering rules, image filtering, PNG decode in BGR order, RepeatDataset."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    imgs, images, anns = {}, [], []
+    for i, (h, w) in enumerate([(40, 64), (40, 64), (40, 64), (40, 64), (20, 64)]):
+        arr = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)         # RGB on disk
+        os.makedirs(tmp_path / 'img' / 'city', exist_ok=True)
+        Image.fromarray(arr).save(tmp_path / 'img' / 'city' / f'{i}.png')
+        imgs[i] = arr
+        images.append(dict(id=100 + i, file_name=f'city/{i}.png', height=h, width=w, segm_file=f'{i}_seg.png'))
+    cats = [dict(id=24, name='person'), dict(id=26, name='car'), dict(id=99, name='unicorn')]
+
+    def ann(aid, img, cat, box, crowd=0, area=None, **kw):
+        return dict(id=aid, image_id=100 + img, category_id=cat, bbox=box, iscrowd=crowd,
+                    area=box[2] * box[3] if area is None else area, segmentation=[], **kw)
+    anns += [ann(1, 0, 26, [5, 6, 20, 10]), ann(2, 0, 24, [1.5, 2.5, 8, 9]), ann(3, 0, 26, [30, 3, 10, 10], crowd=1),
+             ann(4, 0, 26, [3, 3, 0.5, 9]), ann(5, 0, 99, [3, 3, 9, 9]), ann(6, 0, 24, [3, 3, 9, 9], area=0),
+             ann(7, 0, 24, [3, 3, 9, 9], ignore=True)]
+    anns += [ann(8, 1, 26, [10, 10, 12, 12], crowd=1)]           # image 1: only crowd -> dropped by Cityscapes
+    anns += [ann(9, 2, 99, [10, 10, 12, 12])]                    # image 2: no annotation of a wanted class
+    anns += [ann(10, 4, 26, [10, 5, 12, 12])]                    # image 4: smaller than min_size 32
+    # image 3: no annotations at all
+    with open(tmp_path / 'ann.json', 'w') as f:
+        json.dump(dict(images=images, annotations=anns, categories=cats), f)
+    return imgs
+
+
+def test_cityscapes_dataset_parsing_and_decode(tmp_path):
+    from oadg_amd.datasets import build_dataset
+    imgs = _write(tmp_path)
+    cfg = dict(type='RepeatDataset', times=3,
+               dataset=dict(type='CityscapesDataset', ann_file=str(tmp_path / 'ann.json'),
+                            img_prefix=str(tmp_path / 'img') + '/', pipeline=[]))
+    ds = build_dataset(cfg, default_args=dict(device='cpu'))
+    inner = ds.dataset
+    assert inner.cat_ids == [24, 26] and inner.cat2label == {24: 0, 26: 1}      # file order, not CLASSES order
+    assert [d['id'] for d in inner.data_infos] == [100] and len(ds) == 3
+    a = inner.get_ann_info(0)
+    assert np.array_equal(a['bboxes'], np.array([[5, 6, 25, 16], [1.5, 2.5, 9.5, 11.5]], np.float32))
+    assert np.array_equal(a['labels'], np.array([1, 0])) and a['labels'].dtype == np.int64
+    assert np.array_equal(a['bboxes_ignore'], np.array([[30, 3, 40, 13]], np.float32))
+    batch, boxes, labels = ds.batch([0, 1, 2])
+    assert batch.shape == (3, 40, 64, 3) and batch.dtype == torch.uint8
+    assert np.array_equal(batch[1].numpy(), imgs[0][:, :, ::-1])                # BGR, as cv2 / mmcv.imfrombytes
+    assert np.array_equal(boxes[2], a['bboxes'])
+    # test_mode keeps every image, in file order
+    t = build_dataset(dict(type='CityscapesDataset', ann_file=str(tmp_path / 'ann.json'), test_mode=True,
+                           img_prefix=str(tmp_path / 'img')), default_args=dict(device='cpu'))
+    assert len(t) == 5 and t.get_ann_info(3)['bboxes'].shape == (0, 4)
+    # plain CocoDataset keeps the crowd-only image (coco.py:99-121) and applies the in-image intersection rule
+    c = build_dataset(dict(type='CocoDataset', classes=('person', 'car'), ann_file='ann.json', data_root=str(tmp_path),
+                           img_prefix='img'), default_args=dict(device='cpu'))
+    assert [d['id'] for d in c.data_infos] == [100, 101]
+
+
+def test_missing_files_fall_back_to_synthetic(capsys):
+    from oadg_amd.datasets import build_dataset
+    from oadg_amd.pipelines import SyntheticCityscapes
+    cfg = dict(type='RepeatDataset', times=8,
+               dataset=dict(type='CityscapesDataset', ann_file='/nonexistent/ann.json', img_prefix='/nonexistent/', pipeline=[]))
+    ds = build_dataset(cfg, default_args=dict(device='cpu', seed=3), synthetic_fallback=True)
+    assert isinstance(ds, SyntheticCityscapes) and 'not found' in capsys.readouterr().out
+    with pytest.raises(FileNotFoundError):
+        build_dataset(cfg, default_args=dict(device='cpu'))
+
+
+@pytest.mark.gpu
+def test_real_files_through_the_reference_pipeline_and_a_train_step(dev, tmp_path):
+    """PNG files + COCO json -> CityscapesDataset -> the reference's full train pipeline list (Resize, RandomFlip, OAMix,
+    Normalize, Pad) on the device -> one bf16 train step with finite losses."""
+    from PIL import Image
+    from oadg_amd import Config, build_detector, hip_conv
+    from oadg_amd.apis import TrainEngine, build_optimizer
+    from oadg_amd.datasets import build_dataset
+    from oadg_amd.pipelines import DevicePipeline
+    from inputs import lowpass_image, synthetic_boxes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg_multiscale.py'))
+    rs = np.random.RandomState(1)
+    H, W, images, anns = 256, 512, [], []
+    os.makedirs(tmp_path / 'img', exist_ok=True)
+    for i in range(2):
+        Image.fromarray(lowpass_image(rs, H, W, 4)[:, :, ::-1]).save(tmp_path / 'img' / f'{i}.png')
+        images.append(dict(id=i, file_name=f'{i}.png', height=H, width=W, segm_file=''))
+        for j, b in enumerate(synthetic_boxes(rs, 6, H, W, 24, 120)):
+            anns.append(dict(id=10 * i + j, image_id=i, category_id=24 + (j % 8), iscrowd=0, segmentation=[],
+                             bbox=[float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])],
+                             area=float((b[2] - b[0]) * (b[3] - b[1]))))
+    cats = [dict(id=24 + k, name=n) for k, n in enumerate(('person', 'rider', 'car', 'truck', 'bus', 'train',
+                                                            'motorcycle', 'bicycle'))]
+    with open(tmp_path / 'ann.json', 'w') as f:
+        json.dump(dict(images=images, annotations=anns, categories=cats), f)
+    ds = build_dataset(dict(type='CityscapesDataset', ann_file=str(tmp_path / 'ann.json'), img_prefix=str(tmp_path / 'img')),
+                       default_args=dict(device=dev))
+    pipeline = [dict(t) for t in cfg.data.train.pipeline]
+    pipeline[2] = dict(type='Resize', img_scale=[(512, 200), (512, 256)], keep_ratio=True)
+    pipe = DevicePipeline(pipeline, dtype=torch.bfloat16, one_scale_per_batch=True)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    data = pipe(*ds.batch([0, 1]))
+    assert data['img'].shape[0] == 2 and data['img'].shape[2] % 32 == 0 and data['img2'].shape == data['img'].shape
+    det = build_detector(cfg.model)
+    det.init_weights()
+    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    hip_conv.enable()
+    out = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16).step(data)
+    assert np.isfinite(float(out['loss'])) and float(out['loss']) > 0

@@ -102,9 +102,9 @@ def main():
     amp = torch.bfloat16 if a.amp == 'bf16' else None
     if amp is not None:
         hip_conv.enable()
+    from oadg_amd.datasets import build_dataset
     dcfg = cfg.data.test
-    ds_args = {k: v for k, v in dcfg.items() if k in ('img_shape', 'num_boxes', 'num_classes', 'length', 'box_size')}
-    ds = SyntheticCityscapes(seed=12345, device=dev, **ds_args)
+    ds = build_dataset(dcfg, default_args=dict(seed=12345, device=dev, test_mode=True), synthetic_fallback=True)
     pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32)
     n = len(ds) if a.max_samples is None else min(len(ds), a.max_samples)
     bs = cfg.data.get('samples_per_gpu', 1)
@@ -125,7 +125,7 @@ def main():
         print(f'writing results to {a.out}')
     if a.eval:
         assert a.eval == ['bbox'], "only --eval bbox is built"
-        m, aps = eval_map(results, annotations, ds_args.get('num_classes', 8))
+        m, aps = eval_map(results, annotations, len(getattr(ds, 'CLASSES', None) or range(dcfg.get('num_classes', 8))))
         print(f'AP50 (eval_map, area): mAP {m:.4f}  per class ' + ' '.join(f'{v:.3f}' for v in aps))
 
 

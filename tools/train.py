@@ -8,9 +8,9 @@
 
 CONFIG may be one of this repo's configs (configs/oadg/*.py) or an unmodified reference config (its
 ``/ws/external/...`` bases are resolved against the tree the config lives in, or $OADG_CONFIG_ROOT).
-Datasets other than ``SyntheticCityscapes`` are out of scope of this build: a reference
-config's dataset section is replaced by the synthetic Cityscapes-shaped source while its pipeline (OAMix,
-Normalize, Pad, Collect keys) is honoured.
+``CityscapesDataset`` / ``CocoDataset`` (COCO-format json + image files, oadg_amd/datasets.py) and
+``SyntheticCityscapes`` are built; a dataset whose annotation file is absent on this machine is replaced by the
+synthetic Cityscapes-shaped source (with a notice) while its pipeline list is honoured.
 """
 import argparse
 import os
@@ -116,11 +116,11 @@ def main():
     engine = TrainEngine(model, optimizer, distributed=distributed, amp_dtype=amp,
                          find_unused_parameters=cfg.get('find_unused_parameters', False))
     sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
+    from oadg_amd.datasets import build_dataset
+    ds = build_dataset(cfg.data.train, default_args=dict(seed=seed + rank, device=dev), synthetic_fallback=True)
     dcfg = cfg.data.train
     while 'dataset' in dcfg and dcfg.get('type') in ('RepeatDataset',):
         dcfg = dcfg.dataset
-    ds_args = {k: v for k, v in dcfg.items() if k in ('img_shape', 'num_boxes', 'num_classes', 'length', 'box_size')}
-    ds = SyntheticCityscapes(seed=seed + rank, device=dev, **ds_args)
     pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32, one_scale_per_batch=True)
     bs = cfg.data.get('samples_per_gpu', 2)
     epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
