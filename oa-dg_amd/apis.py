@@ -180,6 +180,13 @@ class TrainEngine:
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
         self.ddp = self.reducer = None
+        # Opt-in (OADG_STEP_PRIO=-1|0|1): run the train step on its own HIP stream of that priority
+        # (hipDeviceGetStreamPriorityRange: -1 high .. 1 low on MI355X) so its kernels are dispatched ahead of the data
+        # pipeline's side stream.  Measured (tools/probe/prio.sh): no gain beyond the +-1 ms run-to-run spread, so the
+        # default stays the caller's stream.
+        prio = os.environ.get('OADG_STEP_PRIO', 'none')
+        dev = next(model.parameters()).device
+        self.stream = torch.cuda.Stream(device=dev, priority=int(prio)) if (dev.type == 'cuda' and prio != 'none') else None
         from . import hip_conv
         # EXPERIMENTAL, off by default: weight gradients beside the data-gradient chain on a side stream (-1.4 ms per
         # step measured, but tools/probe/side_debug2.py still shows a cross-stream race in some weight gradients)
@@ -207,6 +214,19 @@ class TrainEngine:
         return self.module._parse_losses(losses), len(data['img_metas'])
 
     def step(self, data):
+        if self.stream is None:
+            return self._step(data)
+        # the whole step on the prioritised stream, ordered after the caller's stream on entry and before it on exit
+        caller = torch.cuda.current_stream()
+        self.stream.wait_stream(caller)
+        with torch.cuda.stream(self.stream):
+            out = self._step(data)
+        caller.wait_stream(self.stream)
+        for t in [out['loss']] + [v for v in out['log_vars'].values() if torch.is_tensor(v)]:
+            t.record_stream(caller)
+        return out
+
+    def _step(self, data):
         self.optimizer.zero_grad(set_to_none=True)
         (loss, log_vars), n = self.forward_losses(data)
         with _rf('sec:backward'):

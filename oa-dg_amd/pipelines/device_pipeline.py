@@ -8,6 +8,7 @@ the collated batch ``train_step`` consumes, with Normalize+Pad fused into the OA
 tensors (logical [N,3,H,W], channels_last), never as host arrays.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -158,7 +159,7 @@ class DevicePipeline:
         private numpy stream - so it also overlaps the step's host work; None keeps it in the caller's thread on
         the global numpy stream (bit-reproducible against the oracle with a single ``np.random.seed``)."""
         if getattr(self, '_stream', None) is None:
-            self._stream = torch.cuda.Stream(device=imgs_u8.device)
+            self._stream = torch.cuda.Stream(device=imgs_u8.device, priority=int(os.environ.get('OADG_PIPE_PRIO', '0')))
             self._stream.wait_stream(torch.cuda.current_stream())
         if worker_seed is None:
             return _Prefetched(*self._run_on_side_stream(imgs_u8, gt_bboxes, gt_labels))
