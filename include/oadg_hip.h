@@ -211,7 +211,7 @@ int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, const void*
                                       int stride, int pad, int dil, int* splits, void* stream);
 int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float* gbias, const float* w,
                                      const float* scale, const float* mean, const float* var, float eps, int K, int C,
-                                     int R, int S, float* dw, float* dgamma, void* stream);
+                                     int R, int S, float* dw, float* dgamma, int w_krsc, void* stream);
 
 /* probe switches for tools/bench_conv.py only: force the 128-tile weight-gradient kernel, its LDS stage count
  * (1 / 2, else automatic) and the workgroup count the split heuristic aims at (0 = automatic) */
@@ -220,13 +220,15 @@ void oadg_debug_wgrad(int force128, int stages, int target_blocks);
 /* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
  * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with
  * bias_in), fp32 [K,C,R,S] -> bf16 wf [K,R,S,C] and (optional) wt [C,R,S,K] flipped for the data gradient.
- * _bwd: gwf bf16 [K,R,S,C], gbias fp32 [K] -> dw fp32 [K,C,R,S], dgamma fp32 [K] (d beta = gbias). */
+ * _bwd: gwf bf16 [K,R,S,C], gbias fp32 [K] -> dw fp32 [K,C,R,S], dgamma fp32 [K] (d beta = gbias).
+ * w_krsc != 0: w (and dw) are stored channels-last, [K][R][S][C] in memory (a torch.channels_last parameter), else
+ * [K][C][R][S]. */
 int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const float* bias_in, int K, int C, int R, int S, void* wf,
-                           void* wt, float* bias, float* scale, void* stream);
+                           void* wt, float* bias, float* scale, int w_krsc, void* stream);
 int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
-                               float* dgamma, void* stream);
+                               float* dgamma, int w_krsc, void* stream);
 
 /* fused backward of the conv epilogue y = relu(conv + bias [+ residual]) (Bottleneck.forward resnet.py:285-300,
  * RPNHead.forward_single rpn_head.py:62 `F.relu(x, inplace=True)`, the bias/BN-shift gradient of every conv):

@@ -1221,7 +1221,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
                                                            const float* __restrict__ bias_in, int K, int C, int R,
                                                            int S, unsigned short* __restrict__ wf,
                                                            unsigned short* __restrict__ wt, float* __restrict__ bias,
-                                                           float* __restrict__ scale_out) {
+                                                           float* __restrict__ scale_out, int w_krsc) {
     const int k = blockIdx.x;
     float scale = 1.f, b = bias_in ? bias_in[k] : 0.f;
     if (gamma) {
@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
     const float* wk = w + (size_t)k * n;
     for (int i = threadIdx.x; i < n; i += 256) {      // i runs over the OUTPUT order (r, s, c): coalesced writes
         const int c = i % C, rs = i / C;
-        const unsigned short v = f32_to_bf16(wk[(size_t)c * RS + rs] * scale);
+        const unsigned short v = f32_to_bf16(wk[w_krsc ? (size_t)i : (size_t)c * RS + rs] * scale);
         wf[(size_t)k * n + i] = v;
         if (wt) wt[((size_t)c * RS + (RS - 1 - rs)) * K + k] = v;
     }
@@ -1249,16 +1249,16 @@ __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned sh
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ var, float eps, int K, int C,
                                                                int R, int S, float* __restrict__ dw,
-                                                               float* __restrict__ dgamma) {
+                                                               float* __restrict__ dgamma, int w_krsc) {
     __shared__ float red[16];
     const int k = blockIdx.x;
     const int RS = R * S, n = C * RS;
     const float sc = scale ? scale[k] : 1.f;
     const float* wk = w + (size_t)k * n;
     float dot = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {      // i over (c, r, s): coalesced reads of w / writes of dw
+    for (int i = threadIdx.x; i < n; i += 256) {      // i over w's memory order: coalesced reads of w / writes of dw
         const int rs = i % RS, c = i / RS;
-        const float g = bf16_to_f32(gwf[(size_t)k * n + (size_t)rs * C + c]);
+        const float g = bf16_to_f32(gwf[(size_t)k * n + (w_krsc ? (size_t)i : (size_t)rs * C + c)]);
         dw[(size_t)k * n + i] = g * sc;
         dot += g * wk[i];
     }
@@ -1272,11 +1272,11 @@ __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned sh
 
 extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
                                       const float* var, float eps, const float* bias_in, int K, int C, int R, int S,
-                                      void* wf, void* wt, float* bias, float* scale, void* stream) {
+                                      void* wf, void* wt, float* bias, float* scale, int w_krsc, void* stream) {
     if (!w || !wf || K < 1 || C < 1 || R < 1 || S < 1) return OADG_EARG;
     if (gamma && (!beta || !mean || !var)) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean, var, eps,
-                       bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale);
+                       bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale, w_krsc);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const floa
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ var, float eps, int K,
                                                                      int C, int R, int S, float* __restrict__ dw,
-                                                                     float* __restrict__ dgamma) {
+                                                                     float* __restrict__ dgamma, int w_krsc) {
     extern __shared__ float gsum[];            // [R*S][C]
     __shared__ float red[16];
     const int k = blockIdx.x;
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const floa
     float dot = 0.f;
     for (int i = threadIdx.x; i < n; i += 1024) {
         const int rs = i % RS, c = i / RS;
-        const float g = gsum[rs * C + c];
+        const float g = gsum[w_krsc ? i : rs * C + c];
         dw[(size_t)k * n + i] = g * sc;
         dot += g * wk[i];
     }
@@ -1333,24 +1333,25 @@ __global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const floa
 
 extern "C" int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float* gbias, const float* w,
                                                 const float* scale, const float* mean, const float* var, float eps,
-                                                int K, int C, int R, int S, float* dw, float* dgamma, void* stream) {
+                                                int K, int C, int R, int S, float* dw, float* dgamma, int w_krsc,
+                                                void* stream) {
     if (!part || splits < 1 || !w || !dw) return OADG_EARG;
     if (dgamma && (!mean || !var)) return OADG_EARG;
     const size_t lds = 5 * (size_t)C * R * S * sizeof(float);
     if (lds > 5 * 12000) return OADG_EARG;    // callers fall back to the reduced form
     hipLaunchKernelGGL(prep_weights_bwd_parts_kernel, dim3(K), dim3(1024), lds, (hipStream_t)stream, part, splits, gbias,
-                       w, scale, mean, var, eps, K, C, R, S, dw, dgamma);
+                       w, scale, mean, var, eps, K, C, R, S, dw, dgamma, w_krsc);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
 
 extern "C" int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
                                           const float* mean, const float* var, float eps, int K, int C, int R, int S,
-                                          float* dw, float* dgamma, void* stream) {
+                                          float* dw, float* dgamma, int w_krsc, void* stream) {
     if (!gwf || !w || !dw) return OADG_EARG;
     if (dgamma && (!mean || !var)) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_bwd_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream,
-                       (const unsigned short*)gwf, gbias, w, scale, mean, var, eps, K, C, R, S, dw, dgamma);
+                       (const unsigned short*)gwf, gbias, w, scale, mean, var, eps, K, C, R, S, dw, dgamma, w_krsc);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -341,15 +341,35 @@ class RPNHead(AnchorHead):
             tok = hip_conv.GradToken()
             x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok)
             if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
-                pad = 128 - n_cls - n_reg
-                w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight,
-                               self.rpn_cls.weight.new_zeros((pad,) + tuple(self.rpn_cls.weight.shape[1:]))])
-                b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, self.rpn_cls.bias.new_zeros(pad)])
+                w, b = self._fused_head_params()
                 y = conv2d(x, w, b, 1, 0, 1, in_token=tok)
                 return _SplitHeads.apply(y, n_cls, n_reg)
             return self.rpn_cls(x), self.rpn_reg(x)
         x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True)   # relu(rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)
+
+    def _fused_head_params(self):
+        """[rpn_cls; rpn_reg; zero rows] weight / bias of the fused 1x1 head, built once per forward pass (the
+        pyramid levels share it: one concatenation and one gradient split per step instead of five)."""
+        c = getattr(self, '_fused_cache', None)
+        if c is not None:
+            return c
+        wc, wr = self.rpn_cls.weight, self.rpn_reg.weight
+        pad = 128 - wc.shape[0] - wr.shape[0]
+        z = getattr(self, '_fused_pad', None)
+        if z is None or z[0].device != wc.device or z[0].dtype != wc.dtype:
+            z = self._fused_pad = (wc.new_zeros((pad,) + tuple(wc.shape[1:])), self.rpn_cls.bias.new_zeros(pad))
+        c = (torch.cat([wc, wr, z[0]]), torch.cat([self.rpn_cls.bias, self.rpn_reg.bias, z[1]]))
+        if torch.is_grad_enabled():
+            self._fused_cache = c
+        return c
+
+    def forward(self, feats):
+        self._fused_cache = None
+        try:
+            return super().forward(feats)
+        finally:
+            self._fused_cache = None
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         losses = super().loss(cls_scores, bbox_preds, gt_bboxes, None, img_metas,

@@ -164,7 +164,12 @@ class _PrepWeights(torch.autograd.Function):
         L = _lib.lib()
         K, C, R, S = w.shape
         leaf = all(t is None or t.grad_fn is None for t in (w, gamma, beta, bias_in))
-        w = w.detach().float().contiguous()
+        w = w.detach().float()
+        # a torch.channels_last parameter ([K][R][S][C] in memory) is read - and its gradient written - in place: no
+        # re-layout copy forward, no stride-fixing clone in AccumulateGrad
+        krsc = int(R * S > 1 and not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last))
+        if not krsc:
+            w = w.contiguous()
         dev = w.device
         wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         wt = torch.empty((C, K, R, S), dtype=torch.bfloat16, device=dev,
@@ -175,10 +180,13 @@ class _PrepWeights(torch.autograd.Function):
         f = lambda t: t.detach().float().contiguous() if t is not None else None  # noqa: E731
         g_, b_, m_, v_, bi_ = f(gamma), f(beta), f(mean), f(var), f(bias_in)
         check(L.oadg_prep_conv_weights(ptr(w), ptr(g_), ptr(b_), ptr(m_), ptr(v_), float(eps), ptr(bi_), K, C, R, S,
-                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), stream_ptr()),
+                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), krsc, stream_ptr()),
               'oadg_prep_conv_weights')
         ctx.save_for_backward(w, scale, m_, v_)
-        ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S)
+        # no zero tensors for the outputs nobody differentiates (autograd would otherwise fill a weight-sized zero
+        # gradient for the transposed copy and a [K] one for an unused bias on every step); backward handles None
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S, krsc)
         ctx.leaf_inputs = leaf      # False: autograd ops (not AccumulateGrad) consume the gradients next
         ctx.wtoken = wtoken
         outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
@@ -188,7 +196,7 @@ class _PrepWeights(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gwf, gbias, _gwt):
         w, scale, mean, var = ctx.saved_tensors
-        eps, has_bn, has_bias_in, K, C, R, S = ctx.cfg
+        eps, has_bn, has_bias_in, K, C, R, S, krsc = ctx.cfg
         L = _lib.lib()
         dw = dgamma = dbeta = dbias_in = None
         gb = gbias.float().contiguous() if (gbias is not None and gbias.numel()) else None
@@ -205,17 +213,18 @@ class _PrepWeights(torch.autograd.Function):
           if tok is not None and tok.parts is not None:
             parts, tok.parts = tok.parts, None
           if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
-            dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
+            dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb), ptr(w), ptr(scale), ptr(mean),
-                                                     ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), stream_ptr()),
+                                                     ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), krsc,
+                                                     stream_ptr()),
                   'oadg_prep_conv_weights_bwd_parts')
           elif gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dw = torch.empty((K, C, R, S), dtype=torch.float32, device=w.device)
+            dw = torch.empty_like(w)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
-                                               R, S, ptr(dw), ptr(dgamma), stream_ptr()),
+                                               R, S, ptr(dw), ptr(dgamma), krsc, stream_ptr()),
                   'oadg_prep_conv_weights_bwd')
         if side is not None:
             cur = torch.cuda.current_stream()

@@ -4,7 +4,7 @@ import importlib.util
 import os
 import sys
 
-_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'oa-dg_amd')
+_dir = os.environ.get('OADG_PKG_DIR') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'oa-dg_amd')   # (override: A/B probes)
 _spec = importlib.util.spec_from_file_location(
     'oadg_amd', os.path.join(_dir, '__init__.py'), submodule_search_locations=[_dir])
 _mod = importlib.util.module_from_spec(_spec)

@@ -154,13 +154,18 @@ def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, d
     assert err <= 2e-3 * w.grad.abs().max().item(), (err, w.grad.abs().max().item())
 
 
-def test_prepared_weights_fold_bn_forward_backward(dev):
-    """csrc prep_weights kernels: BN fold + layouts and their backward against the unfused torch expression."""
+@pytest.mark.parametrize('w_channels_last', [False, True])
+def test_prepared_weights_fold_bn_forward_backward(dev, w_channels_last):
+    """csrc prep_weights kernels: BN fold + layouts and their backward against the unfused torch expression, for a
+    contiguous and for a torch.channels_last parameter (read and differentiated in place, gradient in its strides)."""
     import torch.nn as nn
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(5)
     K, C, R = 128, 64, 3
-    w = (torch.randn(K, C, R, R, device=dev, generator=g) / 24).requires_grad_(True)
+    w = torch.randn(K, C, R, R, device=dev, generator=g) / 24
+    if w_channels_last:
+        w = w.contiguous(memory_format=torch.channels_last)
+    w.requires_grad_(True)
     bn = nn.BatchNorm2d(K).to(dev).eval()
     with torch.no_grad():
         bn.weight.copy_(torch.rand(K, device=dev, generator=g) + 0.5)
@@ -181,6 +186,7 @@ def test_prepared_weights_fold_bn_forward_backward(dev):
     s2 = gam * torch.rsqrt(bn.running_var + bn.eps)
     torch.autograd.backward([w2 * s2.view(-1, 1, 1, 1), bet - bn.running_mean * s2], [gw.float(), gb])
     assert torch.allclose(w.grad, w2.grad, rtol=1e-5, atol=1e-6)
+    assert w.grad.stride() == w.stride()
     assert torch.allclose(bn.weight.grad, gam.grad, rtol=1e-4, atol=1e-4)
     assert torch.allclose(bn.bias.grad, bet.grad, rtol=1e-6, atol=1e-6)
 

@@ -38,6 +38,25 @@ def main():
         eng.step(data)
         nxt = pipe.prefetch(*batches[(i + 1) % 3])
     torch.cuda.synchronize()
+    if '--small-ops' in sys.argv:
+        # who launches the small element-wise kernels?  aten op -> innermost frame of this package, per step
+        from torch.profiler import ProfilerActivity, profile
+        import collections
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as p:
+            data = nxt.get()
+            eng.step(data)
+            torch.cuda.synchronize()
+        want = ('aten::zero_', 'aten::fill_', 'aten::cat', 'aten::copy_', 'aten::add', 'aten::add_', 'aten::mul',
+                'aten::index', 'aten::index_select', 'aten::gather', 'aten::where', 'aten::sub', 'aten::div')
+        agg = collections.Counter()
+        for e in p.events():
+            if e.name in want:
+                fr = [f for f in (e.stack or []) if 'oa-dg_amd' in f or 'oadg_amd' in f]
+                where = fr[0].split('/')[-1] if fr else ((e.stack or ['autograd engine'])[0].split('/')[-1])
+                agg[(e.name, where[:70], str(e.input_shapes)[:50])] += 1
+        for (name, where, shp), n in agg.most_common(70):
+            print(f'{n:4d} {name:18s} {where:70s} {shp}')
+        return
     if '--torchprof' in sys.argv:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p:
