@@ -230,6 +230,12 @@ int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float*
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
                                float* dgamma, int w_krsc, void* stream);
 
+/* ResNet stem tail in one pass: out [N,Ho,Wo,C] = max_pool2d(relu(x + bias), kernel 3, stride 2, padding 1) for NHWC bf16
+ * x [N,H,W,C] (resnet.py:631-637 with the eval-mode BN folded into conv1; bias = BN shift, fp32 [C] or NULL), bit-identical
+ * to the element-wise chain add (bf16) -> relu -> max_pool2d.  Ho = (H - 1) / 2 + 1.  C % 8 == 0. */
+int oadg_bias_relu_maxpool_nhwc_bf16(const void* x, const float* bias, void* out, int N, int H, int W, int C,
+                                     void* stream);
+
 /* fused backward of the conv epilogue y = relu(conv + bias [+ residual]) (Bottleneck.forward resnet.py:285-300,
  * RPNHead.forward_single rpn_head.py:62 `F.relu(x, inplace=True)`, the bias/BN-shift gradient of every conv):
  *   g = dy * (y > 0) as bf16 (y == NULL: no mask), dbias[k] = sum over the M pixels of g[., k]

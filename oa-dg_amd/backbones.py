@@ -1,6 +1,8 @@
 """ResNet-50/101 backbone with mmdet's state_dict layout (mmdet/models/backbones/resnet.py:97-302,306-657,
 mmdet/models/utils/res_layer.py).  Frozen stem + stage 1, BN always in eval mode (norm_eval)."""
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
 from . import hip_conv
@@ -122,8 +124,22 @@ class ResNet(nn.Module):
             for p in m.parameters():
                 p.requires_grad = False
 
+    def _stem(self, x):
+        """maxpool(relu(bn1(conv1(x)))) (resnet.py:631-637).  Frozen stem on the MI355X in bf16: the library convolution
+        without bias, then bias + ReLU + max-pool in one pass (csrc/eltwise.hip) - same bits as the unfused chain."""
+        from . import hip_conv, hip_ops, layers
+        c, bn, mp = self.conv1, self.bn1, self.maxpool
+        frozen = not (c.weight.requires_grad or bn.weight.requires_grad or bn.bias.requires_grad or x.requires_grad)
+        if hip_conv.ENABLED and x.is_cuda and frozen and not bn.training and layers.FOLD_EVAL_BN and c.bias is None and \
+                (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) and c.out_channels % 8 == 0 and \
+                (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False):
+            w, b = layers.folded_frozen(c, bn)
+            y = F.conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16), None, c.stride, c.padding, c.dilation)
+            return hip_ops.bias_relu_maxpool(y, b)
+        return mp(conv_bn(x, c, bn, relu=True))
+
     def forward(self, x):
-        x = self.maxpool(conv_bn(x, self.conv1, self.bn1, relu=True))
+        x = self._stem(x)
         outs = []
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)

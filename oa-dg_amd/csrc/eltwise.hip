@@ -280,6 +280,62 @@ extern "C" int oadg_fpn_topdown_bwd(const void* g, void* dtop, int N, int H, int
     return OADG_OK;
 }
 
+// ResNet stem tail (resnet.py:631-637 `relu(norm1(conv1(x)))` -> `maxpool`, BN folded): out = maxpool3x3/s2/p1(relu(x + b)).
+// x + b is rounded to bf16 before the ReLU like the unfused element-wise chain; add, rounding and ReLU are monotone, so
+// they are applied once to the window maximum - bit-identical to add -> relu -> max_pool2d, in one pass instead of three.
+namespace {
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const unsigned short* __restrict__ x,
+                                                                const float* __restrict__ bias,
+                                                                unsigned short* __restrict__ out, int N, int H, int W,
+                                                                int Ho, int Wo, int C8) {
+    const long total = (long)N * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        long p = i / C8;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho), n = (int)(p / Ho);
+        float m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int h = 2 * ho - 1 + dy;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int w = 2 * wo - 1 + dx;
+                if ((unsigned)w >= (unsigned)W) continue;
+                float a[8];
+                unpack8(reinterpret_cast<const uint4*>(x)[(((long)n * H + h) * W + w) * C8 + c8], a);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], a[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = m[k];
+            // autocast: the bias is cast to bf16, the sum is rounded to bf16
+            if (bias) v = bf16_to_f32(f32_to_bf16(v + bf16_to_f32(f32_to_bf16(bias[c8 * 8 + k]))));
+            m[k] = fmaxf(v, 0.f);
+        }
+        reinterpret_cast<uint4*>(out)[i] = pack8(m);
+    }
+}
+}  // namespace
+
+extern "C" int oadg_bias_relu_maxpool_nhwc_bf16(const void* x, const float* bias, void* out, int N, int H, int W, int C,
+                                                void* stream) {
+    if (!x || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return OADG_EARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C >> 3);
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)x, bias, (unsigned short*)out, N, H, W, Ho, Wo, C >> 3);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
 // out[k] = sum_r part[r][k] in a fixed order (deterministic): the second stage of every column-sum producer
 extern "C" int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream) {
     if (!part || !out || rows < 1 || K < 1 || rows > 0x7fffffffL) return OADG_EARG;

@@ -219,6 +219,21 @@ def fpn_topdown(lat, top):
 
 
 # --------------------------------------------------------------------------------------- NMS
+def bias_relu_maxpool(x, bias):
+    """max_pool2d(relu(x + bias[None, :, None, None]), 3, 2, 1) for a bf16 channels_last map without gradient (the frozen
+    ResNet stem, resnet.py:631-637): one pass over the 537 MB stem output instead of three."""
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and not x.requires_grad and x.shape[1] % 8 == 0
+    x = x.contiguous(memory_format=torch.channels_last)
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                      memory_format=torch.channels_last)
+    b = bias.detach().float().contiguous() if bias is not None else None
+    check(_lib.lib().oadg_bias_relu_maxpool_nhwc_bf16(ptr(x), ptr(b), ptr(out), N, H, W, C, stream_ptr()),
+          'oadg_bias_relu_maxpool_nhwc_bf16')
+    return out
+
+
 def nms_sorted_batched(boxes, counts, iou_thr, max_keep=-1):
     """Greedy NMS on boxes [I, Mmax, 4] already sorted by descending score (and class-offset).
 

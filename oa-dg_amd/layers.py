@@ -76,6 +76,18 @@ def conv_bn(x, conv, bn, relu=False, residual=None, **tokens):
     return conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, relu, residual)
 
 
+def folded_frozen(conv, bn):
+    """(w * s, beta - mean * s) of a frozen conv + eval-mode BN pair, cached on the conv until a tensor is overwritten."""
+    key = (conv.weight._version, bn.weight._version, bn.bias._version, bn.running_mean._version,
+           bn.running_var._version, conv.weight.device, conv.weight.data_ptr())
+    cached = getattr(conv, '_folded', None)
+    if cached is None or cached[0] != key:
+        with torch.no_grad():
+            scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            cached = conv._folded = (key, conv.weight * scale.view(-1, 1, 1, 1), bn.bias - bn.running_mean * scale)
+    return cached[1], cached[2]
+
+
 def build_norm_layer(cfg, num_features, postfix=''):
     """mmcv.cnn.build_norm_layer for BN: returns (name, layer); ``requires_grad`` from the cfg."""
     cfg = dict(cfg)

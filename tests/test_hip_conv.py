@@ -380,3 +380,42 @@ def test_shared_weight_gradients_accumulate(dev):
                 assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item(), uses
     finally:
         hip_conv.enable(False)
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 64, 64, 96), (1, 64, 37, 53), (1, 8, 5, 7), (2, 128, 2, 2)])
+def test_bias_relu_maxpool_is_the_unfused_chain(dev, N, C, H, W):
+    """csrc/eltwise.hip bias_relu_maxpool_kernel == max_pool2d(relu(x + b)) in bf16, bit for bit (stem tail)."""
+    import torch.nn.functional as F
+    from oadg_amd import hip_ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = (torch.randn(N, C, H, W, device=dev, generator=g) * 2).bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(C, device=dev, generator=g)
+    y = x + b.bfloat16().view(1, -1, 1, 1)
+    assert y.dtype == torch.bfloat16
+    ref = F.max_pool2d(F.relu(y), 3, 2, 1)
+    out = hip_ops.bias_relu_maxpool(x, b)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out, ref)
+    assert torch.equal(hip_ops.bias_relu_maxpool(x, None), F.max_pool2d(F.relu(x), 3, 2, 1))
+
+
+def test_resnet_stem_fused_tail_matches_module_chain(dev):
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import ResNet
+    torch.manual_seed(0)
+    net = ResNet(50, frozen_stages=1, norm_eval=True).to(dev).to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        net.bn1.running_mean.normal_()
+        net.bn1.running_var.uniform_(0.5, 1.5)
+        net.bn1.bias.normal_()
+    x = torch.randn(2, 3, 96, 160, device=dev).contiguous(memory_format=torch.channels_last)
+    was = hip_conv.ENABLED
+    try:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            hip_conv.enable(False)
+            ref = net._stem(x)
+            hip_conv.enable(True)
+            out = net._stem(x)
+    finally:
+        hip_conv.enable(was)
+    assert out.dtype == ref.dtype == torch.bfloat16 and torch.equal(out, ref)

@@ -56,6 +56,26 @@ def main():
                 agg[(e.name, where[:70], str(e.input_shapes)[:50])] += 1
         for (name, where, shp), n in agg.most_common(70):
             print(f'{n:4d} {name:18s} {where:70s} {shp}')
+        print('---- element-wise ops on large tensors (>= 1M elements)')
+        big = collections.Counter()
+        for e in p.events():
+            if e.name.startswith('aten::') and e.name not in ('aten::empty', 'aten::view', 'aten::empty_like', 'aten::as_strided',
+                                                              'aten::permute', 'aten::reshape', 'aten::slice', 'aten::narrow',
+                                                              'aten::select', 'aten::expand', 'aten::detach', 'aten::alias',
+                                                              'aten::empty_strided', 'aten::transpose', 'aten::contiguous',
+                                                              'aten::to', 'aten::_to_copy', 'aten::unbind', 'aten::split',
+                                                              'aten::chunk', 'aten::zeros', 'aten::clone', 'aten::result_type'):
+                n = 0
+                for shp in (e.input_shapes or []):
+                    if shp:
+                        m = 1
+                        for d in shp:
+                            m *= d
+                        n = max(n, m)
+                if n >= 1_000_000:
+                    big[(e.name, str(e.input_shapes)[:90])] += 1
+        for (name, shp), n in sorted(big.items(), key=lambda kv: -kv[1]):
+            print(f'{n:4d} {name:28s} {shp}')
         return
     if '--torchprof' in sys.argv:
         from torch.profiler import ProfilerActivity, profile
