@@ -601,6 +601,14 @@ class DeltaXYWHBBoxCoder:
 
 def bbox2roi(bbox_list):
     """list of [n_i, >=4] boxes -> [sum n_i, 5] with the list position as batch index (transforms.py:75-94)."""
+    sizes = [int(b.size(0)) for b in bbox_list]
+    if len(bbox_list) > 1 and sum(sizes) > 0 and bbox_list[0].is_cuda:
+        # one index column for the whole batch (built on the host from the known sizes, uploaded through pinned memory)
+        # and two concatenations, instead of a fill + a concatenation per image
+        first = bbox_list[0]
+        idx = _pinned_to(torch.from_numpy(np.repeat(np.arange(len(sizes), dtype=np.float32), sizes)), first.device)
+        boxes = torch.cat([b[:, :4] for b in bbox_list], 0)
+        return torch.cat([idx.to(boxes.dtype)[:, None], boxes], dim=1)
     rois = []
     for img_id, b in enumerate(bbox_list):
         if b.size(0) > 0:

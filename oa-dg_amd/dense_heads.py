@@ -116,8 +116,6 @@ class AnchorHead(nn.Module):
         num_imgs = len(img_metas)
         assert len(anchor_list) == len(valid_flag_list) == num_imgs
         num_level_anchors = [a.size(0) for a in anchor_list[0]]
-        concat_anchors = [torch.cat(a) for a in anchor_list]
-        concat_flags = [torch.cat(f) for f in valid_flag_list]
         if gt_bboxes_ignore_list is None:
             gt_bboxes_ignore_list = [None] * num_imgs
         if gt_labels_list is None:
@@ -131,6 +129,17 @@ class AnchorHead(nn.Module):
             fused = self._fused_targets(pending[1], srs, num_level_anchors, gt_labels_list, unmap_outputs)
             if fused is not None:
                 return fused
+        # per-image concatenation over the levels; the images of a batch share their (cached) anchor / flag lists
+        memo = {}
+
+        def cat_once(lst):
+            if id(lst) not in memo:
+                memo[id(lst)] = torch.cat(lst)
+            return memo[id(lst)]
+        concat_anchors = [cat_once(a) for a in anchor_list]
+        concat_flags = [cat_once(f) for f in valid_flag_list]
+        if fast and pending is not None and pending[0] == (num_imgs, tuple(num_level_anchors)):
+            pass
         elif fast:   # one host read for the whole batch instead of ~6 per image
             ars = [self._assign_inside(concat_anchors[i], concat_flags[i], gt_bboxes_list[i], img_metas[i],
                                        None if self.sampling else gt_labels_list[i]) for i in range(num_imgs)]

@@ -38,6 +38,41 @@ def main():
         eng.step(data)
         nxt = pipe.prefetch(*batches[(i + 1) % 3])
     torch.cuda.synchronize()
+    if '--callers' in sys.argv:
+        # which lines of this package call the small tensor ops?  (python-side calls only; autograd's are not seen)
+        import collections
+        import traceback
+        counts = collections.Counter()
+
+        def wrap(owner, name):
+            orig = getattr(owner, name)
+
+            def shim(*a, **k):
+                for fr in reversed(traceback.extract_stack(limit=12)[:-1]):
+                    if 'oa-dg_amd' in fr.filename:
+                        counts[(name, os.path.basename(fr.filename), fr.lineno)] += 1
+                        break
+                return orig(*a, **k)
+            setattr(owner, name, shim)
+        for nm in ('cat', 'stack', 'zeros', 'ones', 'full', 'arange', 'where', 'tensor', 'as_tensor', 'empty', 'zeros_like',
+                   'ones_like', 'full_like', 'gather', 'sort', 'topk', 'cumsum', 'nonzero', 'clamp', 'exp', 'log', 'abs'):
+            wrap(torch, nm)
+        for nm in ('new_zeros', 'new_full', 'new_ones', 'new_tensor', 'new_empty', 'float', 'long', 'int', 'to', 'clone',
+                   'contiguous', 'sum', 'mean', 'nonzero', 'index_select', 'masked_fill', 'clamp', 'expand', 'repeat',
+                   '__getitem__', '__setitem__', '__mul__', '__add__', '__sub__', '__truediv__', 'view', 'reshape',
+                   'permute', 'sigmoid', 'softmax', 'index_fill_', 'index_copy_', 'fill_', 'zero_', 'copy_'):
+            wrap(torch.Tensor, nm)
+        data = nxt.get()
+        eng.step(data)
+        torch.cuda.synchronize()
+        byline = collections.Counter()
+        for (nm, f, ln), n in counts.items():
+            byline[(f, ln)] += n
+        print('---- tensor-op calls per step by source line (top 60)')
+        for (f, ln), n in byline.most_common(60):
+            ops = ', '.join(f'{nm}x{c}' for (nm, f2, l2), c in counts.items() if (f2, l2) == (f, ln))
+            print(f'{n:4d} {f}:{ln}  {ops}')
+        return
     if '--small-ops' in sys.argv:
         # who launches the small element-wise kernels?  aten op -> innermost frame of this package, per step
         from torch.profiler import ProfilerActivity, profile
