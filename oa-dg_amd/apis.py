@@ -134,10 +134,33 @@ class FlatGradReducer:
             o = b['start']
             for p in b['params']:
                 self.bucket_of[p] = b
-                self.views[p] = self.flat[o:o + p.numel()].view_as(p)
+                # the slice carries the parameter's own memory layout (channels_last conv weights included): the reduced
+                # gradient then has the parameter's strides and the optimizer's multi-tensor kernels keep their fast path
+                self.views[p] = self._like_param(self.flat[o:o + p.numel()], p)
                 o += p.numel()
             b['pending'], b['work'] = len(b['params']), None
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in params]
+
+    @staticmethod
+    def _dense(t):
+        return t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last) or \
+            (t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d))
+
+    @classmethod
+    def _like_param(cls, flat_slice, p):
+        if cls._dense(p):
+            return flat_slice.as_strided(p.shape, p.stride())
+        return flat_slice.view_as(p)
+
+    @classmethod
+    def _memory_order(cls, g, p):
+        """the gradient as a flat fp32 vector in the PARAMETER's memory order"""
+        if g.stride() == p.stride() and cls._dense(g):
+            return g.as_strided((g.numel(),), (1,)).float()
+        if cls._dense(p):          # rare: a gradient laid out differently from its parameter
+            return torch.empty_strided(p.shape, p.stride(), dtype=torch.float32, device=g.device).copy_(g) \
+                .as_strided((g.numel(),), (1,))
+        return g.reshape(-1).float()
 
     def _ready(self, p):
         b = self.bucket_of[p]
@@ -148,7 +171,7 @@ class FlatGradReducer:
     def _launch(self, b):
         _join_side_streams()          # weight gradients are produced on hip_conv's side stream
         flat = self.flat[b['start']:b['end']]
-        parts = [(p.grad if p.grad is not None else self.views[p].zero_()).reshape(-1).float() for p in b['params']]
+        parts = [self._memory_order(p.grad if p.grad is not None else self.views[p].zero_(), p) for p in b['params']]
         torch.cat(parts, out=flat)
         b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
                                     group=self.group, async_op=True)
