@@ -109,7 +109,7 @@ class FlatGradReducer:
     xGMI is point-to-point (7 links per GPU), so a ring all-reduce moves 2(N-1)/N of the 166 MB per GPU: a handful
     of large buckets keeps each collective bandwidth-bound rather than latency-bound."""
 
-    def __init__(self, module, bucket_mb=64, group=None):
+    def __init__(self, module, bucket_mb=64, group=None, tail_mb=6):
         self.group = group
         self.world = dist.get_world_size(group)
         params = [p for p in module.parameters() if p.requires_grad][::-1]
@@ -121,10 +121,16 @@ class FlatGradReducer:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.buckets, cur, size, off = [], [], 0, 0
         limit = bucket_mb * (1 << 20) // 4
-        for p in params:
+        # the parameters that become ready last (the first trainable backbone stage) get a small bucket of their own:
+        # its all-reduce is the only one that cannot overlap with the backward pass
+        tail, acc = len(params), 0
+        while tail > 1 and acc + params[tail - 1].numel() <= tail_mb * (1 << 20) // 4:
+            tail -= 1
+            acc += params[tail].numel()
+        for i, p in enumerate(params):
             cur.append(p)
             size += p.numel()
-            if size >= limit:
+            if size >= limit or i == tail - 1:
                 self.buckets.append(dict(params=cur, start=off, end=off + size))
                 off, cur, size = off + size, [], 0
         if cur:
