@@ -213,6 +213,15 @@ int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float*
                                      const float* scale, const float* mean, const float* var, float eps, int K, int C,
                                      int R, int S, float* dw, float* dgamma, int w_krsc, void* stream);
 
+/* one parity class of a strided data gradient: a stride-1 convolution over x (= dy) whose out_h x out_w output pixels
+ * per image are stored on the strided grid row = ((n*OH + ho*osh + oph)*OW + wo*osw + opw) of y [N,OH,OW,K]; residual and
+ * mask are read at the same rows; input positions past the extent of x read zeros.  Replaces the stride-2 branch of
+ * aten.convolution_backward (cuDNN/MIOpen data gradient) for Bottleneck.conv2 / downsample (resnet.py:97-302). */
+int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                                  const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int pad, int dil,
+                                  int relu, int out_h, int out_w, int OH, int OW, int osh, int osw, int oph, int opw,
+                                  const void* mask, float* colsum_part, void* stream);
+
 /* probe switches for tools/bench_conv.py only: force the 128-tile weight-gradient kernel, its LDS stage count
  * (1 / 2, else automatic) and the workgroup count the split heuristic aims at (0 = automatic) */
 void oadg_debug_wgrad(int force128, int stages, int target_blocks);
@@ -222,10 +231,12 @@ void oadg_debug_wgrad(int force128, int stages, int target_blocks);
  * bias_in), fp32 [K,C,R,S] -> bf16 wf [K,R,S,C] and (optional) wt [C,R,S,K] flipped for the data gradient.
  * _bwd: gwf bf16 [K,R,S,C], gbias fp32 [K] -> dw fp32 [K,C,R,S], dgamma fp32 [K] (d beta = gbias).
  * w_krsc != 0: w (and dw) are stored channels-last, [K][R][S][C] in memory (a torch.channels_last parameter), else
- * [K][C][R][S]. */
+ * [K][C][R][S].  wt_mode 2 (3x3 / pad 1 and 1x1 stride-2 layers): wt receives, instead of the flipped copy, the weights of
+ * the four parity-class convolutions of the stride-2 data gradient, blocks [C][taps][K] in the order (0,0) (0,1) (1,0)
+ * (1,1) with 1, 2, 2, 4 taps (1x1: one block) - see oadg_conv2d_nhwc_bf16_scatter. */
 int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const float* bias_in, int K, int C, int R, int S, void* wf,
-                           void* wt, float* bias, float* scale, int w_krsc, void* stream);
+                           void* wt, float* bias, float* scale, int w_krsc, int wt_mode, void* stream);
 int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
                                float* dgamma, int w_krsc, void* stream);

@@ -33,7 +33,19 @@ struct ConvArgs {
     float* colsum;                // [pixel tiles][K] fp32 partial column sums of the stored y, or null
     int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil, relu;
     long M;
+    // output scatter (stride-2 data gradients, one launch per parity class): pixel (n, ho, wo) of this launch is row
+    // ((n * OH + ho * osh + oph) * OW + wo * osw + opw) of y / res / mask.  scatter == 0: row = m.
+    int scatter, OH, OW, osh, osw, oph, opw;
 };
+
+__device__ __forceinline__ long out_row(const ConvArgs& a, long m) {
+    if (!a.scatter) return m;
+    const long t = m / a.Wo;
+    const int wo = (int)(m - t * a.Wo);
+    const long n = t / a.Ho;
+    const int ho = (int)(t - n * a.Ho);
+    return (n * a.OH + (long)ho * a.osh + a.oph) * a.OW + (long)wo * a.osw + a.opw;
+}
 
 // Last step of both epilogues for one 16-byte piece (8 channels of a pixel): residual add, ReLU, ReLU-backward
 // mask, bf16 rounding, and the running column sums of what is stored.
@@ -229,7 +241,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         for (int it = 0; it < NPIECE; ++it) {
             const int q = it * 256 + tid;
             const long m = m0 + q / SPR;
-            const size_t off = (size_t)m * a.K + k0 + (q % SPR) * 8;
+            const size_t off = (size_t)out_row(a, m < a.M ? m : 0) * a.K + k0 + (q % SPR) * 8;
             rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         const long m = m0 + row;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
-        const size_t off = (size_t)m * a.K + k0 + sg * 8;
+        const size_t off = (size_t)out_row(a, m) * a.K + k0 + sg * 8;
         *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
     }
     if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
@@ -568,7 +580,8 @@ int auto_variant(long M, int H, int W, int C, int K, int nchunks) {
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
-                void* stream, const void* mask = nullptr, float* colsum_part = nullptr) {
+                void* stream, const void* mask = nullptr, float* colsum_part = nullptr, const int* sc = nullptr) {
+    // sc (optional, 8 ints): out_h, out_w = output extent of this launch; OH, OW, osh, osw, oph, opw = scatter map
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % 64 != 0) return OADG_EARG;   // other shapes stay on the library path
@@ -581,6 +594,14 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     a.relu = relu;
     a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+    a.scatter = 0; a.OH = a.Ho; a.OW = a.Wo; a.osh = a.osw = 1; a.oph = a.opw = 0;
+    if (sc) {
+        if (stride != 1 || sc[0] < 1 || sc[1] < 1 || sc[4] < 1 || sc[5] < 1 || sc[6] < 0 || sc[7] < 0) return OADG_EARG;
+        if ((long)(sc[0] - 1) * sc[4] + sc[6] >= sc[2] || (long)(sc[1] - 1) * sc[5] + sc[7] >= sc[3]) return OADG_EARG;
+        a.Ho = sc[0]; a.Wo = sc[1];           // rows past the input extent read the zero line
+        a.scatter = 1; a.OH = sc[2]; a.OW = sc[3]; a.osh = sc[4]; a.osw = sc[5]; a.oph = sc[6]; a.opw = sc[7];
+        if (variant == 0 || variant == 2) variant = 3;      // the 128-tile kernels carry the scatter map
+    }
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
     const bool post = residual != nullptr || mask != nullptr;
@@ -654,6 +675,20 @@ extern "C" int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const floa
                                         float* colsum_part, void* stream) {
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, variant, stream,
                        mask, colsum_part);
+}
+
+// One parity class of a strided data gradient (or any stride-1 convolution whose output pixels are written on a
+// strided grid of a larger tensor): the launch covers out_h x out_w output pixels per image (input rows / columns past
+// the extent of x read zeros), pixel (n, ho, wo) is stored at row ((n*OH + ho*osh + oph)*OW + wo*osw + opw) of y
+// (and residual / mask are read there).  colsum_part has ceil(N*out_h*out_w / 128) rows.
+extern "C" int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bias, const void* residual,
+                                             void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
+                                             int S, int pad, int dil, int relu, int out_h, int out_w, int OH, int OW,
+                                             int osh, int osw, int oph, int opw, const void* mask,
+                                             float* colsum_part, void* stream) {
+    const int sc[8] = {out_h, out_w, OH, OW, osh, osw, oph, opw};
+    return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, 1, pad, dil, relu, 3, stream, mask,
+                       colsum_part, sc);
 }
 
 // rows of the colsum_part buffer for a problem / variant (0 = automatic)
@@ -1221,7 +1256,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
                                                            const float* __restrict__ bias_in, int K, int C, int R,
                                                            int S, unsigned short* __restrict__ wf,
                                                            unsigned short* __restrict__ wt, float* __restrict__ bias,
-                                                           float* __restrict__ scale_out, int w_krsc) {
+                                                           float* __restrict__ scale_out, int w_krsc, int wt_mode) {
     const int k = blockIdx.x;
     float scale = 1.f, b = bias_in ? bias_in[k] : 0.f;
     if (gamma) {
@@ -1238,7 +1273,23 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
         const int c = i % C, rs = i / C;
         const unsigned short v = f32_to_bf16(wk[w_krsc ? (size_t)i : (size_t)c * RS + rs] * scale);
         wf[(size_t)k * n + i] = v;
-        if (wt) wt[((size_t)c * RS + (RS - 1 - rs)) * K + k] = v;
+        if (wt && wt_mode != 2) {
+            wt[((size_t)c * RS + (RS - 1 - rs)) * K + k] = v;
+        } else if (wt) {
+            // stride-2 data gradient as four stride-1 convolutions over dy, one per output parity class (ph, pw), class
+            // blocks [C][taps][K] back to back in the order (0,0) (0,1) (1,0) (1,1).  3x3 / pad 1: parity 0 uses the
+            // centre tap, parity 1 the taps 2 (dy[a]) and 0 (dy[a+1]) in that order; 1x1: a single class.
+            if (RS == 1) {
+                wt[(size_t)c * K + k] = v;
+            } else {
+                const int r = rs / S, q = rs - r * S;
+                const int ph = r == 1 ? 0 : 1, pw = q == 1 ? 0 : 1;
+                const int tr = r == 0 ? 1 : 0, tq = q == 0 ? 1 : 0;          // r = 1 -> 0, r = 2 -> 0, r = 0 -> 1
+                const int Sc = pw ? 2 : 1, T = (ph ? 2 : 1) * Sc;
+                const int cls_off = ph == 0 ? (pw == 0 ? 0 : 1) : (pw == 0 ? 3 : 5);
+                wt[(size_t)cls_off * C * K + ((size_t)c * T + tr * Sc + tq) * K + k] = v;
+            }
+        }
     }
 }
 
@@ -1272,11 +1323,13 @@ __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned sh
 
 extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
                                       const float* var, float eps, const float* bias_in, int K, int C, int R, int S,
-                                      void* wf, void* wt, float* bias, float* scale, int w_krsc, void* stream) {
+                                      void* wf, void* wt, float* bias, float* scale, int w_krsc, int wt_mode,
+                                      void* stream) {
     if (!w || !wf || K < 1 || C < 1 || R < 1 || S < 1) return OADG_EARG;
+    if (wt && wt_mode == 2 && !((R == 3 && S == 3) || (R == 1 && S == 1))) return OADG_EARG;
     if (gamma && (!beta || !mean || !var)) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean, var, eps,
-                       bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale, w_krsc);
+                       bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale, w_krsc, wt_mode);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

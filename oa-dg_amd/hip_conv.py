@@ -5,6 +5,7 @@ Forward and the stride-1 data gradient run on the hand-written kernel; the weigh
 over the pixel dimension) still go through ``aten.convolution_backward`` (MIOpen) this round.
 """
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -71,6 +72,42 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         check(L.oadg_colsum_reduce(ptr(part), part.shape[0], K, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
         return y, cs
     return y
+
+
+_S2_CLASSES = ((0, 0, 1, 1, 0), (0, 1, 1, 2, 1), (1, 0, 2, 1, 3), (1, 1, 2, 2, 5))    # ph, pw, taps_h, taps_w, block offset
+
+
+def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False):
+    """dx of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0) as one stride-1 convolution over dy per output parity
+    class, each written on its strided grid of dx (csrc oadg_conv2d_nhwc_bf16_scatter; ``wt`` = the class filters from
+    ``_PrepWeights`` mode 2).  ``mask``: ReLU-backward mask (the convolution's input), ``want_colsum``: also return the
+    column sums of the masked dx (the producer's bias gradient) - the same epilogue fusions as the stride-1 path."""
+    L = _lib.lib()
+    N, C, H, W = xshape
+    K, Ho, Wo = gy.shape[1], gy.shape[2], gy.shape[3]
+    gx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=gy.device, memory_format=torch.channels_last)
+    classes = _S2_CLASSES if R == 3 else _S2_CLASSES[:1]
+    if R == 1:
+        gx.zero_()                       # odd rows / columns receive no gradient
+    geo = []
+    for ph, pw, th, tw, off in classes:
+        ha, wa = (H - ph + 1) // 2, (W - pw + 1) // 2
+        if ha > 0 and wa > 0:
+            geo.append((ph, pw, th, tw, off, ha, wa, (N * ha * wa + 127) // 128))
+    part = torch.empty((sum(g[-1] for g in geo), C), dtype=torch.float32, device=gy.device) if want_colsum else None
+    row = 0
+    for ph, pw, th, tw, off, ha, wa, tiles in geo:
+        wptr = ctypes.c_void_p(wt.data_ptr() + off * C * K * 2)
+        pptr = ctypes.c_void_p(part.data_ptr() + row * C * 4) if part is not None else None
+        check(L.oadg_conv2d_nhwc_bf16_scatter(ptr(gy), wptr, None, None, ptr(gx), ptr(_zeros(gy.device)), N, Ho, Wo, K, C,
+                                              th, tw, 0, 1, 0, ha, wa, H, W, 2, 2, ph, pw, ptr(mask), pptr,
+                                              stream_ptr()), 'oadg_conv2d_nhwc_bf16_scatter')
+        row += tiles
+    if want_colsum:
+        cs = torch.empty((C,), dtype=torch.float32, device=gy.device)
+        check(L.oadg_colsum_reduce(ptr(part), part.shape[0], C, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
+        return gx, cs
+    return gx
 
 
 def conv_wgrad(x16, gy16, K, R, S, stride, pad, dil):
@@ -172,6 +209,7 @@ class _PrepWeights(torch.autograd.Function):
             w = w.contiguous()
         dev = w.device
         wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        want_wt = int(want_wt)         # 0 none, 1 flipped / transposed copy (stride-1 dgrad), 2 stride-2 parity classes
         wt = torch.empty((C, K, R, S), dtype=torch.bfloat16, device=dev,
                          memory_format=torch.channels_last) if want_wt else None
         has_bias = gamma is not None or bias_in is not None
@@ -180,7 +218,7 @@ class _PrepWeights(torch.autograd.Function):
         f = lambda t: t.detach().float().contiguous() if t is not None else None  # noqa: E731
         g_, b_, m_, v_, bi_ = f(gamma), f(beta), f(mean), f(var), f(bias_in)
         check(L.oadg_prep_conv_weights(ptr(w), ptr(g_), ptr(b_), ptr(m_), ptr(v_), float(eps), ptr(bi_), K, C, R, S,
-                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), krsc, stream_ptr()),
+                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), krsc, want_wt, stream_ptr()),
               'oadg_prep_conv_weights')
         ctx.save_for_backward(w, scale, m_, v_)
         # no zero tensors for the outputs nobody differentiates (autograd would otherwise fill a weight-sized zero
@@ -240,8 +278,20 @@ class _PrepWeights(torch.autograd.Function):
         return dw, dgamma, dbeta, None, None, None, dbias_in, None, None
 
 
+S2_DGRAD = os.environ.get('OADG_S2_DGRAD', '1') == '1'      # stride-2 data gradients on the csrc kernels (else MIOpen)
+
+
 def _wt_useful(x, K, C, stride, pad, dil, R):
-    return bool(x.requires_grad and stride == 1 and dil * (R - 1) - pad >= 0 and K % 64 == 0 and C % 64 == 0)
+    """which second weight copy the data gradient of this convolution wants (``_PrepWeights`` ``want_wt``): 1 = flipped
+    / transposed (stride 1), 2 = the four parity-class filters of a stride-2 3x3 / pad 1 or 1x1 / pad 0 layer, 0 = none
+    (library data gradient)."""
+    if not (x.requires_grad and K % 64 == 0 and C % 64 == 0):
+        return 0
+    if stride == 1 and dil * (R - 1) - pad >= 0:
+        return 1
+    if S2_DGRAD and stride == 2 and dil == 1 and ((R == 3 and pad == 1) or (R == 1 and pad == 0)):
+        return 2
+    return 0
 
 
 def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
@@ -354,7 +404,15 @@ class _Conv2dMFMA(torch.autograd.Function):
         extra = None
         if in_token is not None:
             extra, in_token.extra = in_token.extra, None
-        if need_x and wt is not None:
+        if need_x and wt is not None and stride == 2:
+            # dx of the stride-2 layers (Bottleneck.conv2 / downsample of a stage's first block): parity-class convolutions
+            if in_token is not None and extra is None:
+                gx, in_token.colsum = conv_dgrad_s2(gy, wt, x16.shape, R, mask=x16, want_colsum=True)
+                in_token.grad_ptr = gx.data_ptr()
+            else:
+                gx = conv_dgrad_s2(gy, wt, x16.shape, R)
+            need_x = False
+        elif need_x and wt is not None:
             # dx = conv(dy, rot180(W)^T) [+ identity gradient] [* (x > 0), column sums -> producer's bias gradient]
             if in_token is not None:
                 gx, in_token.colsum = conv_forward(gy, wt, None, extra, 1, dil * (R - 1) - pad, dil, False,

@@ -146,13 +146,14 @@ class DevicePipeline:
             metas[i].update(img_shape=(H, W, 3), pad_shape=(Hp, Wp, 3))
         return dict(img=[img], img_metas=[metas])
 
-    def prefetch(self, imgs_u8, gt_bboxes, gt_labels, worker_seed=None):
+    def prefetch(self, imgs_u8, gt_bboxes, gt_labels, worker_seed=None, ready=None):
         """Enqueue the whole pipeline for one batch on a side stream and return a handle (``.get()``).
 
         This is the device-side analogue of the reference's DataLoader workers (``workers_per_gpu`` processes
         with prefetching, configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes.py:27): augmentation of
         batch i+1 overlaps the training step of batch i.  The inputs must already be complete on the device
-        (resident batches); OA-Mix's small host reads only wait on this stream.
+        (resident batches) or ``ready`` is the event recorded after their producer (decode + upload, synthetic
+        generation) on its stream; OA-Mix's small host reads only wait on this stream.
 
         ``worker_seed`` not None: the host side of the pipeline (OA-Mix's draws and ~1000 launches, ~10 ms) runs
         in a worker THREAD with its own ``RandomState(worker_seed)`` stream - a DataLoader worker likewise owns a
@@ -162,7 +163,7 @@ class DevicePipeline:
             self._stream = torch.cuda.Stream(device=imgs_u8.device, priority=int(os.environ.get('OADG_PIPE_PRIO', '0')))
             self._stream.wait_stream(torch.cuda.current_stream())
         if worker_seed is None:
-            return _Prefetched(*self._run_on_side_stream(imgs_u8, gt_bboxes, gt_labels))
+            return _Prefetched(*self._run_on_side_stream(imgs_u8, gt_bboxes, gt_labels, ready))
         if getattr(self, '_pool', None) is None:
             from concurrent.futures import ThreadPoolExecutor
             from .oa_mix import use_random_state
@@ -172,9 +173,11 @@ class DevicePipeline:
                 torch.cuda.set_device(dev)
                 use_random_state(rs)
             self._pool = ThreadPoolExecutor(1, thread_name_prefix='oadg-pipeline', initializer=init)
-        return _PrefetchedFuture(self._pool.submit(self._run_on_side_stream, imgs_u8, gt_bboxes, gt_labels))
+        return _PrefetchedFuture(self._pool.submit(self._run_on_side_stream, imgs_u8, gt_bboxes, gt_labels, ready))
 
-    def _run_on_side_stream(self, imgs_u8, gt_bboxes, gt_labels):
+    def _run_on_side_stream(self, imgs_u8, gt_bboxes, gt_labels, ready=None):
+        if ready is not None:
+            self._stream.wait_event(ready)
         with torch.cuda.stream(self._stream):
             out = self(imgs_u8, gt_bboxes, gt_labels)
             evt = torch.cuda.Event()

@@ -419,3 +419,71 @@ def test_resnet_stem_fused_tail_matches_module_chain(dev):
     finally:
         hip_conv.enable(was)
     assert out.dtype == ref.dtype == torch.bfloat16 and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize('N,C,H,W,K,R', [(2, 128, 24, 40, 128, 3), (1, 64, 23, 37, 192, 3), (2, 256, 16, 18, 64, 1),
+                                         (1, 128, 9, 7, 128, 1), (1, 64, 2, 2, 64, 3), (2, 128, 31, 64, 256, 3)])
+def test_stride2_data_gradient_parity_classes(dev, N, C, H, W, K, R):
+    """conv_dgrad_s2 (four parity-class convolutions + strided store) against autograd's data gradient of the stride-2
+    convolution in fp32, with and without the fused ReLU mask / column sums; even and odd extents."""
+    import torch.nn.functional as F
+    from oadg_amd import hip_conv
+    pad = 1 if R == 3 else 0
+    g = torch.Generator(device=dev).manual_seed(11)
+    w = (torch.randn(K, C, R, R, device=dev, generator=g) / (C * R * R) ** 0.5).requires_grad_(True)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    wf, _, wt = hip_conv.prepared(w, None, None, 2)
+    y = F.conv2d(x.float(), wf.detach().float(), None, 2, pad)
+    gy = torch.randn(y.shape, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+    xr = x.float().requires_grad_(True)
+    F.conv2d(xr, wf.detach().float(), None, 2, pad).backward(gy.float())
+    ref = xr.grad
+    got = hip_conv.conv_dgrad_s2(gy, wt, x.shape, R)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert (got.float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-6
+    got_m, cs = hip_conv.conv_dgrad_s2(gy, wt, x.shape, R, mask=x, want_colsum=True)
+    refm = ref * (x.float() > 0)
+    assert (got_m.float() - refm).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-6
+    assert torch.equal(got_m == 0, (got_m == 0) | (x <= 0))
+    assert torch.allclose(cs, got_m.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+def test_downsample_stage_backward_on_own_stride2_kernels(dev, monkeypatch):
+    """A stage with a stride-2 first block (Bottleneck.conv2 3x3/s2 + downsample 1x1/s2): gradients with the csrc
+    stride-2 data gradients (and the ReLU mask / bias gradient of conv1 fused into conv2's) against the library ones."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import make_res_layer
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(0)
+        layer = make_res_layer(256, 128, 2, 2, 1, 'pytorch', dict(type='BN', requires_grad=True)).to(dev)
+        layer.eval()
+        for m in layer.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+                torch.nn.init.normal_(m.bias, 0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.2)
+        g = torch.Generator(device=dev).manual_seed(1)
+        x0 = torch.randn(2, 256, 30, 44, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        gy = torch.randn(2, 512, 15, 22, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+        res = {}
+        for mode in (True, False):
+            monkeypatch.setattr(hip_conv, 'S2_DGRAD', mode)
+            layer.zero_grad(set_to_none=True)
+            x = torch.relu(x0).clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                y = layer(x)
+            y.backward(gy)
+            res[mode] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in layer.named_parameters()})
+        assert torch.equal(res[True][0], res[False][0])
+
+        def close(a, b, what):
+            d = (a - b).abs()
+            assert d.max().item() <= 3e-2 * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
+            assert d.mean().item() <= 5e-3 * b.abs().mean().item() + 1e-7, (what, d.mean().item(), b.abs().mean().item())
+        close(res[True][1], res[False][1], 'x.grad')
+        for n in res[False][2]:
+            close(res[True][2][n], res[False][2][n], n)
+    finally:
+        hip_conv.enable(False)

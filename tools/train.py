@@ -126,29 +126,67 @@ def main():
     epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
     iters_per_epoch = len(ds) // (bs * world)
     interval = cfg.get('log_config', {}).get('interval', 50)
-    it, t0 = start_iter, time.time()
-    for epoch in range(epochs):
-        for k in range(iters_per_epoch):
-            if a.max_iters is not None and it >= a.max_iters:
-                break
-            sched.set(epoch, it)
-            base = (epoch * iters_per_epoch + k) * bs * world + rank * bs
-            imgs, boxes, labels = ds.batch([(base + j) % len(ds) for j in range(bs)])
-            out = engine.step(pipe(imgs, boxes, labels))
-            it += 1
-            if rank == 0 and it % interval == 0:
-                lv = {n: float(v) for n, v in out['log_vars'].items()}
-                print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
-                      f'time: {(time.time() - t0) / (it - start_iter):.3f} ' +
-                      ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
+
+    def save_checkpoint(epoch, it):
         if rank == 0 and cfg.get('checkpoint_config', {}).get('interval', 0):
-            path = os.path.join(work_dir, f'epoch_{epoch + 1}.pth')
-            torch.save(dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
-                            meta=dict(iter=it, epoch=epoch + 1, mmdet_version='2.20.0-compatible keys')), path)
-            torch.save(dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
-                            meta=dict(iter=it, epoch=epoch + 1)), os.path.join(work_dir, 'latest.pth'))
+            state = dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
+                         meta=dict(iter=it, epoch=epoch + 1, mmdet_version='2.20.0-compatible keys'))
+            torch.save(state, os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
+            torch.save(state, os.path.join(work_dir, 'latest.pth'))
+
+    it, t0 = start_iter, time.time()
+    # software pipeline, the analogue of the reference's DataLoader workers: a loader thread produces batch i+2 (decode +
+    # pinned upload, or the synthetic generator), the pipeline worker augments batch i+1 on its side stream (own numpy
+    # stream, seeded like a DataLoader worker: datasets/builder.py:194-199), the main thread trains on batch i
+    from concurrent.futures import ThreadPoolExecutor
+
+    def index_lists():
+        for epoch in range(epochs):
+            for k in range(iters_per_epoch):
+                base = (epoch * iters_per_epoch + k) * bs * world + rank * bs
+                yield epoch, k, [(base + j) % len(ds) for j in range(bs)]
+
+    def load(item):
+        torch.cuda.set_device(dev)
+        batch = ds.batch(item[2])
+        ready = torch.cuda.Event()
+        ready.record()
+        return item, batch, ready
+    loader = ThreadPoolExecutor(1, thread_name_prefix='oadg-loader')
+    wseed = seed + rank + 1000
+    todo = index_lists()
+    pending_load = [loader.submit(load, i) for i in [next(todo, None)] if i is not None]
+    staged = []          # (epoch, k, prefetched batch)
+
+    def advance():
+        if pending_load:
+            item, batch, ready = pending_load.pop(0).result()
+            nxt = next(todo, None)
+            if nxt is not None:
+                pending_load.append(loader.submit(load, nxt))
+            staged.append((item[0], item[1], pipe.prefetch(*batch, worker_seed=wseed, ready=ready)))
+    advance()
+    last_epoch = None
+    while staged:
+        epoch, k, handle = staged.pop(0)
         if a.max_iters is not None and it >= a.max_iters:
             break
+        if last_epoch is not None and epoch != last_epoch:
+            save_checkpoint(last_epoch, it)
+        last_epoch = epoch
+        sched.set(epoch, it)
+        data = handle.get()
+        advance()                        # batch i+1 is augmented while this step runs
+        out = engine.step(data)
+        it += 1
+        if rank == 0 and it % interval == 0:
+            lv = {n: float(v) for n, v in out['log_vars'].items()}
+            print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
+                  f'time: {(time.time() - t0) / (it - start_iter):.3f} ' +
+                  ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
+    if last_epoch is not None:
+        save_checkpoint(last_epoch, it)
+    loader.shutdown(wait=False, cancel_futures=True)
 
 
 if __name__ == '__main__':
