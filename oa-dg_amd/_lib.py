@@ -55,6 +55,7 @@ SIGNATURES = {
     'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_relu_bias_bwd_workspace_bytes': (ctypes.c_size_t, [cl, ci]),
     'oadg_relu_bias_bwd': (ci, [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, cl, ci, vp]),
+    'oadg_stem_conv7x7s2_nhwc_bf16': (ci, [vp, vp, vp, ci, ci, ci, vp]),
     'oadg_bias_relu_maxpool_nhwc_bf16': (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     'oadg_fpn_topdown_fwd': (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_fpn_topdown_bwd': (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),

@@ -5,9 +5,14 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn.modules.batchnorm import _BatchNorm
 
+import os
+
 from . import hip_conv
 from .layers import Conv2d, build_norm_layer, constant_init, conv_bn, kaiming_init
 from .registry import BACKBONES
+
+
+STEM_KERNEL = os.environ.get('OADG_STEM_KERNEL', '1') == '1'      # own 7x7/s2 stem convolution (else MIOpen)
 
 
 class Bottleneck(nn.Module):
@@ -134,7 +139,15 @@ class ResNet(nn.Module):
                 (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) and c.out_channels % 8 == 0 and \
                 (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False):
             w, b = layers.folded_frozen(c, bn)
-            y = F.conv2d(x.to(torch.bfloat16), w.to(torch.bfloat16), None, c.stride, c.padding, c.dilation)
+            x = x.to(torch.bfloat16)
+            if STEM_KERNEL and tuple(w.shape) == (64, 3, 7, 7) and (c.stride, c.padding, c.dilation) == \
+                    ((2, 2), (3, 3), (1, 1)) and x.shape[3] % 2 == 0 and x.numel() < (1 << 31):
+                wp = getattr(c, '_stem_wp', None)
+                if wp is None or wp[0] is not w:
+                    wp = c._stem_wp = (w, hip_ops.stem_weights(w))
+                y = hip_ops.stem_conv(x, wp[1])          # csrc/stem_conv.hip: 7x7/s2 on the matrix cores
+            else:
+                y = F.conv2d(x, w.to(torch.bfloat16), None, c.stride, c.padding, c.dilation)
             return hip_ops.bias_relu_maxpool(y, b)
         return mp(conv_bn(x, c, bn, relu=True))
 

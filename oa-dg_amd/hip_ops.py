@@ -219,6 +219,29 @@ def fpn_topdown(lat, top):
 
 
 # --------------------------------------------------------------------------------------- NMS
+def stem_conv(x, wp):
+    """conv2d(x [N,3,H,W], w [64,3,7,7], stride 2, padding 3) without bias for a bf16 channels_last image (W even), on the
+    MFMA stem kernel (csrc/stem_conv.hip); ``wp`` from :func:`stem_weights`.  No gradient (frozen stem)."""
+    require_cuda(x)
+    assert x.dtype == torch.bfloat16 and x.shape[1] == 3 and x.shape[3] % 2 == 0 and not x.requires_grad
+    x = x.contiguous(memory_format=torch.channels_last)
+    N, _, H, W = x.shape
+    y = torch.empty((N, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
+                    memory_format=torch.channels_last)
+    check(_lib.lib().oadg_stem_conv7x7s2_nhwc_bf16(ptr(x), ptr(wp), ptr(y), N, H, W, stream_ptr()),
+          'oadg_stem_conv7x7s2_nhwc_bf16')
+    return y
+
+
+def stem_weights(w):
+    """fp32 [64,3,7,7] -> bf16 [64][7][8][4]: filter row, 8 input pixels (the first one left of the filter: zero), 4
+    channels (the fourth zero) - the reduction order of the stem kernel."""
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    wp = torch.zeros((64, 7, 8, 4), dtype=torch.bfloat16, device=w.device)
+    wp[:, :, 1:, :3] = w.detach().permute(0, 2, 3, 1).to(torch.bfloat16)
+    return wp.contiguous()
+
+
 def bias_relu_maxpool(x, bias):
     """max_pool2d(relu(x + bias[None, :, None, None]), 3, 2, 1) for a bf16 channels_last map without gradient (the frozen
     ResNet stem, resnet.py:631-637): one pass over the 537 MB stem output instead of three."""

@@ -62,5 +62,8 @@ class FPN(nn.Module):
                                                                   **self.upsample_cfg)
         outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
         for _ in range(self.num_outs - len(outs)):   # fpn.py:184-188
-            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+            # fpn.py:177-181 `F.max_pool2d(outs[-1], 1, stride=2)`: a kernel-1 pool is a strided subsample - the same
+            # values without the pooling library (whose kernels are compiled per shape)
+            last = outs[-1][:, :, ::2, ::2]
+            outs.append(last.contiguous(memory_format=torch.channels_last) if last.dim() == 4 and last.is_cuda else last)
         return tuple(outs)
