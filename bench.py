@@ -152,6 +152,8 @@ def main():
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     det.log_vars_on_host = False             # log_vars stay on the device (read at a log interval in training)
     engine = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=distributed, amp_dtype=amp)
+    if a.conv == 'miopen':
+        hip_conv.enable(False)               # (the engine enables the MFMA convolutions for bf16 training)
     set_random_seed(1 + rank)                # per-rank data / augmentation streams
     ds = SyntheticCityscapes(img_shape=(a.height, a.width), num_boxes=20, num_classes=8, seed=rank, device=dev)
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=amp or torch.float32)

@@ -217,6 +217,10 @@ class TrainEngine:
         dev = next(model.parameters()).device
         self.stream = torch.cuda.Stream(device=dev, priority=int(prio)) if (dev.type == 'cuda' and prio != 'none') else None
         from . import hip_conv
+        # bf16 training on the MI355X runs its convolutions on the csrc MFMA kernels (OADG_CONV=miopen: library path)
+        if amp_dtype is torch.bfloat16 and next(model.parameters()).is_cuda and \
+                os.environ.get('OADG_CONV', 'mfma') == 'mfma':
+            hip_conv.enable()
         # EXPERIMENTAL, off by default: weight gradients beside the data-gradient chain on a side stream (-1.4 ms per
         # step measured, but tools/probe/side_debug2.py still shows a cross-stream race in some weight gradients)
         hip_conv.WGRAD_SIDE_STREAM = os.environ.get('OADG_WGRAD_STREAM', '0') == '1' and \
