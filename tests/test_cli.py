@@ -1,0 +1,62 @@
+"""The drop-in CLI surface: tools/train.py and tools/test.py accept the reference's flags
+(tools/train.py:22-89, tools/test.py:24-130) and tools/dist_train.sh exists with the reference's calling convention."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(f'oadg_tools_{name}', os.path.join(ROOT, 'tools', f'{name}.py'))
+    mod = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.pop(0)
+    return mod
+
+
+def test_train_cli_accepts_the_reference_flags(monkeypatch):
+    train = _load('train')
+    monkeypatch.setattr(sys, 'argv', ['train.py', 'cfg.py', '--work-dir', 'w', '--resume-from', 'r.pth', '--auto-resume',
+                                      '--no-validate', '--gpu-ids', '0', '1', '--seed', '3', '--deterministic',
+                                      '--cfg-options', 'a.b=1', 'c=x', '--launcher', 'pytorch', '--local_rank', '2',
+                                      '--debug_mode'])
+    a = train.parse_args()
+    assert (a.config, a.work_dir, a.resume_from, a.auto_resume, a.no_validate) == ('cfg.py', 'w', 'r.pth', True, True)
+    assert a.gpu_ids == [0, 1] and a.seed == 3 and a.deterministic and a.launcher == 'pytorch' and a.local_rank == 2
+    assert a.cfg_options == {'a.b': '1', 'c': 'x'} and os.environ['LOCAL_RANK'] in ('2', os.environ['LOCAL_RANK'])
+    monkeypatch.setattr(sys, 'argv', ['train.py', 'cfg.py', '--gpus', '1', '--gpu-ids', '0'])
+    with pytest.raises(SystemExit):              # mutually exclusive, as in the reference
+        train.parse_args()
+    monkeypatch.setattr(sys, 'argv', ['train.py', 'cfg.py', '--options', 'a=1', '--cfg-options', 'b=2'])
+    with pytest.raises(ValueError):
+        train.parse_args()
+
+
+def test_test_cli_and_eval_map(monkeypatch):
+    import numpy as np
+    test = _load('test')
+    monkeypatch.setattr(sys, 'argv', ['test.py', 'cfg.py', 'ck.pth', '--out', 'r.pkl', '--eval', 'bbox', '--cfg-options',
+                                      'a=1', '--launcher', 'none', '--local_rank', '0'])
+    a = test.parse_args()
+    assert (a.config, a.checkpoint, a.out, a.eval) == ('cfg.py', 'ck.pth', 'r.pkl', ['bbox'])
+    # mean_ap.py semantics on a hand-checked case: class 0: 2 gts, detections (tp 0.9, fp 0.8, tp 0.7) -> AP = 0.5 + 0.5 * 2/3
+    res = [[np.array([[0, 0, 10, 10, 0.9], [50, 50, 60, 60, 0.8], [100, 100, 120, 120, 0.7]], np.float32),
+            np.zeros((0, 5), np.float32)]]
+    ann = [(np.array([[0, 0, 10, 10], [100, 100, 120, 120]], np.float32), np.array([0, 0]))]
+    m, aps = test.eval_map(res, ann, 2)
+    assert abs(aps[0] - (0.5 + 0.5 * 2 / 3)) < 1e-6 and len(aps) == 1 and abs(m - aps[0]) < 1e-12
+    # a duplicate detection of an already matched gt is a false positive
+    res = [[np.array([[0, 0, 10, 10, 0.9], [0, 0, 10, 10, 0.8]], np.float32), np.zeros((0, 5), np.float32)]]
+    ann = [(np.array([[0, 0, 10, 10]], np.float32), np.array([0]))]
+    assert abs(test.eval_map(res, ann, 2)[1][0] - 1.0) < 1e-6
+
+
+def test_dist_train_script_follows_the_reference_convention():
+    sh = open(os.path.join(ROOT, 'tools', 'dist_train.sh')).read()
+    assert 'CONFIG=$1' in sh and 'GPUS=$2' in sh and 'PORT' in sh and '--launcher pytorch' in sh
