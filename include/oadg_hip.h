@@ -242,7 +242,7 @@ int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float*
                                float* dgamma, int w_krsc, void* stream);
 
 /* ResNet stem convolution (backbones/resnet.py:585-596 conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) on the matrix
- * cores: x bf16 NHWC [N,H,W,3] (W even), wp = prepared weights bf16 [64][7][8][4] (k = filter row, 8 input pixels starting
+ * cores: x bf16 NHWC [N,H,W,3], wp = prepared weights bf16 [64][7][8][4] (k = filter row, 8 input pixels starting
  * one left of the filter - pixel 0 zero -, 4 channels - channel 3 zero), y = round_bf16(conv) NHWC [N,Ho,Wo,64] without
  * bias, Ho = (H-1)/2+1, Wo = (W-1)/2+1.  Replaces the cuDNN/MIOpen call of the reference for this layer. */
 int oadg_stem_conv7x7s2_nhwc_bf16(const void* x, const void* wp, void* y, int N, int H, int W, void* stream);

@@ -141,7 +141,7 @@ class ResNet(nn.Module):
             w, b = layers.folded_frozen(c, bn)
             x = x.to(torch.bfloat16)
             if STEM_KERNEL and tuple(w.shape) == (64, 3, 7, 7) and (c.stride, c.padding, c.dilation) == \
-                    ((2, 2), (3, 3), (1, 1)) and x.shape[3] % 2 == 0 and x.numel() < (1 << 31):
+                    ((2, 2), (3, 3), (1, 1)) and x.numel() < (1 << 31):
                 wp = getattr(c, '_stem_wp', None)
                 if wp is None or wp[0] is not w:
                     wp = c._stem_wp = (w, hip_ops.stem_weights(w))

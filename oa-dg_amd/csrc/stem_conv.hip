@@ -22,6 +22,7 @@ constexpr int ST_ROWB = ST_PC * 8;                         // bytes per patch ro
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+template <bool EVENW>
 __global__ __launch_bounds__(256) void stem_conv7x7s2_kernel(const unsigned short* __restrict__ x,
                                                             const unsigned short* __restrict__ wp,
                                                             unsigned short* __restrict__ y, int N, int H, int W,
@@ -30,34 +31,47 @@ __global__ __launch_bounds__(256) void stem_conv7x7s2_kernel(const unsigned shor
     __shared__ __attribute__((aligned(16))) unsigned short otile[4][16 * 64];          // per wave: 16 pixels x 64 ch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wo0 = blockIdx.x * ST_TW, ho0 = blockIdx.y * ST_TH, n = blockIdx.z;
-    // ---- zero the patch (channel 3 of every pixel and everything outside the image stay zero)
+    // ---- stage: image rows 2*ho0 - 3 .. +12, pixels 2*wo0 - 4 .. +133 (3 channels, 6 bytes) -> 8-byte LDS pixels.
+    // Item i = (patch row, dword d of the row segment) holds elements 2d, 2d+1 (element e = pixel e / 3, channel e % 3).
+    // W even: rows and the segment start are dword aligned, so a dword lies entirely inside or outside the image row and
+    // one predicated 4-byte load per item does; W odd: two 2-byte loads.  All loads of a thread are issued before the
+    // first LDS write (no control flow between them).
+    constexpr int NDW = (134 * 3 + 1) / 2;            // 201 dwords per row
+    constexpr int NIT = (ST_PR * NDW + 255) / 256;    // 11 items per thread
+    const int px0 = 2 * wo0 - 4;
+    unsigned v[NIT];
+    unsigned ok[NIT];                                  // bit 0 / 1: low / high element inside the image
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int pr = i / NDW, d = i - pr * NDW;
+        const int row = 2 * ho0 - 3 + pr;
+        const bool rowok = i < ST_PR * NDW && (unsigned)row < (unsigned)H;
+        const int e0 = 2 * d, p0 = e0 / 3, p1 = (e0 + 1) / 3;
+        const bool in0 = rowok && (unsigned)(px0 + p0) < (unsigned)W;
+        const bool in1 = rowok && (unsigned)(px0 + p1) < (unsigned)W;
+        const long base = ((long)n * H + row) * W * 3 + (long)px0 * 3 + e0;
+        if (EVENW) {
+            v[it] = in0 ? *reinterpret_cast<const unsigned*>(x + base) : 0u;
+            ok[it] = in0 ? 3u : 0u;
+        } else {
+            const unsigned lo = in0 ? x[base] : 0u, hi = in1 ? x[base + 1] : 0u;
+            v[it] = lo | (hi << 16);
+            ok[it] = (in0 ? 1u : 0u) | (in1 ? 2u : 0u);
+        }
+    }
+    // ---- zero the patch (channel 3 of every pixel and everything outside the image stay zero), then scatter
     for (int i = tid; i < ST_PR * ST_ROWB / 16; i += 256) reinterpret_cast<uint4*>(patch)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    // ---- stage: image rows 2*ho0 - 3 .. +12, pixels 2*wo0 - 4 .. +133 (3 channels, 6 bytes) -> 8-byte LDS pixels.
-    // The row segment starts on a 4-byte boundary (W even): dword d holds elements 2d, 2d+1 of the segment.
     {
-        const int px0 = 2 * wo0 - 4;
-        constexpr int NDW = (134 * 3 + 1) / 2;            // 201 dwords per row
-        for (int i = tid; i < ST_PR * NDW; i += 256) {
+        unsigned short* p16 = reinterpret_cast<unsigned short*>(patch);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
             const int pr = i / NDW, d = i - pr * NDW;
-            const int row = 2 * ho0 - 3 + pr;
-            if ((unsigned)row >= (unsigned)H) continue;
-            const long base = ((long)n * H + row) * W * 3 + (long)px0 * 3;      // element index of the segment start
-            const int e0 = 2 * d;
-            // both elements of the dword must be inside the image row
-            const int p0 = e0 / 3, c0 = e0 - p0 * 3, p1 = (e0 + 1) / 3, c1 = (e0 + 1) - p1 * 3;
-            const bool in0 = (unsigned)(px0 + p0) < (unsigned)W && p0 < 134;
-            const bool in1 = (unsigned)(px0 + p1) < (unsigned)W && p1 < 134;
-            if (!in0 && !in1) continue;
-            unsigned v;
-            if (in0 && in1) {
-                v = *reinterpret_cast<const unsigned*>(x + base + e0);
-            } else {
-                v = in0 ? (unsigned)x[base + e0] : ((unsigned)x[base + e0 + 1] << 16);
-            }
-            unsigned short* prow = reinterpret_cast<unsigned short*>(patch + pr * ST_ROWB);
-            if (in0) prow[p0 * 4 + c0] = (unsigned short)(v & 0xffffu);
-            if (in1) prow[p1 * 4 + c1] = (unsigned short)(v >> 16);
+            const int e0 = 2 * d, p0 = e0 / 3, c0 = e0 - p0 * 3, p1 = (e0 + 1) / 3, c1 = (e0 + 1) - p1 * 3;
+            if (ok[it] & 1u) p16[pr * (ST_ROWB / 2) + p0 * 4 + c0] = (unsigned short)(v[it] & 0xffffu);
+            if (ok[it] & 2u) p16[pr * (ST_ROWB / 2) + p1 * 4 + c1] = (unsigned short)(v[it] >> 16);
         }
     }
     // ---- weights: A[channel = nt*16 + (lane & 15)][k = r*32 + (lane >> 4)*8 ..] = 8 contiguous bf16 of wp [64][7][32]
@@ -118,12 +132,16 @@ __global__ __launch_bounds__(256) void stem_conv7x7s2_kernel(const unsigned shor
 }  // namespace
 
 extern "C" int oadg_stem_conv7x7s2_nhwc_bf16(const void* x, const void* wp, void* y, int N, int H, int W, void* stream) {
-    if (!x || !wp || !y || N < 1 || H < 1 || W < 2 || (W & 1)) return OADG_EARG;
+    if (!x || !wp || !y || N < 1 || H < 1 || W < 1) return OADG_EARG;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((long)N * H * W * 3 >= (1L << 31)) return OADG_EARG;
     dim3 grid((Wo + ST_TW - 1) / ST_TW, (Ho + ST_TH - 1) / ST_TH, N);
-    hipLaunchKernelGGL(stem_conv7x7s2_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
-                       (const unsigned short*)wp, (unsigned short*)y, N, H, W, Ho, Wo);
+    if (W & 1)
+        hipLaunchKernelGGL(stem_conv7x7s2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)wp, (unsigned short*)y, N, H, W, Ho, Wo);
+    else
+        hipLaunchKernelGGL(stem_conv7x7s2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned short*)x, (const unsigned short*)wp, (unsigned short*)y, N, H, W, Ho, Wo);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

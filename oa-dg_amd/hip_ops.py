@@ -220,10 +220,10 @@ def fpn_topdown(lat, top):
 
 # --------------------------------------------------------------------------------------- NMS
 def stem_conv(x, wp):
-    """conv2d(x [N,3,H,W], w [64,3,7,7], stride 2, padding 3) without bias for a bf16 channels_last image (W even), on the
+    """conv2d(x [N,3,H,W], w [64,3,7,7], stride 2, padding 3) without bias for a bf16 channels_last image, on the
     MFMA stem kernel (csrc/stem_conv.hip); ``wp`` from :func:`stem_weights`.  No gradient (frozen stem)."""
     require_cuda(x)
-    assert x.dtype == torch.bfloat16 and x.shape[1] == 3 and x.shape[3] % 2 == 0 and not x.requires_grad
+    assert x.dtype == torch.bfloat16 and x.shape[1] == 3 and not x.requires_grad
     x = x.contiguous(memory_format=torch.channels_last)
     N, _, H, W = x.shape
     y = torch.empty((N, 64, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.bfloat16, device=x.device,
