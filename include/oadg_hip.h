@@ -71,11 +71,16 @@ int oadg_ce_jsd_bwd(const float* logits, const int64_t* labels, const float* wei
 int oadg_roi_align_fwd(const void* const* feats_host, const int* heights_host, const int* widths_host,
                        const float* scales_host, int levels, int N, int C, int dtype, float finest_scale,
                        const float* rois, int K, int PH, int PW, int sampling_ratio, int aligned,
-                       void* out, void* stream);
+                       void* out, const int* order, void* stream);
 int oadg_roi_align_bwd(float* const* dfeats_host, const int* heights_host, const int* widths_host,
                        const float* scales_host, int levels, int N, int C, int dtype, float finest_scale,
                        const float* rois, int K, int PH, int PW, int sampling_ratio, int aligned,
-                       const void* grad_out, void* stream);
+                       const void* grad_out, const int* order, void* stream);
+/* order (optional, int32 [K], NULL = 0..K-1): workgroup b processes RoI order[b]; results do not depend on it.
+ * oadg_roi_order_keys writes an int64 key per RoI (level, image, 16-feature-pixel cell of the centre); processing the RoIs
+ * in argsort(keys) order keeps the feature rows / gradient lines of neighbouring RoIs in L2. */
+int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float finest_scale, long long* keys,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy NMS, batched over images

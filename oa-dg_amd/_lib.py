@@ -32,9 +32,10 @@ SIGNATURES = {
     'oadg_ce_jsd_fwd': (ci, [vp, vp, vp, cl, ci, ci, cf, cf, cf, vp, cs, vp, vp]),
     'oadg_ce_jsd_bwd': (ci, [vp, vp, vp, cl, ci, ci, cf, cf, cf, vp, vp, vp]),
     'oadg_roi_align_fwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
-                                vp, ci, ci, ci, ci, ci, vp, vp]),
+                                vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_roi_align_bwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
-                                vp, ci, ci, ci, ci, ci, vp, vp]),
+                                vp, ci, ci, ci, ci, ci, vp, vp, vp]),
+    'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_resize_bilinear_u8': (ci, [vp, ci, ci, ci, vp, ci, ci, vp]),

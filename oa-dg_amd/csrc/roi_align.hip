@@ -33,6 +33,7 @@ struct Pyramid {
     int N;
     int C;
     float finest_scale;
+    const int* order;      // optional: workgroup b handles RoI order[b] (spatially sorted RoIs share cache lines)
 };
 
 // single_level_roi_extractor.py:50-54
@@ -110,7 +111,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const float* __restrict__ rois,
                                                             int K, int PH, int PW, int sampling_ratio,
                                                             int aligned, T* __restrict__ out) {
-    const int k = blockIdx.x;
+    const int k = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* roi = rois + (size_t)k * 5;
     const RoiGeom g = roi_geom(roi, p, PH, PW, sampling_ratio, aligned);
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const flo
     __shared__ int oy[RB_MAXP], ny[RB_MAXP], ox[RB_MAXP], nx[RB_MAXP];
     __shared__ int overflow;
     __shared__ T slab[RB_MAXP * RB_MAXP * 256];
-    const int k = blockIdx.x;
+    const int k = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* roi = rois + (size_t)k * 5;
     const RoiGeom g = roi_geom(roi, p, PH, PW, sampling_ratio, aligned);
@@ -299,10 +300,31 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(Pyramid p, const flo
     }
 }
 
+// sort key of a RoI for the processing order of the two kernels above: (pyramid level, image, 16-feature-pixel cell
+// of the RoI centre, row-major).  Proposals cluster around objects: workgroups that run together then read the same
+// feature rows and - backward - add into the same gradient lines while those are still in L2.
+__global__ void roi_order_key_kernel(const float* __restrict__ rois, int K, int n_img, int levels, float finest_scale,
+                                     long long* __restrict__ keys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float* r = rois + (size_t)k * 5;
+    const float w = fmaxf(r[3] - r[1], 0.f), h = fmaxf(r[4] - r[2], 0.f);
+    float l = floorf(log2f(sqrtf(w * h) / finest_scale + 1e-6f));
+    l = fminf(fmaxf(l, 0.f), (float)(levels - 1));
+    const int lvl = (int)l;
+    const float cell = 64.f * (float)(1 << lvl);
+    int qx = (int)((r[1] + r[3]) * 0.5f / cell), qy = (int)((r[2] + r[4]) * 0.5f / cell);
+    qx = qx < 0 ? 0 : (qx > 1023 ? 1023 : qx);
+    qy = qy < 0 ? 0 : (qy > 1023 ? 1023 : qy);
+    int b = (int)r[0];
+    b = b < 0 ? 0 : (b >= n_img ? n_img - 1 : b);
+    keys[k] = (((long long)lvl * n_img + b) * 1024 + qy) * 1024 + qx;
+}
+
 int fill_pyramid(Pyramid& p, const void* const* feats, float* const* dfeats, const int* heights,
                  const int* widths, const float* scales, int levels, int N, int C, float finest_scale) {
     if (levels < 1 || levels > OADG_MAX_LEVELS || N < 1 || C < 4 || (C & 3)) return OADG_EARG;
-    p.levels = levels; p.N = N; p.C = C; p.finest_scale = finest_scale;
+    p.levels = levels; p.N = N; p.C = C; p.finest_scale = finest_scale; p.order = nullptr;
     for (int l = 0; l < levels; ++l) {
         if ((feats && !feats[l]) || (dfeats && !dfeats[l]) || heights[l] < 1 || widths[l] < 1) return OADG_EARG;
         p.feat[l] = feats ? feats[l] : nullptr;
@@ -320,12 +342,13 @@ extern "C" {
 int oadg_roi_align_fwd(const void* const* feats, const int* heights, const int* widths,
                        const float* scales, int levels, int N, int C, int dtype, float finest_scale,
                        const float* rois, int K, int PH, int PW, int sampling_ratio, int aligned,
-                       void* out, void* stream) {
+                       void* out, const int* order, void* stream) {
     if (!feats || !heights || !widths || !scales || !rois || !out) return OADG_EARG;
     if (K < 0 || PH < 1 || PW < 1 || (dtype != 0 && dtype != 1)) return OADG_EARG;
     Pyramid p;
     const int rc = fill_pyramid(p, feats, nullptr, heights, widths, scales, levels, N, C, finest_scale);
     if (rc) return rc;
+    p.order = order;
     if (K == 0) return OADG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
@@ -338,16 +361,28 @@ int oadg_roi_align_fwd(const void* const* feats, const int* heights, const int* 
     return OADG_OK;
 }
 
+// keys[k] (int64) = locality sort key of RoI k; `order` of the two functions above = argsort(keys) as int32
+int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float finest_scale, long long* keys,
+                        void* stream) {
+    if (!rois || !keys || K < 0 || n_img < 1 || levels < 1 || levels > OADG_MAX_LEVELS) return OADG_EARG;
+    if (K == 0) return OADG_OK;
+    hipLaunchKernelGGL(roi_order_key_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, rois, K, n_img,
+                       levels, finest_scale, keys);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
 // Accumulates into the fp32 gradient maps dfeats[l] ([N, H_l, W_l, C], caller zero-initialises).
 int oadg_roi_align_bwd(float* const* dfeats, const int* heights, const int* widths, const float* scales,
                        int levels, int N, int C, int dtype, float finest_scale, const float* rois, int K,
                        int PH, int PW, int sampling_ratio, int aligned, const void* grad_out,
-                       void* stream) {
+                       const int* order, void* stream) {
     if (!dfeats || !heights || !widths || !scales || !rois || !grad_out) return OADG_EARG;
     if (K < 0 || PH < 1 || PW < 1 || (dtype != 0 && dtype != 1)) return OADG_EARG;
     Pyramid p;
     const int rc = fill_pyramid(p, nullptr, dfeats, heights, widths, scales, levels, N, C, finest_scale);
     if (rc) return rc;
+    p.order = order;
     if (K == 0) return OADG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)

@@ -5,6 +5,7 @@ torch's, plumbing only) and enqueues the HIP kernels on torch's current stream. 
 hot path happens in Python and nothing here falls back to torch ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -133,6 +134,9 @@ def _as_nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+ROI_LOCALITY_ORDER = os.environ.get('OADG_ROI_ORDER', '1') == '1'
+
+
 class _RoIAlignFPN(torch.autograd.Function):
 
     @staticmethod
@@ -150,17 +154,26 @@ class _RoIAlignFPN(torch.autograd.Function):
         out = torch.empty((K, C, PH, PW), dtype=dt, device=rois.device,
                           memory_format=torch.channels_last)
         P, Hs, Ws, Ss = _pyramid_args(feats, scales)
+        order = None
+        if ROI_LOCALITY_ORDER and K >= 512:
+            # process the RoIs level by level, image by image, cell by cell (the result does not depend on the order):
+            # neighbouring RoIs share feature rows and - backward - gradient lines while those are still in L2
+            keys = torch.empty((K,), dtype=torch.int64, device=rois.device)
+            check(L.oadg_roi_order_keys(ptr(rois), K, N, len(feats), float(finest_scale), ptr(keys), stream_ptr()),
+                  'oadg_roi_order_keys')
+            order = keys.argsort().int()
         check(_timed('roi_align_fwd', L.oadg_roi_align_fwd, P, Hs, Ws, Ss, len(feats), N, C,
                      0 if dt == torch.float32 else 1, float(finest_scale), ptr(rois), K, PH, PW,
-                     int(sampling_ratio), int(bool(aligned)), ptr(out), stream_ptr()), 'oadg_roi_align_fwd')
-        ctx.save_for_backward(rois)
+                     int(sampling_ratio), int(bool(aligned)), ptr(out), ptr(order), stream_ptr()), 'oadg_roi_align_fwd')
+        ctx.save_for_backward(rois, order if order is not None else rois.new_zeros(0))
         ctx.meta = ([tuple(f.shape) for f in feats], dt, tuple(scales), float(finest_scale),
                     int(sampling_ratio), int(bool(aligned)), (PH, PW))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (rois,) = ctx.saved_tensors
+        rois, order = ctx.saved_tensors
+        order = order if order.numel() else None
         shapes, dt, scales, finest_scale, sampling_ratio, aligned, (PH, PW) = ctx.meta
         L = _lib.lib()
         gout = gout.contiguous(memory_format=torch.channels_last)
@@ -172,7 +185,7 @@ class _RoIAlignFPN(torch.autograd.Function):
         P, Hs, Ws, Ss = _pyramid_args(grads, scales)
         check(_timed('roi_align_bwd', L.oadg_roi_align_bwd, P, Hs, Ws, Ss, len(grads), N, C,
                      0 if dt == torch.float32 else 1, finest_scale, ptr(rois), rois.shape[0], PH, PW,
-                     sampling_ratio, aligned, ptr(gout), stream_ptr()), 'oadg_roi_align_bwd')
+                     sampling_ratio, aligned, ptr(gout), ptr(order), stream_ptr()), 'oadg_roi_align_bwd')
         grads = [g if dt == torch.float32 else g.to(dt) for g in grads]
         return (None, None, None, None, None, None, *grads)
 
