@@ -81,3 +81,29 @@ def test_two_rank_data_parallel_step(torch_ddp):
     if len(_RESULTS) == 2:             # the lean reducer and torch DDP average to the same gradients / parameters
         assert np.allclose(_RESULTS[False][0], _RESULTS[True][0], rtol=1e-6, atol=1e-9)
         assert np.allclose(_RESULTS[False][1], _RESULTS[True][1], rtol=1e-6, atol=1e-9)
+
+
+def test_flat_reducer_layout_helpers_and_tail_bucket(monkeypatch):
+    """FlatGradReducer without a process group: gradient slices carry the parameter's memory layout (channels_last conv
+    weights), gradients land in parameter memory order whatever their own strides, and the last-ready parameters get a
+    small bucket of their own."""
+    import torch.nn as nn
+    from oadg_amd import apis
+    R = apis.FlatGradReducer
+    p = torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    flat = torch.zeros(p.numel())
+    v = R._like_param(flat, p)
+    assert v.stride() == p.stride() and v.shape == p.shape
+    for g in (torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last), torch.randn(8, 4, 3, 3)):
+        torch.cat([R._memory_order(g, p)], out=flat)
+        assert torch.equal(v, g)
+    monkeypatch.setattr(apis.dist, 'get_world_size', lambda g=None: 1)
+    monkeypatch.setattr(apis.dist, 'broadcast', lambda *a, **k: None)
+    net = nn.Sequential(nn.Conv2d(8, 8, 3), nn.Conv2d(8, 16, 3), nn.Linear(64, 4096), nn.Linear(4096, 512))
+    red = R(net, bucket_mb=4, tail_mb=1)
+    sizes = [b['end'] - b['start'] for b in red.buckets]
+    assert sum(sizes) == sum(q.numel() for q in net.parameters())
+    assert red.buckets[0]['params'][0] is list(net.parameters())[-1]          # reverse registration order
+    assert sizes[-1] * 4 <= (1 << 20) and red.buckets[-1]['params'][-1] is list(net.parameters())[0]
+    for q in net.parameters():
+        assert red.views[q].shape == q.shape and red.views[q].stride() == q.stride()
