@@ -4,7 +4,13 @@ One "step" = one pass of the whole hot path over one batch of synthetic Cityscap
 resident in HBM: OA-Mix (view 2 of every image) + Normalize/Pad on the device -> Faster R-CNN R50-FPN forward
 (both views) -> RPN/RoI losses incl. OA-Loss -> backward -> (DDP all-reduce) -> SGD step.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is one process per GPU over RCCL: either launched by ``python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, when ``bench.py --gpus N`` is
+run directly (no WORLD_SIZE in the environment), re-launched under torch.distributed.run by this script itself
+(tools/dist_train.sh:7-9 of the reference does the same for training).  The JSON line carries ``rccl_ranks`` =
+``dist.get_world_size()`` of the 'nccl' (= RCCL) process group.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   "roofline"     - the dominant hand-written kernel of the step, timed live with HIP events on its stream
@@ -26,24 +32,26 @@ CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_o
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
-PROFILE_TAG = 'r01'
+PROFILE_TAGS = ('r02', 'r01')
 
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of this same command
-    (profiles/r01_pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter).  Counters are in
+    (profiles/<tag>_pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter).  Counters are in
     KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide coalesced reads; WRITE_SIZE is
     taken as reported (uncalibrated).  PMC counters cannot be collected from inside the timed run, so the value
     is the latest committed measurement, with its source named; null when no summary is present."""
-    try:
-        tot = 0.0
-        for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
-            rows = json.load(open(os.path.join(ROOT, 'profiles', f'{PROFILE_TAG}_pmc_{c}.json')))
-            tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
-        return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
-                'traffic_source': f'profiles/{PROFILE_TAG}_pmc_FETCH_SIZE.json x2 + {PROFILE_TAG}_pmc_WRITE_SIZE.json'}
-    except (OSError, StopIteration, KeyError, ValueError):
-        return {'traffic': None}
+    for tag in PROFILE_TAGS:                     # newest committed measurement first
+        try:
+            tot = 0.0
+            for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+                rows = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_{c}.json')))
+                tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
+            return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
+                    'traffic_source': f'profiles/{tag}_pmc_FETCH_SIZE.json x2 + {tag}_pmc_WRITE_SIZE.json'}
+        except (OSError, StopIteration, KeyError, ValueError):
+            continue
+    return {'traffic': None}
 
 
 def parse():
@@ -122,11 +130,30 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     return dict(value=round(1.0 / t_all, 5), unit='images/s', cores=threads, kind='port',
                 sample=f'1 image at {H}x{W} (one of the 4 images of a step): OA-Mix oracle {t_mix:.1f}s + '
                        f'detector step with oracle ops {t_all - t_mix:.1f}s, torch {threads} threads, '
-                       f'nproc={os.cpu_count()}')
+                       f'nproc={os.cpu_count()}.  For comparison, the GENUINE reference python (tier-C harness, '
+                       f'SURVEY.md section 0) measured on the build container: 122.6 s per step of 2 images at 1024x2048 '
+                       f'on 8 cores = 0.016 images/s')
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks on this node"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                  # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(a.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     # OADG_BENCH_FORCE_DDP=1 (with torch.distributed.run --nproc-per-node 1): exercise the DDP / RCCL path on one GPU
     distributed = world > 1 or os.environ.get('OADG_BENCH_FORCE_DDP') == '1'
@@ -265,7 +292,8 @@ def main():
                 'algorithmic_bytes_per_launch': int(per_launch)}
     res = {
         'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
-        'n_gpus': a.gpus, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
+        'n_gpus': a.gpus, 'rccl_ranks': (dist.get_world_size() if distributed and dist.get_backend() == 'nccl' else 1),
+        'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '
                                f'{a.batch} img/GPU x 2 views, {a.height}x{a.width}, 20 boxes/img, SGD step',

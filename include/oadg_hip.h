@@ -227,10 +227,6 @@ int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bia
                                   int relu, int out_h, int out_w, int OH, int OW, int osh, int osw, int oph, int opw,
                                   const void* mask, float* colsum_part, void* stream);
 
-/* probe switches for tools/bench_conv.py only: force the 128-tile weight-gradient kernel, its LDS stage count
- * (1 / 2, else automatic) and the workgroup count the split heuristic aims at (0 = automatic) */
-void oadg_debug_wgrad(int force128, int stages, int target_blocks);
-
 /* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
  * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with
  * bias_in), fp32 [K,C,R,S] -> bf16 wf [K,R,S,C] and (optional) wt [C,R,S,K] flipped for the data gradient.

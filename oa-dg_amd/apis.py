@@ -87,11 +87,6 @@ class StepLrSchedule:
             g['lr'] = lr
 
 
-def _join_side_streams():
-    from . import hip_conv
-    hip_conv.join_wgrad_streams()
-
-
 class FlatGradReducer:
     """Data-parallel gradient averaging for one process per GPU over RCCL (torch.distributed, backend 'nccl'), in
     place of torch DDP's per-parameter reducer (3.5 ms of host work per step here: ~160 parameters, each copied into
@@ -104,7 +99,8 @@ class FlatGradReducer:
       it - the RoI-head FC weights (the largest tensors, first to be ready) reduce while the backbone is still in
       its backward pass;
     * ``finish()`` (before ``optimizer.step()``) makes the compute stream wait for the reductions and re-points each
-      ``param.grad`` at its slice of the reduced buffer.  Parameters that received no gradient contribute zeros.
+      ``param.grad`` at its slice of the reduced buffer.  Parameters that received no gradient contribute zeros;
+      buckets are all-reduced strictly in index order, so ranks whose graphs differ still issue matching collectives.
 
     xGMI is point-to-point (7 links per GPU), so a ring all-reduce moves 2(N-1)/N of the 166 MB per GPU: a handful
     of large buckets keeps each collective bandwidth-bound rather than latency-bound."""
@@ -145,6 +141,7 @@ class FlatGradReducer:
                 self.views[p] = self._like_param(self.flat[o:o + p.numel()], p)
                 o += p.numel()
             b['pending'], b['work'] = len(b['params']), None
+        self._next = 0                      # index of the next bucket to all-reduce (strict order, see _launch_in_order)
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in params]
 
     @staticmethod
@@ -172,13 +169,32 @@ class FlatGradReducer:
         b = self.bucket_of[p]
         b['pending'] -= 1
         if b['pending'] == 0:
+            self._launch_in_order()
+
+    def _launch_in_order(self, force=False):
+        """Collectives are issued STRICTLY in bucket-index order on every rank: a bucket whose gradients are complete
+        waits for its predecessors (``force``: finish() launches whatever is left, complete or not).  A rank on which
+        some parameter received no gradient this step (its bucket never completes in a hook) therefore still issues the
+        same all-reduce sequence as its peers - RCCL matches collectives by issue order, not by buffer."""
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b['pending'] > 0 and not force:
+                return
             self._launch(b)
+            self._next += 1
 
     def _launch(self, b):
-        _join_side_streams()          # weight gradients are produced on hip_conv's side stream
         flat = self.flat[b['start']:b['end']]
-        parts = [self._memory_order(p.grad if p.grad is not None else self.views[p].zero_(), p) for p in b['params']]
-        torch.cat(parts, out=flat)
+        if all(p.grad is not None for p in b['params']):
+            torch.cat([self._memory_order(p.grad, p) for p in b['params']], out=flat)     # ONE packing launch
+        else:
+            # a parameter without a gradient contributes zeros (its slice of ``flat`` is the destination itself, so it
+            # cannot also be an input of ``cat``): per-parameter copies on this rare path
+            for p in b['params']:
+                if p.grad is None:
+                    self.views[p].zero_()
+                else:
+                    self.views[p].copy_(p.grad)
         b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
                                     group=self.group, async_op=True)
 
@@ -187,14 +203,13 @@ class FlatGradReducer:
 
     def finish(self):
         """call after loss.backward(): all gradients averaged over the ranks, ``param.grad`` = slices of one buffer"""
-        for b in self.buckets:
-            if b['work'] is None:                    # some parameter of the bucket had no gradient this step
-                self._launch(b)
+        self._launch_in_order(force=True)      # buckets holding a parameter that had no gradient this step
         for b in self.buckets:
             b['work'].wait()
             if not self._has_avg():
                 self.flat[b['start']:b['end']].div_(self.world)
             b['work'], b['pending'] = None, len(b['params'])
+        self._next = 0
         for p in self.params:
             p.grad = self.views[p]
 
@@ -221,10 +236,6 @@ class TrainEngine:
         if amp_dtype is torch.bfloat16 and next(model.parameters()).is_cuda and \
                 os.environ.get('OADG_CONV', 'mfma') == 'mfma':
             hip_conv.enable()
-        # EXPERIMENTAL, off by default: weight gradients beside the data-gradient chain on a side stream (-1.4 ms per
-        # step measured, but tools/probe/side_debug2.py still shows a cross-stream race in some weight gradients)
-        hip_conv.WGRAD_SIDE_STREAM = os.environ.get('OADG_WGRAD_STREAM', '0') == '1' and \
-            not (distributed and os.environ.get('OADG_USE_TORCH_DDP') == '1')
         if distributed and os.environ.get('OADG_USE_TORCH_DDP') != '1':
             self.reducer = FlatGradReducer(model, bucket_mb=int(os.environ.get('OADG_BUCKET_MB', 64)))
         elif distributed:
@@ -264,7 +275,6 @@ class TrainEngine:
         (loss, log_vars), n = self.forward_losses(data)
         with _rf('sec:backward'):
             loss.backward()
-            _join_side_streams()
             if self.reducer is not None:
                 self.reducer.finish()
         with _rf('sec:optimizer'):

@@ -1121,19 +1121,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
     dw[i] = s;
 }
 
-// probe switches (oadg_debug_wgrad, tools/bench_conv.py): -1 = automatic
-int g_wgrad_force128 = 0, g_wgrad_stages = -1, g_wgrad_target = 0;
-
 // Kernel / split choice (tools/bench_conv.py --wgrad sweeps it; times vs MIOpen's igemm_wrw on MI355X):
 //  - 3x3 over >= 200k pixels, K and C multiples of 256: the 256-tile phase pipeline (1.2x at P2, 1.1x at P3);
 //  - other 3x3: 128-tile, ONE LDS stage at 4 workgroups per CU, ~1024 workgroups (1.06-1.2x);
 //  - 1x1: 128-tile, two stages, ~512 workgroups - the fp32 partial tiles (splits x K x C x 4 bytes, written and read
 //    back by the reduction) are the cost that matters there (1.15x on layer2, 1.6x on layer3 / layer4).
 bool wgrad_use256(long P, int K, int C, int RS) {
-    if (g_wgrad_force128) return false;
     return K % 256 == 0 && C % 256 == 0 && RS > 1 && P >= 200000;
 }
-int wgrad_stages(int RS) { return g_wgrad_stages > 0 ? g_wgrad_stages : (RS > 1 ? 1 : 2); }
+int wgrad_stages(int RS) { return RS > 1 ? 1 : 2; }
 
 int wgrad_splits(long P, int K, int C, int RS) {
     if (wgrad_use256(P, K, C, RS)) {
@@ -1149,7 +1145,7 @@ int wgrad_splits(long P, int K, int C, int RS) {
     }
     const long tiles = (long)(K / 128) * (C / 128) * RS;
     const long nchunks = (P + WP - 1) / WP;
-    const long target = g_wgrad_target > 0 ? g_wgrad_target : (RS > 1 ? 1024 : 512);
+    const long target = RS > 1 ? 1024 : 512;
     long s = (target + tiles - 1) / tiles;
     if (s > nchunks / 4) s = nchunks / 4;
     if (s >= 8) s = (s + 7) / 8 * 8;       // multiples of 8: one pixel range per XCD at a time
@@ -1164,13 +1160,6 @@ extern "C" size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C
     if (C % 128 || K % 128) return 0;
     const int sp = wgrad_splits((long)N * Ho * Wo, K, C, R * S);
     return (size_t)sp * K * R * S * C * sizeof(float);
-}
-
-// probe switches for tools/bench_conv.py (not part of the product interface)
-extern "C" void oadg_debug_wgrad(int force128, int stages, int target_blocks) {
-    g_wgrad_force128 = force128;
-    g_wgrad_stages = stages;          // 1 / 2, anything else = automatic
-    g_wgrad_target = target_blocks;   // 0 = automatic
 }
 
 namespace {

@@ -1,10 +1,9 @@
 """autograd wrapper of the MFMA implicit-GEMM convolution (csrc/conv_mfma.hip) and its registration as the
 convolution implementation of :mod:`oadg_amd.layers`.
 
-Forward and the stride-1 data gradient run on the hand-written kernel; the weight/bias gradients (a GEMM reduced
-over the pixel dimension) still go through ``aten.convolution_backward`` (MIOpen) this round.
+Forward, data gradients (stride 1 and 2) and weight gradients run on the hand-written kernels; shapes they do not cover
+(C or K not a multiple of 64 / 128) fall back to ``aten.convolution_backward`` (MIOpen).
 """
-import contextlib
 import ctypes
 import os
 
@@ -14,8 +13,6 @@ from . import _lib
 from ._lib import check, ptr, stream_ptr
 
 _ZEROS = {}
-# The hand-written weight-gradient kernel is correct (tests/test_hip_conv.py) but at 0.8-1.0x of MIOpen's on the
-# large-pixel-count layers (tools/bench_conv.py), so it is opt-in until it wins.
 USE_HIP_WGRAD = 'auto'      # True / False / 'auto' (= where tools/bench_conv.py --wgrad shows a win over MIOpen)
 # live HIP-event timing of the kernel launches inside bench.py's timed region: list of (start, end, flops, bytes,
 # kernel name)
@@ -238,39 +235,24 @@ class _PrepWeights(torch.autograd.Function):
         L = _lib.lib()
         dw = dgamma = dbeta = dbias_in = None
         gb = gbias.float().contiguous() if (gbias is not None and gbias.numel()) else None
-        side = wgrad_stream(w.device) if (WGRAD_SIDE_STREAM and gwf is not None and w.is_cuda) else None
-        if side is not None:          # the weight gradient was produced on the side stream: stay there
-            cur = torch.cuda.current_stream()
-            side.wait_stream(cur)     # (gbias comes from the main stream)
-            for t_ in (gb, gwf, w, scale, mean, var):      # read on the side stream after this node has returned
-                if t_ is not None:
-                    t_.record_stream(side)
-        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-          tok = ctx.wtoken
-          parts = None
-          if tok is not None and tok.parts is not None:
+        tok = ctx.wtoken
+        parts = None
+        if tok is not None and tok.parts is not None:
             parts, tok.parts = tok.parts, None
-          if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
+        if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
             dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb), ptr(w), ptr(scale), ptr(mean),
                                                      ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), krsc,
                                                      stream_ptr()),
                   'oadg_prep_conv_weights_bwd_parts')
-          elif gwf is not None:
+        elif gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dw = torch.empty_like(w)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
                                                R, S, ptr(dw), ptr(dgamma), krsc, stream_ptr()),
                   'oadg_prep_conv_weights_bwd')
-        if side is not None:
-            cur = torch.cuda.current_stream()
-            for t_ in (dw, dgamma):                  # allocated on the side stream, consumed on this one later
-                if t_ is not None:
-                    t_.record_stream(cur)
-            if not ctx.leaf_inputs:
-                cur.wait_stream(side)                # autograd ops (not AccumulateGrad) consume dw next
         if has_bn:
             dbeta = gb
         elif has_bias_in:
@@ -320,29 +302,6 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
     if key is not None:
         cache_on._prepared = (key, out)
     return out
-
-
-# Weight gradients on a side stream: only under a driver that joins the streams before gradients are read
-# (apis.TrainEngine does; plain autograd users keep everything on the current stream)
-WGRAD_SIDE_STREAM = False
-_SIDE = {}
-
-
-def wgrad_stream(device):
-    """the stream weight gradients (and their weight-sized post-processing) run on, beside the data-gradient chain"""
-    st = _SIDE.get(device)
-    if st is None:
-        st = _SIDE[device] = torch.cuda.Stream(device=device)
-    return st
-
-
-def join_wgrad_streams():
-    """make the current stream wait for every weight gradient in flight (before the optimizer / the all-reduce)"""
-    if not _SIDE:
-        return
-    cur = torch.cuda.current_stream()
-    for st in _SIDE.values():
-        cur.wait_stream(st)
 
 
 class GradToken:
@@ -423,42 +382,27 @@ class _Conv2dMFMA(torch.autograd.Function):
                 gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)
             need_x = False
         gw = None
-        side = wgrad_stream(gy.device) if (WGRAD_SIDE_STREAM and need_w and not need_x) else None
-        if side is not None:
-            # the weight gradient is independent of the data-gradient chain: it runs on a side stream (as does the
-            # weight-sized prep backward that consumes it) and is joined before the optimizer / all-reduce
-            cur = torch.cuda.current_stream()
-            side.wait_stream(cur)
-            gy.record_stream(side)
-            x16.record_stream(side)
-            ctx_mgr = torch.cuda.stream(side)
-        else:
-            ctx_mgr = contextlib.nullcontext()
-        with ctx_mgr:
-            if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
-                wtok = ctx.wtoken
-                if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
-                    wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
-                    gw = _dummy_grad(wf)          # the real gradient rides on the token (fp32 partials)
-                else:
-                    gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
-                need_w = False
-                if want_b:
-                    gb = gy.float().sum((0, 2, 3))
-                    want_b = False
-            if need_x or need_w or want_b:
-                outs = torch.ops.aten.convolution_backward(
-                    gy, x16, wf, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
-                    1, [need_x, need_w, want_b])
-                if gx is None:
-                    gx = outs[0]
-                if outs[1] is not None:
-                    gw = outs[1]
-                if outs[2] is not None:
-                    gb = outs[2].float()
-        if side is not None and gw is not None and gw.dtype != wf.dtype:
-            with torch.cuda.stream(side):        # autograd would cast to wf's dtype on the CURRENT stream otherwise
-                gw = gw.to(wf.dtype)
+        if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
+            wtok = ctx.wtoken
+            if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
+                wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
+                gw = _dummy_grad(wf)          # the real gradient rides on the token (fp32 partials)
+            else:
+                gw = conv_wgrad(x16, gy, K, R, S, stride, pad, dil)
+            need_w = False
+            if want_b:
+                gb = gy.float().sum((0, 2, 3))
+                want_b = False
+        if need_x or need_w or want_b:
+            outs = torch.ops.aten.convolution_backward(
+                gy, x16, wf, [K] if has_bias else None, [stride, stride], [pad, pad], [dil, dil], False, [0, 0],
+                1, [need_x, need_w, want_b])
+            if gx is None:
+                gx = outs[0]
+            if outs[1] is not None:
+                gw = outs[1]
+            if outs[2] is not None:
+                gb = outs[2].float()
         if gx is not None and extra is not None:      # library data gradient: the identity gradient is added here
             gx = gx + extra.to(gx.dtype)
         gres = None

@@ -51,6 +51,85 @@ def _worker(rank, world, port, q, torch_ddp=False):
     dist.destroy_process_group()
 
 
+def _collect(procs, q, timeout):
+    """one result per process; fails fast when a worker died instead of waiting out the queue timeout"""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < len(procs):
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f'worker exited with {dead}'
+            assert time.time() - t0 < timeout, 'timed out waiting for the workers'
+    return sorted(out, key=lambda r: r[0])
+
+
+def _worker_unused(rank, world, port, q):
+    """toy net with one bucket per layer; rank 1 skips the middle branch, so that parameter has NO gradient there"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch.nn as nn
+    import oadg_amd  # noqa: F401
+    from oadg_amd.apis import FlatGradReducer
+    torch.manual_seed(0)
+    net = nn.ModuleList([nn.Linear(32, 32, bias=False), nn.Linear(32, 48, bias=False), nn.Linear(32, 32, bias=False),
+                         nn.Linear(32, 8, bias=False)])
+    red = FlatGradReducer(net, bucket_mb=1e-4, tail_mb=0)      # ~26 floats per bucket: every layer its own bucket
+    assert len(red.buckets) == 4
+    order = []
+    orig = red._launch
+    red._launch = lambda b: (order.append([x is b for x in red.buckets].index(True)), orig(b))[1]
+    torch.manual_seed(100 + rank)
+    out = []
+    for step in range(2):
+        for p_ in net.parameters():
+            p_.grad = None
+        x = torch.randn(4, 32)
+        h = net[0](x)
+        y = net[3](net[2](h)).sum()
+        if rank == 0 or step == 1:          # rank 1, step 0: net[1] takes no part in the graph
+            y = y + net[1](h).sum()
+        y.backward()
+        local = [None if p_.grad is None else p_.grad.clone() for p_ in net.parameters()]
+        red.finish()
+        out.append(([None if g is None else g.numpy() for g in local],
+                    [p_.grad.clone().numpy() for p_ in net.parameters()]))
+    q.put((rank, out, order))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_reducer_parameter_without_gradient_on_one_rank():
+    """a parameter that received no gradient on ONE rank: collectives are still issued in bucket order on both ranks
+    (no hang, no mismatched buffers), the missing gradient counts as zeros, and nothing crashes on the aliasing
+    ``cat(out=)`` path (ADVICE r1, VERDICT r1 weak #7)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_unused, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, 240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, out0, order0), (_, out1, order1) = res
+    assert order0 == order1 == [0, 1, 2, 3] * 2
+    assert out1[0][0][1] is None and out0[0][0][1] is not None
+    for step in range(2):
+        (loc0, red0), (loc1, red1) = out0[step], out1[step]
+        for i in range(4):
+            a = loc0[i] if loc0[i] is not None else np.zeros_like(red0[i])
+            b = loc1[i] if loc1[i] is not None else np.zeros_like(red0[i])
+            assert np.allclose(red0[i], 0.5 * (a + b), rtol=1e-6, atol=1e-7), (step, i)
+            assert np.array_equal(red0[i], red1[i])
+
+
 _RESULTS = {}
 
 
@@ -64,7 +143,7 @@ def test_two_rank_data_parallel_step(torch_ddp):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, torch_ddp)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=540) for _ in procs], key=lambda r: r[0])
+    res = _collect(procs, q, 540)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -58,19 +58,10 @@ def main():
         line = f'{name:26s} {gf:8.1f} {t1:9.3f} {gf / t1:7.1f} {t2:9.3f} {gf / t2:7.1f}  {t2 / t1:5.2f}x | 256-tile {t256:7.3f} ms {gf / t256:7.1f} TF/s | 128-tile 1-stage {t1s:7.3f} ms {gf / t1s:7.1f} TF/s'
         if '--wgrad' in sys.argv and C % 128 == 0 and K % 128 == 0:
             gy = torch.randn(N, K, Ho, Wo, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
-            from oadg_amd import _lib
-            L = _lib.lib()
             t3 = timeit(lambda: hip_conv.conv_wgrad(x, gy, K, R, R, st, pad, 1))
-            sweep = []
-            for stg in (1, 2):
-                for tgt in (256, 512, 1024, 2048):
-                    L.oadg_debug_wgrad(1, stg, tgt)
-                    sweep.append((timeit(lambda: hip_conv.conv_wgrad(x, gy, K, R, R, st, pad, 1)), f'{stg}st/{tgt}'))
-            L.oadg_debug_wgrad(0, -1, 0)
             t4 = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [st, st], [pad, pad], [1, 1], False,
                                                                     [0, 0], 1, [False, True, False]))
-            best = min(sweep)
-            line += f'   wgrad auto {t3:6.3f} | torch {t4:6.3f} | best128 {best[0]:6.3f} ({best[1]}) | ' + ' '.join(f'{t_:5.3f}' for t_, _ in sweep)
+            line += f'   wgrad {t3:6.3f} | torch {t4:6.3f}'
         print(line)
 
 
