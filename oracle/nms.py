@@ -69,5 +69,8 @@ def batched_nms(boxes, scores, idxs, nms_cfg, class_agnostic=False):
         _, k = nms(b[m], scores[m], thr)
         mask[m[k]] = True
     keep = mask.nonzero(as_tuple=False).view(-1)
-    keep = keep[scores[keep].argsort(descending=True)]
+    # mmcv: keep[scores[keep].argsort(descending=True)] - an UNSTABLE argsort, so the order among exactly equal scores
+    # (saturated sigmoids are common) is whatever the torch build's sort does.  The restatement fixes it: ties in
+    # ascending input index, i.e. the same order the single-call branch above produces.
+    keep = keep[torch.sort(scores[keep], descending=True, stable=True)[1]]
     return torch.cat([boxes[keep], scores[keep].view(-1, 1)], 1), keep

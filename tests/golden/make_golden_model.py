@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 import refload  # noqa: E402
-from inputs import model_batch, named_weights  # noqa: E402
+from inputs import DC5_SCALE, model_batch, named_weights  # noqa: E402
 from oracle import nms as ONMS  # noqa: E402
 from oracle import roi_align as ORA  # noqa: E402
 
@@ -32,7 +32,11 @@ class OracleRoIAlign(nn.Module):
         return ORA.roi_align(x, rois, self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
 
 
-def build_reference_detector():
+def build_reference_detector(config='r50fpn'):
+    """config 'r50fpn': the reference's own configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py;
+    'dc5': BASELINE configs[3], which the reference does not ship - the model dict comes from this repo's composed
+    configs/oadg/faster_rcnn_r101_dc5_1x_dwd_oadg.py (reference type strings only) and is built by the REFERENCE's
+    registries, so every module executed is still reference code."""
     refload.install(ops=dict(RoIAlign=OracleRoIAlign, batched_nms=ONMS.batched_nms, nms=ONMS.nms))
     for m in ['mmdet.core.bbox.assigners.max_iou_assigner', 'mmdet.core.bbox.samplers.random_sampler',
               'mmdet.core.bbox.coder.delta_xywh_bbox_coder', 'mmdet.core.bbox.iou_calculators.iou2d_calculator',
@@ -43,20 +47,24 @@ def build_reference_detector():
               'mmdet.models.roi_heads.bbox_heads.contrastive_head',
               'mmdet.models.roi_heads.contrastive_roi_head', 'mmdet.models.detectors.faster_rcnn']:
         refload.ref(m)
-    os.environ['OADG_CONFIG_ROOT'] = refload.REF
     import oadg_amd
-    cfg = oadg_amd.Config.fromfile(
-        os.path.join(refload.REF, 'configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'),
-        import_custom_modules=False)
+    if config == 'dc5':
+        cfg = oadg_amd.Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r101_dc5_1x_dwd_oadg.py'),
+                                       import_custom_modules=False)
+    else:
+        os.environ['OADG_CONFIG_ROOT'] = refload.REF
+        cfg = oadg_amd.Config.fromfile(
+            os.path.join(refload.REF, 'configs/OA-DG/cityscapes/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'),
+            import_custom_modules=False)
     model_cfg = refload.to_cfg(cfg.to_dict()['model'])
     model_cfg['backbone']['init_cfg'] = None
     det = refload.ref('mmdet.models.builder', 'build_detector')(model_cfg)
     return det
 
 
-def load_named(model):
+def load_named(model, scale=None):
     sd = model.state_dict()
-    w = named_weights({k: v.shape for k, v in sd.items()})
+    w = named_weights({k: v.shape for k, v in sd.items()}, scale)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()})
 
 
@@ -72,7 +80,7 @@ def to_batch(b):
                            for _ in range(b['img'].shape[0])])
 
 
-def grad_report(model):
+def grad_report(model, samples=True):
     rep = {}
     groups = {}
     for n, p in model.named_parameters():
@@ -83,19 +91,20 @@ def grad_report(model):
         groups[top] += float(p.grad.double().pow(2).sum())
     for k, v in groups.items():
         rep['gn_' + k] = np.float64(np.sqrt(v))
+    params = dict(model.named_parameters())
     for n in ['roi_head.bbox_head.fc_cls.weight', 'roi_head.bbox_head.fc_cont.2.weight',
               'rpn_head.rpn_cls.weight', 'neck.fpn_convs.0.conv.bias', 'backbone.layer4.2.conv3.weight']:
-        p = dict(model.named_parameters())[n]
-        rep['g_' + n] = p.grad.detach().flatten()[:4096].numpy().copy()
+        if samples and n in params:
+            rep['g_' + n] = params[n].grad.detach().flatten()[:4096].numpy().copy()
     return rep
 
 
-def main(h=256, w=512, n_img=2, seed=0):
-    det = build_reference_detector()
-    load_named(det)
+def main(h=256, w=512, n_img=2, seed=0, config='r50fpn', name=None, n_gt=12, n_cls=8, samples=True):
+    det = build_reference_detector(config)
+    load_named(det, DC5_SCALE if config == 'dc5' else None)
     det.train()
     integrate = refload.ref('mmdet.models.detectors.base', 'integrate_data')
-    batch = model_batch(seed, n_img, h, w)
+    batch = model_batch(seed, n_img, h, w, n_gt=n_gt, n_cls=n_cls)
     data = to_batch(batch)
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -105,18 +114,20 @@ def main(h=256, w=512, n_img=2, seed=0):
     loss, log_vars = det._parse_losses(losses)
     loss.backward()
     print('reference step', time.time() - t0, 's', log_vars)
-    out = dict(h=np.int64(h), w=np.int64(w), n_img=np.int64(n_img), seed=np.int64(seed))
+    out = dict(h=np.int64(h), w=np.int64(w), n_img=np.int64(n_img), seed=np.int64(seed), n_gt=np.int64(n_gt),
+               n_cls=np.int64(n_cls), ref_step_seconds=np.float64(time.time() - t0))
     for k, v in log_vars.items():
         out['lv_' + k] = np.float64(v)
-    out.update(grad_report(det))
+    out.update(grad_report(det, samples))
     # intermediate pins: sampled RoIs and labels (indices exact), random proposals
     tg = det.roi_head.bbox_targets
     out['roi_labels'] = tg[0].numpy().copy()
     out['roi_bbox_targets_sum'] = np.float64(tg[2].double().sum())
     out['n_params'] = np.int64(sum(p.numel() for p in det.parameters()))
     out['n_trainable'] = np.int64(sum(p.numel() for p in det.parameters() if p.requires_grad))
-    np.savez_compressed(os.path.join(HERE, f'model_step_{h}x{w}.npz'), **out)
-    print('wrote', f'model_step_{h}x{w}.npz', {k: v for k, v in out.items() if k.startswith('lv_') or k.startswith('n_')})
+    name = name or f'model_step_{h}x{w}.npz'
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print('wrote', name, {k: v for k, v in out.items() if k.startswith('lv_') or k.startswith('n_')})
 
 
 def main_test(h=256, w=512, n_img=2, seed=0):
@@ -146,7 +157,12 @@ def main_test(h=256, w=512, n_img=2, seed=0):
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'test':
+    mode = sys.argv[1] if len(sys.argv) > 1 else 'step'
+    if mode == 'test':
         main_test()
+    elif mode == 'full':       # SURVEY 8c G7 at BASELINE config 1's real shape (N=2, 1024x2048): ~2 min, 13.5 GB here
+        main(1024, 2048, samples=False)
+    elif mode == 'dc5':        # BASELINE configs[3] (R101-DC5 OA-DG): 17,280 anchors > nms_pre 12,000 > split_thr 10,000
+        main(384, 768, config='dc5', name='model_step_dc5_384x768.npz', n_cls=7)
     else:
         main()

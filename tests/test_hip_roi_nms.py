@@ -104,3 +104,32 @@ def test_nms_batched_matches_oracle(dev, M, n_img):
     for i in range(n_img):
         assert kc[i] == len(keeps[i])
         assert np.array_equal(k[i, :kc[i]], keeps[i])
+
+
+@pytest.mark.parametrize('n_ids', [1, 3])
+def test_nms_12000_through_the_split_thr_branch(dev, n_ids):
+    """R101-DC5 (BASELINE configs[3]): nms_pre = 12000 >= mmcv's split_thr = 10000, so batched_nms takes its per-id
+    loop + global re-sort (configs/_base_/models/faster_rcnn_r50_caffe_dc5.py:75-79).  The product always
+    runs ONE offset-coded scan over the stably sorted boxes; both must give the same keep list, in the same order,
+    including among exactly tied scores (ascending input index), cut at max_per_img = 2000."""
+    from oadg_amd import hip_ops
+    M = 12000
+    rs = np.random.RandomState(7 + n_ids)
+    cx = rs.uniform(0, 1280, M); cy = rs.uniform(0, 736, M)
+    w = rs.uniform(8, 400, M); h = rs.uniform(8, 400, M)
+    boxes = torch.tensor(np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32))
+    scores = torch.tensor(rs.uniform(0, 1, M).astype(np.float32))
+    scores[rs.randint(0, M, 600)] = 0.99609375            # a tie group, as saturated sigmoids produce
+    ids = torch.tensor(rs.randint(0, n_ids, M))
+    dets, keep = ONMS.batched_nms(boxes, scores, ids, dict(type='nms', iou_threshold=0.7))
+    assert boxes.shape[0] >= 10000                         # i.e. the oracle went through the split branch
+    keep = keep[:2000]
+    # product formulation (dense_heads.RPNHead.get_bboxes): stable sort, class offset, one scan
+    b, s, i = boxes.to(dev), scores.to(dev), ids.to(dev)
+    order = s.sort(descending=True, stable=True)[1]
+    off = i.to(b) * (b.max() + 1)
+    k, kc = hip_ops.nms_sorted_batched((b + off[:, None])[order][None],
+                                       torch.tensor([M], device=dev, dtype=torch.int32), 0.7, 2000)
+    mine = order[k[0, :int(kc[0])].long()].cpu()
+    assert len(mine) == len(keep) == 2000
+    assert torch.equal(mine, keep)

@@ -12,22 +12,26 @@ import numpy as np
 import pytest
 import torch
 
-from inputs import model_batch, named_weights
+from inputs import DC5_SCALE, model_batch, named_weights
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
 
 
-def build_and_load(device='cpu'):
+DC5_CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r101_dc5_1x_dwd_oadg.py')
+
+
+def build_and_load(device='cpu', cfg=CFG):
     from oadg_amd import Config, build_detector
-    det = build_detector(Config.fromfile(CFG).model)
-    w = named_weights({k: v.shape for k, v in det.state_dict().items()})
+    det = build_detector(Config.fromfile(cfg).model)
+    w = named_weights({k: v.shape for k, v in det.state_dict().items()}, DC5_SCALE if cfg == DC5_CFG else None)
     det.load_state_dict({k: torch.as_tensor(v) for k, v in w.items()})
     return det.to(device).train()
 
 
 def make_data(g, device='cpu'):
-    b = model_batch(int(g['seed']), int(g['n_img']), int(g['h']), int(g['w']))
+    kw = dict(n_gt=int(g['n_gt']), n_cls=int(g['n_cls'])) if 'n_gt' in g.files else {}
+    b = model_batch(int(g['seed']), int(g['n_img']), int(g['h']), int(g['w']), **kw)
     shape = b['img'].shape[2:] + (3,)
     t = lambda x: torch.tensor(x, device=device)  # noqa: E731
     return dict(img=t(b['img']), img2=t(b['img2']), gt_bboxes=[t(x) for x in b['gt_bboxes']],
@@ -154,3 +158,108 @@ def test_r101_dc5_oadg_config_trains_one_step(dev):
     finally:
         hip_conv.enable(False)
     assert {'loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'acc', 'loss_bbox', 'loss_cont', 'loss'} <= set(out['log_vars'])
+
+
+def _gpu_step_vs_fixture(dev, golden_dir, fixture, cfg, bf16, tol_loss, tol_acc, tol_gn, min_same, monkeypatch):
+    """one train step of the PRODUCT path on the device against a fixture written by the reference's own python.
+    bf16=True is the benchmarked configuration: channels_last model, autocast bf16, every convolution on the csrc MFMA
+    kernels (hip_conv.enable()), BN folded, HIP losses / RoIAlign / NMS / assigner."""
+    from oadg_amd import hip_conv
+    from oadg_amd.detectors import integrate_data
+    g = np.load(os.path.join(golden_dir, fixture))
+    torch.backends.cudnn.allow_tf32 = False
+    monkeypatch.setattr(torch.backends.cudnn, 'deterministic', True)
+    det = build_and_load(dev, cfg)
+    data = make_data(g, dev)
+    torch.manual_seed(int(g['seed']))
+    np.random.seed(int(g['seed']))
+    if bf16:
+        det = det.to(memory_format=torch.channels_last)
+        hip_conv.enable()
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                losses = det(**integrate_data(data, det.train_cfg))
+            loss, log_vars = det._parse_losses(losses)
+            loss.backward()
+        finally:
+            hip_conv.enable(False)
+    else:
+        out = det.train_step(data, None)
+        out['loss'].backward()
+        log_vars = out['log_vars']
+    torch.cuda.synchronize()
+    dev_l = {k: abs(v - float(g['lv_' + k])) / abs(float(g['lv_' + k])) for k, v in log_vars.items()}
+    same = (det.roi_head.bbox_targets[0].cpu().numpy() == g['roi_labels']).mean()
+    dev_g = {k: abs(v - float(g['gn_' + k])) / float(g['gn_' + k]) for k, v in grad_groups(det).items()}
+    print(fixture, 'bf16' if bf16 else 'fp32', 'loss dev', {k: f'{v:.2e}' for k, v in dev_l.items()},
+          'labels same', same, 'grad-norm dev', {k: f'{v:.2e}' for k, v in dev_g.items()})
+    for k, v in dev_l.items():
+        assert v <= (tol_acc if k == 'acc' else tol_loss), (k, v)
+    assert same >= min_same, same
+    assert set(dev_g) == {k[3:] for k in g.files if k.startswith('gn_')}
+    for k, v in dev_g.items():
+        assert v <= tol_gn, (k, v)
+
+
+@pytest.mark.gpu
+def test_bf16_mfma_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
+    """THE BENCHMARKED PATH (bench.py: bf16 autocast + csrc MFMA convolutions + folded BN) against the reference's
+    fp32 step (base.py:413-455 via tests/golden/make_golden_model.py).  bf16 has 8 mantissa bits: activations carry
+    ~4e-3 relative rounding per layer, which also flips a few discrete decisions (top-k / NMS / IoU thresholds, ~1 %
+    of the sampled RoIs).  Measured on MI355X (round 2): loss terms 1e-4..3e-3 (3e-2 for loss_cls / loss_bbox
+    of the DC5 fixture, where 2 of 2048 sampled RoIs flip), acc <= 3.6e-2, per-module gradient norms 1e-5..1.1e-2,
+    sampled labels >= 99.9 % identical.  Asserted: 5e-2 / 5e-2 / 3e-2 / 99 %.  north_star's 1e-4 bar is held by the
+    per-kernel tests on identical operands and by the fp32 product step (1e-7..2.5e-4 against the same fixtures)."""
+    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_256x512.npz', CFG, True, 5e-2, 5e-2, 3e-2, 0.99, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bf16', [False, True])
+def test_full_size_config1_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypatch):
+    """SURVEY 8c G7 at BASELINE config 1's real shape: N=2, 1024x2048 (the reference needs 72 s and 13.5 GB for this
+    step on the build container's 8 cores)."""
+    tol = (5e-2, 5e-2, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
+    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_1024x2048.npz', CFG, bf16, *tol, monkeypatch)
+
+
+def test_r101_dc5_host_logic_reproduces_reference_step(golden_dir):
+    """BASELINE configs[3] on CPU with oracle ops: single-level RoI path (single_level_roi_extractor.py:107-110),
+    2048-channel RoIAlign, 15 anchors per location, allowed_border=0, nms_pre=12000 >= split_thr=10000 (the per-level
+    loop of batched_nms), max_per_img=2000, num_classes=7."""
+    from oracle.backend import oracle_ops
+    from oadg_amd import layers
+    g = np.load(os.path.join(golden_dir, 'model_step_dc5_384x768.npz'))
+    det = build_and_load(cfg=DC5_CFG)
+    assert sum(p.numel() for p in det.parameters()) == int(g['n_params']) == 184580783
+    assert sum(p.numel() for p in det.parameters() if p.requires_grad) == int(g['n_trainable'])
+    data = make_data(g)
+    torch.manual_seed(int(g['seed']))
+    np.random.seed(int(g['seed']))
+    prev, layers.FOLD_EVAL_BN = layers.FOLD_EVAL_BN, False
+    try:
+        with oracle_ops():
+            out = det.train_step(data, None)
+            out['loss'].backward()
+    finally:
+        layers.FOLD_EVAL_BN = prev
+    for k, v in out['log_vars'].items():
+        ref = float(g['lv_' + k])
+        assert abs(v - ref) <= 1e-6 * abs(ref), (k, v, ref)
+    assert np.array_equal(det.roi_head.bbox_targets[0].numpy(), g['roi_labels'])
+    for k, v in grad_groups(det).items():
+        ref = float(g['gn_' + k])
+        assert abs(v - ref) <= 1e-5 * ref, (k, v, ref)
+    params = dict(det.named_parameters())
+    for k in g.files:
+        if k.startswith('g_'):
+            mine = params[k[2:]].grad.flatten()[:4096].numpy()
+            assert np.abs(mine - g[k]).max() <= 1e-5 * np.abs(g[k]).max() + 1e-9, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bf16', [False, True])
+def test_r101_dc5_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypatch):
+    """R101-DC5 OA-DG product path on the device against the reference-generated fixture: fp32 (library convolutions +
+    HIP RoIAlign / NMS / losses) and the bf16 MFMA path incl. the dilated 3x3 and the 2048->2048 RPN convolution."""
+    tol = (5e-2, 5e-2, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
+    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_dc5_384x768.npz', DC5_CFG, bf16, *tol, monkeypatch)
