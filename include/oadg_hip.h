@@ -143,13 +143,34 @@ int oadg_oamix_box_profiles(const int* qbox, const double* sigma, int n, int H, 
                             float* Mx, void* stream);
 int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, float* union_f,
                         uint8_t* union_u8, void* stream);
+/* workspace: oadg_oamix_saliency_workspace_bytes(n) bytes (the 64x64 maps and integer totals between the launches) */
+size_t oadg_oamix_saliency_workspace_bytes(int n);
 int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
-                        double* scores, void* stream);
+                        double* scores, void* workspace, size_t workspace_bytes, void* stream);
 int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream);
 int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream);
 int oadg_oamix_gray_sum(const uint8_t* img, long npix, long long* sum, void* stream);
 int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, int rx0, int ry0, int rw, int rh,
                          const float* My_row, const float* Mx_row, uint8_t* scratch, void* stream);
+/* bboxes_only_* for ALL gt boxes of an image in a handful of launches (bbox_augmentation.py:74-88 applies the boxes
+ * one after the other; only boxes whose written rect meets another's read footprint are ordered).  steps_dev: the
+ * boxes' steps sorted by dependency level; tile_prefix_*[i] = number of 256-pixel tiles before step i (n + 1 entries,
+ * device and host copies); level_first_host[l] .. level_first_host[l + 1] = steps of level l.  Two launches per
+ * level (blend into scratch, copy back); rect = x0, y0, width, height; scratch_off = byte offset of the step's rect
+ * inside `scratch` (rects of one level are disjoint, so H*W*3 bytes suffice). */
+typedef struct {
+    double minv[6];        /* inverted affine (cv2.warpAffine) */
+    int rect[4];
+    int row;               /* profile row: My + row * H, Mx + row * W */
+    int pad_;
+    long long scratch_off;
+} oadg_bbox_step;
+/* HOST function (no device work): dependency level of each of the n steps in list order - rects [n][4] = x0, y0, w, h
+ * (pixels written), minvs [n][6]; level[j] > level[i] whenever i < j and one writes what the other reads or writes. */
+int oadg_oamix_bbox_levels(const int* rects, const double* minvs, int n, int H, int W, int* level);
+int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* steps_dev, const int* tile_prefix_dev,
+                          const int* level_first_host, int n_levels, const int* tile_prefix_host, const float* My,
+                          const float* Mx, uint8_t* scratch, void* stream);
 int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
                        const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,
                        const uint8_t* union_u8, float* acc, float acc_w, int acc_mode, void* stream);

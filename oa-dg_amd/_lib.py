@@ -68,11 +68,14 @@ SIGNATURES = {
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
-    'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp]),
+    'oadg_oamix_saliency_workspace_bytes': (cs, [ci]),
+    'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp, cs, vp]),
     'oadg_oamix_hist': (ci, [vp, cl, vp, vp]),
     'oadg_oamix_luts': (ci, [vp, vp, vp]),
     'oadg_oamix_gray_sum': (ci, [vp, cl, vp, vp]),
     'oadg_oamix_bbox_step': (ci, [vp, ci, ci, POINTER(cd), ci, ci, ci, ci, vp, vp, vp, vp]),
+    'oadg_oamix_bbox_levels': (ci, [POINTER(ci), POINTER(cd), ci, ci, ci, POINTER(ci)]),
+    'oadg_oamix_bbox_chain': (ci, [vp, ci, ci, vp, vp, POINTER(ci), ci, POINTER(ci), vp, vp, vp, vp]),
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
                               ci, vp]),

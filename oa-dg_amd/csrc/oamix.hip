@@ -210,22 +210,30 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ i
 // one block, thread = intensity; luts[0] = ImageOps.autocontrast, luts[1] = ImageOps.equalize
 __global__ __launch_bounds__(256) void luts_kernel(const int* __restrict__ hist, uint8_t* __restrict__ luts) {
     __shared__ int h[256];
-    __shared__ long pre[256];
+    __shared__ long pre[256], inc[256];
     __shared__ int s_lo, s_hi, s_nz, s_last;
     const int ix = threadIdx.x;
     for (int c = 0; c < 3; ++c) {
         __syncthreads();
         h[ix] = hist[c * 256 + ix];
         __syncthreads();
+        // exclusive prefix sums, first / last non-empty bin and their count: block-parallel (integers: any order)
+        if (ix == 0) { s_lo = 256; s_hi = -1; s_nz = 0; }
+        inc[ix] = h[ix];
+        __syncthreads();
+        if (h[ix]) { atomicMin(&s_lo, ix); atomicMax(&s_hi, ix); atomicAdd(&s_nz, 1); }
+        for (int o = 1; o < 256; o <<= 1) {
+            const long v = ix >= o ? inc[ix - o] : 0;
+            __syncthreads();
+            inc[ix] += v;
+            __syncthreads();
+        }
+        pre[ix] = inc[ix] - h[ix];
+        __syncthreads();
         if (ix == 0) {
-            int lo = 0, hi = 255, nz = 0, last = 0;
-            for (lo = 0; lo < 256; ++lo) if (h[lo]) break;
-            for (hi = 255; hi >= 0; --hi) if (h[hi]) break;
-            long run = 0;
-            for (int i = 0; i < 256; ++i) { pre[i] = run; run += h[i]; if (h[i]) { ++nz; last = h[i]; } }
-            if (lo > 255) lo = 255;      // empty image: Python's loop leaves lo = 255, hi = 0
-            if (hi < 0) hi = 0;
-            s_lo = lo; s_hi = hi; s_nz = nz; s_last = last;
+            s_last = s_hi >= 0 ? h[s_hi] : 0;     // the last non-empty bin's count
+            if (s_lo > 255) s_lo = 255;           // empty image: Python's loop leaves lo = 255, hi = 0
+            if (s_hi < 0) s_hi = 0;
         }
         __syncthreads();
         int ac = ix;
@@ -283,6 +291,73 @@ __global__ void rect_copy_kernel(uint8_t* __restrict__ img, int W, int rx0, int 
     img[p] = scratch[(size_t)i * 3];
     img[p + 1] = scratch[(size_t)i * 3 + 1];
     img[p + 2] = scratch[(size_t)i * 3 + 2];
+}
+
+// The same two phases for MANY boxes per launch: `steps` (device) are sorted into dependency levels by the host
+// (pipelines/oa_mix.py: a box joins a later level than every earlier box whose written rect meets its read footprint
+// or vice versa), so all boxes of one level may be blended concurrently and the reference's sequential result is kept
+// bit for bit.  Workgroup b of a level's launch owns 256 consecutive pixels of one box's rect (binary search of its
+// global tile number in the prefix `tile_prefix`).
+__device__ __forceinline__ int find_step(const int* __restrict__ tile_prefix, int first, int count, int tile) {
+    int lo = first, hi = first + count - 1;        // last step whose prefix <= tile
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_prefix[mid] <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                               const oadg_bbox_step* __restrict__ steps,
+                                                               const int* __restrict__ tile_prefix, int first,
+                                                               int count, int tile_base,
+                                                               const float* __restrict__ My,
+                                                               const float* __restrict__ Mx,
+                                                               uint8_t* __restrict__ scratch) {
+    const int tile = tile_base + blockIdx.x;
+    const int s = find_step(tile_prefix, first, count, tile);
+    const oadg_bbox_step st = steps[s];
+    const int rw = st.rect[2], rh = st.rect[3];
+    const int i = (tile - tile_prefix[s]) * 256 + threadIdx.x;
+    if (i >= rw * rh) return;
+    const int yy = i / rw, xx = i - yy * rw;
+    const int x = st.rect[0] + xx, y = st.rect[1] + yy;
+    Warp wp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wp.m[k] = st.minv[k];
+    long X, Y;
+    warp_xy(wp, x, y, X, Y);
+    const Tap t = make_tap(X, Y, H, W);
+    const float b = My[(size_t)st.row * H + y] * Mx[(size_t)st.row * W + x];
+    const float m = 1.0f - b;
+    const float om = 1.0f - m;
+    const size_t p = ((size_t)y * W + x) * 3;
+    uint8_t* out = scratch + st.scratch_off + (size_t)i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float wv = (float)tap_fetch(t, img, 3, c);
+        const float v = (float)img[p + c] * m + wv * om;
+        out[c] = (uint8_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restrict__ img, int W,
+                                                              const oadg_bbox_step* __restrict__ steps,
+                                                              const int* __restrict__ tile_prefix, int first,
+                                                              int count, int tile_base,
+                                                              const uint8_t* __restrict__ scratch) {
+    const int tile = tile_base + blockIdx.x;
+    const int s = find_step(tile_prefix, first, count, tile);
+    const oadg_bbox_step st = steps[s];
+    const int rw = st.rect[2], rh = st.rect[3];
+    const int i = (tile - tile_prefix[s]) * 256 + threadIdx.x;
+    if (i >= rw * rh) return;
+    const int yy = i / rw, xx = i - yy * rw;
+    const size_t p = ((size_t)(st.rect[1] + yy) * W + st.rect[0] + xx) * 3;
+    const uint8_t* in = scratch + st.scratch_off + (size_t)i * 3;
+    img[p] = in[0];
+    img[p + 1] = in[1];
+    img[p + 2] = in[2];
 }
 
 // ------------------------------------------------------------------------------------------------ compose
@@ -552,20 +627,16 @@ __device__ __forceinline__ void lin_axis(int d, int n_src, int n_dst, int& s0, i
 
 __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                        const int* __restrict__ boxes, int min_side,
-                                                       double* __restrict__ scores) {
+                                                       float* __restrict__ sal_maps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* re = reinterpret_cast<double*>(smem);            // [64*64]
     double* im = re + SN * SN;                                // [64*64]
-    float* sal = reinterpret_cast<float*>(im + SN * SN);      // [64*64]
     __shared__ double red[16];
     __shared__ double s_max;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int x1 = boxes[4 * b], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
     const int w = x2 - x1, h = y2 - y1;
-    if (w < min_side || h < min_side) {
-        if (tid == 0) scores[b] = -1.0;
-        return;
-    }
+    if (w < min_side || h < min_side) return;      // score -1 (saliency_mean_kernel)
     // gray (cv::cvtColor BGR2GRAY fixed point) + bilinear to 64x64, rounded to uint8
     for (int i = tid; i < SN * SN; i += 256) {
         const int dy = i / SN, dx = i - dy * SN;
@@ -645,12 +716,30 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     __syncthreads();
     if (tid == 0) s_max = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     __syncthreads();
-    for (int i = tid; i < SN * SN; i += 256) sal[i] = (float)(re[i] / s_max);
+    // the 64x64 saliency map leaves the workgroup here: the resize to w x h and the mean run on many workgroups per box
+    float* sal_out = sal_maps + (size_t)b * SN * SN;
+    for (int i = tid; i < SN * SN; i += 256) sal_out[i] = (float)(re[i] / s_max);
+}
+
+// bilinear (float32, horizontal then vertical) of the 64x64 map to w x h; total of uint8(v * 255) per box.  The
+// addends are integers, so the block partials and the atomic total are exact in any order.
+__global__ __launch_bounds__(256) void saliency_sum_kernel(const float* __restrict__ sal_maps,
+                                                           const int* __restrict__ boxes, int min_side,
+                                                           unsigned long long* __restrict__ totals) {
+    __shared__ float sal[SN * SN];
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int w = boxes[4 * b + 2] - boxes[4 * b], h = boxes[4 * b + 3] - boxes[4 * b + 1];
+    if (w < min_side || h < min_side) return;
+    const long npx = (long)w * h;
+    const long per = (npx + gridDim.y - 1) / gridDim.y;
+    const long p0 = per * blockIdx.y, p1 = p0 + per < npx ? p0 + per : npx;
+    if (p0 >= npx) return;
+    for (int i = tid; i < SN * SN; i += 256) sal[i] = sal_maps[(size_t)b * SN * SN + i];
     __syncthreads();
-    // bilinear (float32, horizontal then vertical) to w x h; score = mean(uint8(v * 255))
-    double acc = 0.0;
-    for (int i = tid; i < w * h; i += 256) {
-        const int dy = i / w, dx = i - dy * w;
+    unsigned long long acc = 0;
+    for (long i = p0 + tid; i < p1; i += 256) {
+        const int dy = (int)(i / w), dx = (int)(i - (long)dy * w);
         int ya, yb, xa, xb; double fyd, fxd;
         lin_axis(dy, SN, h, ya, yb, fyd);
         lin_axis(dx, SN, w, xa, xb, fxd);
@@ -659,10 +748,20 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
         const float r0 = sal[ya * SN + xa] * ax0 + sal[ya * SN + xb] * fx;
         const float r1 = sal[yb * SN + xa] * ax0 + sal[yb * SN + xb] * fx;
         const float v = r0 * ay0 + r1 * fy;
-        acc += (double)(uint8_t)(v * 255.0f);
+        acc += (unsigned long long)(uint8_t)(v * 255.0f);
     }
-    const double tot = block_sum_d(acc, red);
-    if (tid == 0) scores[b] = tot / (double)((long)w * h);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) atomicAdd(&totals[b], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void saliency_mean_kernel(const unsigned long long* __restrict__ totals, const int* __restrict__ boxes,
+                                     int n, int min_side, double* __restrict__ scores) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const int w = boxes[4 * b + 2] - boxes[4 * b], h = boxes[4 * b + 3] - boxes[4 * b + 1];
+    scores[b] = (w < min_side || h < min_side) ? -1.0 : (double)totals[b] / (double)((long)w * h);
 }
 
 __global__ __launch_bounds__(256) void gray_sum_kernel(const uint8_t* __restrict__ img, long npix,
@@ -704,11 +803,19 @@ int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, f
     return OADG_OK;
 }
 
+size_t oadg_oamix_saliency_workspace_bytes(int n) {
+    return n > 0 ? (size_t)n * (SN * SN * sizeof(float) + sizeof(unsigned long long)) : 0;
+}
+
 int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
-                        double* scores, void* stream) {
+                        double* scores, void* workspace, size_t workspace_bytes, void* stream) {
     if (n == 0) return OADG_OK;
-    if (!img || !boxes || !scores || n < 0) return OADG_EARG;
-    const size_t lds = (size_t)SN * SN * (8 + 8 + 4);
+    if (!img || !boxes || !scores || !workspace || n < 0) return OADG_EARG;
+    if (workspace_bytes < oadg_oamix_saliency_workspace_bytes(n)) return OADG_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* totals = (unsigned long long*)workspace;          // [n], then the [n][64*64] float maps
+    float* maps = (float*)(totals + n);
+    const size_t lds = (size_t)SN * SN * (8 + 8);
     static bool attr_set = false;   // > 64 KiB of dynamic LDS must be opted into once (idempotent)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)saliency_kernel,
@@ -716,8 +823,17 @@ int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int 
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(saliency_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, img, H, W, boxes,
-                       min_side, scores);
+    hipError_t e = hipMemsetAsync(totals, 0, (size_t)n * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(saliency_kernel, dim3(n), dim3(256), lds, st, img, H, W, boxes, min_side, maps);
+    OADG_LAUNCH_CHECK();
+    // crops are up to the whole image: ~64k pixels per workgroup, at most 32 workgroups per box
+    int per_box = n >= 512 ? 1 : (n >= 64 ? 4 : 32);
+    hipLaunchKernelGGL(saliency_sum_kernel, dim3(n, per_box), dim3(256), 0, st, (const float*)maps, boxes, min_side,
+                       totals);
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(saliency_mean_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
+                       (const unsigned long long*)totals, boxes, n, min_side, scores);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
@@ -769,6 +885,29 @@ int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, in
     hipLaunchKernelGGL(rect_copy_kernel, dim3(g), dim3(256), 0, st, img, W, rx0, ry0, rw, rh,
                        (const uint8_t*)scratch);
     OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* steps_dev, const int* tile_prefix_dev,
+                          const int* level_first_host, int n_levels, const int* tile_prefix_host, const float* My,
+                          const float* Mx, uint8_t* scratch, void* stream) {
+    if (!img || !steps_dev || !tile_prefix_dev || !level_first_host || !tile_prefix_host || !My || !Mx || !scratch ||
+        n_levels < 0)
+        return OADG_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < n_levels; ++l) {
+        const int first = level_first_host[l], count = level_first_host[l + 1] - first;
+        if (count <= 0) continue;
+        const int tile_base = tile_prefix_host[first];
+        const int tiles = tile_prefix_host[first + count] - tile_base;
+        if (tiles <= 0) continue;
+        hipLaunchKernelGGL(bbox_blend_multi_kernel, dim3(tiles), dim3(256), 0, st, (const uint8_t*)img, H, W,
+                           steps_dev, tile_prefix_dev, first, count, tile_base, My, Mx, scratch);
+        OADG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles), dim3(256), 0, st, img, W, steps_dev,
+                           tile_prefix_dev, first, count, tile_base, (const uint8_t*)scratch);
+        OADG_LAUNCH_CHECK();
+    }
     return OADG_OK;
 }
 

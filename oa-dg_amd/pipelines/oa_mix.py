@@ -50,6 +50,40 @@ AUG_LISTS = {   # oa_mix.py:15-29
                    'bboxes_only_translate_xy', 'bg_only_rotate', 'bg_only_shear_xy', 'bg_only_translate_xy'],
 }
 MIX_TARGET_DTYPE = np.dtype([('fg_index', '<i4'), ('rect', '<i4', (4,)), ('m_oa', '<f4')])   # oadg_mix_target
+BBOX_STEP_DTYPE = np.dtype([('minv', '<f8', (6,)), ('rect', '<i4', (4,)), ('row', '<i4'), ('pad_', '<i4'),
+                            ('scratch_off', '<i8')])                                          # oadg_bbox_step
+BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
+
+
+def dependency_levels(rects, minvs, H, W):
+    """Level of each bbox-only step such that running the levels in order, and the steps of one level in ANY order,
+    gives the result of running all steps in list order (bbox_augmentation.py:74-88 is sequential): step j goes after
+    every earlier step i whose written rect meets j's read footprint (read after write) or whose read footprint
+    meets j's written rect (write after read).  rects: [n,4] x0,y0,w,h (the mask support = the pixels written);
+    the read footprint = the rect itself plus the bounding box of its warped corners (affine, so the corners bound
+    it) widened by the bilinear taps and the 1/32-px coordinate rounding, clipped to the image."""
+    n = len(rects)
+    if n == 0:
+        return np.zeros((0,), np.int64)
+    r = np.asarray(rects, np.float64)
+    m = np.asarray(minvs, np.float64).reshape(n, 6)
+    x0, y0, x1, y1 = r[:, 0], r[:, 1], r[:, 0] + r[:, 2] - 1, r[:, 1] + r[:, 3] - 1      # inclusive pixel corners
+    cx = np.stack([x0, x1, x0, x1], 1)
+    cy = np.stack([y0, y0, y1, y1], 1)
+    sx = m[:, 0:1] * cx + m[:, 1:2] * cy + m[:, 2:3]
+    sy = m[:, 3:4] * cx + m[:, 4:5] * cy + m[:, 5:6]
+    fx0 = np.clip(np.minimum(np.floor(sx.min(1)) - 2, x0), 0, W - 1)
+    fy0 = np.clip(np.minimum(np.floor(sy.min(1)) - 2, y0), 0, H - 1)
+    fx1 = np.clip(np.maximum(np.ceil(sx.max(1)) + 2, x1), 0, W - 1)
+    fy1 = np.clip(np.maximum(np.ceil(sy.max(1)) + 2, y1), 0, H - 1)
+    level = np.zeros((n,), np.int64)
+    for j in range(1, n):
+        raw = (x0[:j] <= fx1[j]) & (x1[:j] >= fx0[j]) & (y0[:j] <= fy1[j]) & (y1[:j] >= fy0[j])
+        war = (fx0[:j] <= x1[j]) & (fx1[:j] >= x0[j]) & (fy0[:j] <= y1[j]) & (fy1[:j] >= y0[j])
+        hit = raw | war
+        if hit.any():
+            level[j] = level[:j][hit].max() + 1
+    return level
 
 
 def sample_level(n):            # augmix.py:60-61
@@ -114,9 +148,41 @@ def geo_matrix(kind, severity, img_size, center=None, size_for_level=None):
     return np.float32([[1, 0, -lvl], [0, 1, 0]]) if ax == 0 else np.float32([[1, 0, 0], [0, 1, -lvl]])
 
 
+class _PinnedRing:
+    """Per-thread ring of pinned staging buffers for the small descriptor uploads: ``tensor.pin_memory()`` allocates
+    (hipHostMalloc, ~2 ms for a 4096-box descriptor table) on every call; a slot of the ring is reused once the copy
+    that read it has completed (event recorded behind the copy on its stream)."""
+    SLOTS = 16
+
+    def __init__(self):
+        self.bufs, self.events, self.k = [None] * self.SLOTS, [None] * self.SLOTS, 0
+
+    def stage(self, raw):
+        k, self.k = self.k, (self.k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        buf = self.bufs[k]
+        if buf is None or buf.numel() < raw.size:
+            buf = self.bufs[k] = torch.empty((max(4096, 1 << int(raw.size - 1).bit_length()),), dtype=torch.uint8,
+                                             pin_memory=True)
+        buf.numpy()[:raw.size] = raw
+        return k, buf[:raw.size]
+
+
 def _upload(arr, device):
-    """small host array -> device without blocking the host on the stream (pinned staging)."""
-    return torch.from_numpy(np.ascontiguousarray(arr)).pin_memory().to(device, non_blocking=True)
+    """small host array -> device tensor (same dtype / shape) without blocking the host on the stream"""
+    arr = np.ascontiguousarray(arr)
+    ring = getattr(_TLS, 'ring', None)
+    if ring is None:
+        ring = _TLS.ring = _PinnedRing()
+    if arr.size == 0:
+        return torch.from_numpy(arr).to(device)
+    k, src = ring.stage(arr.view(np.uint8).reshape(-1))
+    dst = torch.empty((src.numel(),), dtype=torch.uint8, device=device)
+    dst.copy_(src, non_blocking=True)
+    ev = ring.events[k] = ring.events[k] or torch.cuda.Event()
+    ev.record()
+    return dst.view(torch.from_numpy(arr[:0]).dtype).view(arr.shape)
 
 
 class _ImageState:
@@ -131,18 +197,14 @@ class _ImageState:
         dev = img.device
         H, W = self.H, self.W
         # --- blurred-mask profiles (oa_mix.py:74-93) -------------------------------------------------
-        qbox = np.zeros((n, 4), np.int32)
-        sigma = np.zeros((n, 2), np.float64)
-        self.support = []                                   # conservative rect where the mask can be non-zero
-        for i, gt in enumerate(self.gt):
-            x1, y1, x2, y2 = np.array(gt // spatial_ratio, dtype=np.int32)
-            qbox[i] = (x1, y1, x2, y2)
-            sx = (x2 - x1) * sigma_ratio / 3 * 2
-            sy = (y2 - y1) * sigma_ratio / 3 * 2
-            blur = not (sx <= 0 or sy <= 0)
-            sigma[i] = (sx, sy) if blur else (0.0, 0.0)
-            self.support.append(self._support(int(x1), int(y1), int(x2), int(y2), float(sx), float(sy), blur,
-                                              spatial_ratio))
+        # (vectorised over the boxes: per box  x1, y1, x2, y2 = np.array(gt // ratio, dtype=np.int32);
+        #  sx = (x2 - x1) * sigma_ratio / 3 * 2  as in oa_mix.py:83-90)
+        qbox = np.array(self.gt // spatial_ratio, dtype=np.int32).reshape(n, 4)
+        sxy = np.stack([(qbox[:, 2] - qbox[:, 0]) * sigma_ratio / 3 * 2,
+                        (qbox[:, 3] - qbox[:, 1]) * sigma_ratio / 3 * 2], 1).astype(np.float64).reshape(n, 2)
+        blur = ~((sxy[:, 0] <= 0) | (sxy[:, 1] <= 0))
+        sigma = np.where(blur[:, None], sxy, 0.0)
+        self.support = self._supports(qbox, sxy, blur, spatial_ratio)   # conservative rect where the mask can be non-zero
         assert (qbox >= 0).all(), 'gt boxes must have non-negative coordinates'
         self.My = torch.empty((max(n, 1), H), dtype=torch.float32, device=dev)
         self.Mx = torch.empty((max(n, 1), W), dtype=torch.float32, device=dev)
@@ -161,24 +223,29 @@ class _ImageState:
             ib = np.array(self.gt, dtype=np.int32)
             self._ibox = _upload(ib, dev)
             self._scores_dev = torch.empty((n,), dtype=torch.float64, device=dev)
+            nb = L.oadg_oamix_saliency_workspace_bytes(n)
+            self._sal_ws = torch.empty((nb,), dtype=torch.uint8, device=dev)
             check(L.oadg_oamix_saliency(ptr(img), H, W, ptr(self._ibox), n, spatial_ratio,
-                                        ptr(self._scores_dev), stream_ptr()), 'oadg_oamix_saliency')
+                                        ptr(self._scores_dev), ptr(self._sal_ws), nb, stream_ptr()),
+                  'oadg_oamix_saliency')
             self._scores_host = torch.empty((n,), dtype=torch.float64, pin_memory=True)
             self._scores_host.copy_(self._scores_dev, non_blocking=True)
             self._scores_evt = torch.cuda.Event()
             self._scores_evt.record()
 
-    def _support(self, x1, y1, x2, y2, sx, sy, blur, ratio):
+    def _supports(self, qbox, sxy, blur, ratio):
+        """per box (x0, y0, w, h) of the pixels where its (blurred, x4 resized) mask can be non-zero, None if empty"""
         H, W = self.H, self.W
-        if x2 <= x1 or y2 <= y1:
-            return None                                     # empty at reduced resolution: mask is all zero
-        rx = ((int(np.rint(sx * 4 * 2 + 1)) | 1) - 1) // 2 if blur else 0
-        ry = ((int(np.rint(sy * 4 * 2 + 1)) | 1) - 1) // 2 if blur else 0
-        xa = max(0, ratio * (x1 - rx) - 2 * ratio)
-        xb = min(W, ratio * (x2 + rx) + 2 * ratio)
-        ya = max(0, ratio * (y1 - ry) - 2 * ratio)
-        yb = min(H, ratio * (y2 + ry) + 2 * ratio)
-        return (xa, ya, xb - xa, yb - ya)
+        x1, y1, x2, y2 = (qbox[:, k].astype(np.int64) for k in range(4))
+        rad = lambda s_: np.where(blur, ((np.rint(s_ * 4 * 2 + 1).astype(np.int64) | 1) - 1) // 2, 0)  # noqa: E731
+        rx, ry = rad(sxy[:, 0]), rad(sxy[:, 1])
+        xa = np.maximum(0, ratio * (x1 - rx) - 2 * ratio)
+        xb = np.minimum(W, ratio * (x2 + rx) + 2 * ratio)
+        ya = np.maximum(0, ratio * (y1 - ry) - 2 * ratio)
+        yb = np.minimum(H, ratio * (y2 + ry) + 2 * ratio)
+        empty = (x2 <= x1) | (y2 <= y1)                      # empty at reduced resolution: mask is all zero
+        rows = np.stack([xa, ya, xb - xa, yb - ya], 1).tolist()
+        return [None if e else tuple(r) for e, r in zip(empty.tolist(), rows)]
 
     def scores(self):
         """fg_score_list of get_fg_regions: -1 for boxes thinner than spatial_ratio, else the saliency mean."""
@@ -211,6 +278,7 @@ class OAMix:
         self.kwargs = kwargs            # unknown kwargs are swallowed like the reference (oa_mix.py:72)
         self._bufs = {}
         self.trace = None               # set to [] to record the op sequence (tests)
+        self.stats = None               # set to {} to count compose steps / bbox-step pixels (tools/bench_oamix.py)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _buffers(self, st):
@@ -248,12 +316,10 @@ class OAMix:
             if return_score:
                 ious = bbox_overlaps_np(box, fg_boxes)
                 final = float('inf')
-                if np.sum(ious) > eps:
-                    for iou, fb, fs in zip(ious[0], fg_boxes, fg_scores):
-                        if iou == 0.0 or fb[2] - fb[0] < 1 or fb[3] - fb[1] < 1:
-                            continue
-                        if fs < final:
-                            final = fs
+                if np.sum(ious) > eps:          # min score over the overlapped fg boxes with w, h >= 1 (oa_mix.py:157-170)
+                    ok = (ious[0] != 0.0) & ~((fg_boxes[:, 2] - fg_boxes[:, 0] < 1) | (fg_boxes[:, 3] - fg_boxes[:, 1] < 1))
+                    if ok.any():
+                        final = min(final, float(np.min(np.asarray(fg_scores, np.float64)[ok])))
                 scores.append(final)
             boxes += list(box)
         return (boxes, scores) if return_score else boxes
@@ -320,21 +386,129 @@ class OAMix:
         step['n_tmp'] += 1
         T.copy_(src)
         H, W = st.H, st.W
-        for i, box in enumerate(st.gt):
-            x1, y1, x2, y2 = int(box[0]), int(box[1]), int(box[2]), int(box[3])
-            if (x2 - x1) < 1 or (y2 - y1) < 1:
-                continue                                     # returns before any draw (:45-47)
-            center = ((x1 + x2) / 2., (y1 + y2) / 2.)
-            M = geo_matrix(kind, self.severity, (W, H), center, (x2 - x1 + 1, y2 - y1 + 1))
-            sup = st.support[i]
-            if sup is None or sup[2] <= 0 or sup[3] <= 0:
-                continue                                     # mask identically zero: image unchanged
-            minv = (ctypes.c_double * 6)(*invert_affine(M))
-            check(L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
-                                         ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
-                                         ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
-                                         stream_ptr()), 'oadg_oamix_bbox_step')
+        if BATCH_BOXES:
+            rows, rects, minvs = self._box_matrices(st, kind)
+            if len(rows):
+                self._bbox_chain(st, T, rows, rects, minvs, step)
+        else:
+            for i, box in enumerate(st.gt):
+                x1, y1, x2, y2 = int(box[0]), int(box[1]), int(box[2]), int(box[3])
+                if (x2 - x1) < 1 or (y2 - y1) < 1:
+                    continue                                     # returns before any draw (:45-47)
+                center = ((x1 + x2) / 2., (y1 + y2) / 2.)
+                M = geo_matrix(kind, self.severity, (W, H), center, (x2 - x1 + 1, y2 - y1 + 1))
+                sup = st.support[i]
+                if sup is None or sup[2] <= 0 or sup[3] <= 0:
+                    continue                                     # mask identically zero: image unchanged
+                minv = (ctypes.c_double * 6)(*invert_affine(M))
+                check(L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
+                                             ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
+                                             ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
+                                             stream_ptr()), 'oadg_oamix_bbox_step')
+        if self.stats is not None:
+            self.stats['bbox_ops'] = self.stats.get('bbox_ops', 0) + 1
+            self.stats['bbox_px'] = self.stats.get('bbox_px', 0) + sum(
+                s_[2] * s_[3] for s_ in st.support if s_ is not None and s_[2] > 0 and s_[3] > 0)
         return T
+
+    def _box_matrices(self, st, kind):
+        """The per-box loop above for ALL boxes at once: (rows, rects [m,4], inverted matrices [m,6]) of the boxes that
+        take a step.  Every box with integer width and height >= 1 draws ``uniform(.1, 10)`` and a sign draw, i.e. TWO
+        consecutive doubles of the stream (numpy: uniform(a, b) = a + (b - a) * next_double(), uniform() and random() =
+        next_double()), in box order - one ``random_sample(2 m)`` call consumes exactly the same doubles.  The matrix
+        arithmetic repeats geo_matrix / invert_affine operation for operation in float64 / float32 numpy (no fused
+        multiply-adds), cos / sin of the integer angle through the same libm calls."""
+        gt = st.gt
+        n = len(gt)
+        if n == 0:
+            return [], np.zeros((0, 4), np.int32), np.zeros((0, 6))
+        ib = gt.astype(np.int64)                    # int() truncation of non-negative float32 coordinates
+        x1, y1, x2, y2 = ib[:, 0], ib[:, 1], ib[:, 2], ib[:, 3]
+        draws = ~(((x2 - x1) < 1) | ((y2 - y1) < 1))
+        m = int(draws.sum())
+        r = rng.random_sample(2 * m) if m else np.zeros((0,))
+        level = 0.1 + (self.severity - 0.1) * r[0::2]
+        flip = r[1::2] > 0.5
+        x1, y1, x2, y2 = (v[draws].astype(np.float64) for v in (x1, y1, x2, y2))
+        cx, cy = (x1 + x2) / 2., (y1 + y2) / 2.
+        M = np.zeros((m, 6), np.float64)
+        if kind == 'rotate':
+            deg = np.trunc(level * 30 / 10).astype(np.int64)
+            deg = np.where(flip, -deg, deg)
+            cxf, cyf = cx.astype(np.float32).astype(np.float64), cy.astype(np.float32).astype(np.float64)   # Point2f
+            tab = {d: (math.cos(d * math.pi / 180.0) * 1.0, math.sin(d * math.pi / 180.0) * 1.0) for d in np.unique(deg)}
+            alpha = np.array([tab[d][0] for d in deg], np.float64)
+            beta = np.array([tab[d][1] for d in deg], np.float64)
+            M[:, 0], M[:, 1], M[:, 2] = alpha, beta, (1 - alpha) * cxf - beta * cyf
+            M[:, 3], M[:, 4], M[:, 5] = -beta, alpha, beta * cxf + (1 - alpha) * cyf
+        elif kind in ('shear_x', 'shear_y'):
+            lvl = level * 0.3 / 10.
+            lvl = np.where(flip, -lvl, lvl)
+            f32 = lambda v: np.asarray(v, np.float64).astype(np.float32).astype(np.float64)  # noqa: E731
+            if kind == 'shear_x':
+                M[:, 0], M[:, 1], M[:, 2], M[:, 4] = 1.0, f32(-lvl), f32(-(-lvl * cy)), 1.0
+            else:
+                M[:, 0], M[:, 3], M[:, 4], M[:, 5] = 1.0, f32(-lvl), 1.0, f32(-(-lvl * cx))
+        else:
+            size = (x2 - x1 + 1) if kind == 'translate_x' else (y2 - y1 + 1)
+            lvl = np.trunc(level * (size / 3) / 10)
+            lvl = np.where(flip, -lvl, lvl)
+            M[:, 0], M[:, 4] = 1.0, 1.0
+            M[:, 2 if kind == 'translate_x' else 5] = (-lvl).astype(np.float32).astype(np.float64)
+        # invert_affine, vectorised in the same operation order
+        D = M[:, 0] * M[:, 4] - M[:, 1] * M[:, 3]
+        with np.errstate(divide='ignore'):
+            D = np.where(D != 0, 1.0 / D, 0.0)
+        A11, A22 = M[:, 4] * D, M[:, 0] * D
+        m1, m3 = M[:, 1] * -D, M[:, 3] * -D
+        b1 = -A11 * M[:, 2] - m1 * M[:, 5]
+        b2 = -m3 * M[:, 2] - A22 * M[:, 5]
+        minv = np.stack([A11, m1, b1, m3, A22, b2], 1)
+        sup = [st.support[i] for i in np.nonzero(draws)[0]]
+        live = np.array([s_ is not None and s_[2] > 0 and s_[3] > 0 for s_ in sup], bool)
+        rows = np.nonzero(draws)[0][live]
+        rects = np.array([s_ for s_, ok in zip(sup, live) if ok], np.int32).reshape(-1, 4)
+        return rows, rects, minv[live]
+
+    def _bbox_chain(self, st, T, rows, rects, minvs, step):
+        """all boxes of one bboxes_only_* op: steps sorted by dependency level, one descriptor upload, 2 launches per
+        level (csrc oadg_oamix_bbox_chain)"""
+        L = _lib.lib()
+        b = self._buffers(st)
+        H, W = st.H, st.W
+        n = len(rows)
+        rects = np.ascontiguousarray(rects, np.int32)
+        minvs = np.ascontiguousarray(minvs, np.float64)
+        level = np.zeros((n,), np.int32)
+        check(L.oadg_oamix_bbox_levels(rects.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                       minvs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, H, W,
+                                       level.ctypes.data_as(ctypes.POINTER(ctypes.c_int))), 'oadg_oamix_bbox_levels')
+        order = np.argsort(level, kind='stable')
+        steps = np.zeros((n,), BBOX_STEP_DTYPE)
+        steps['minv'] = np.asarray(minvs, np.float64)[order]
+        steps['rect'] = np.asarray(rects, np.int32)[order]
+        steps['row'] = np.asarray(rows, np.int32)[order]
+        area = steps['rect'][:, 2].astype(np.int64) * steps['rect'][:, 3]
+        lv = level[order]
+        n_levels = int(lv[-1]) + 1
+        if self.stats is not None:
+            self.stats['bbox_levels'] = self.stats.get('bbox_levels', 0) + n_levels
+            self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n
+        first = np.searchsorted(lv, np.arange(n_levels + 1)).astype(np.int32)
+        # the rects of one level are disjoint, so their packed scratch images fit the H*W*3 scratch buffer
+        cum = np.cumsum(area) - area
+        steps['scratch_off'] = 3 * (cum - cum[first[:-1]][lv])
+        tiles = np.zeros((n + 1,), np.int32)
+        tiles[1:] = np.cumsum((area + 255) // 256)
+        dev = st.img.device
+        keep = step.setdefault('keepalive', [])              # descriptor tensors live until the step's launches ran
+        steps_dev = _upload(steps.view(np.uint8).reshape(-1), dev)
+        tiles_dev = _upload(tiles, dev)
+        keep += [steps_dev, tiles_dev]
+        check(L.oadg_oamix_bbox_chain(ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
+                                      first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
+                                      tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(st.My), ptr(st.Mx),
+                                      ptr(b['scratch']), stream_ptr()), 'oadg_oamix_bbox_chain')
 
     # ------------------------------------------------------------------------------------------ one view
     def oamix(self, st, out_u8=None, out_norm=None, norm=None, pad_shape=None):
@@ -363,6 +537,8 @@ class OAMix:
                                            (1 if i == 0 else 2) if last else 0, stream_ptr()),
                       'oadg_oamix_compose')
                 cur = dst
+                if self.stats is not None:
+                    self.stats['compose_steps'] = self.stats.get('compose_steps', 0) + 1
         # get_regions_for_object_aware_mixing (oa_mix.py:245-262)
         scores = st.scores()
         targets = []
