@@ -282,18 +282,22 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
 // pixel).  LDS: two K-tile buffers of four 16 KiB half-tiles each - P0/P1 = pixel rows 0-127 / 128-255,
 // W0/W1 = channel rows likewise - 128 KiB, one workgroup per CU, two waves per SIMD.
 //
-// Schedule (per K-tile t, buffer t & 1): four phases, each = { ds_read one register sub-tile, issue ONE half-tile
-// of global_load_lds, s_barrier, 16 MFMAs (one quadrant x K = 64), s_barrier }.  Pixel group 1 runs one barrier
-// behind group 0, so on every SIMD one wave is in its MFMA phase while the other one is in its load phase.
-//   phase   reads (buffer t&1)   MFMA quadrant   stages (2 glds per thread)
-//     1     P0 + W0              (p0, w0)        P1 of tile t+1   (last read: tile t-1 phase 3)
-//     2     W1                   (p0, w1)        W0 of tile t+1   (last read: tile t-1 phase 4)
-//     3     P1                   (p1, w1)        P0 of tile t+2   (last read: tile t   phase 1)
-//     4     W0                   (p1, w0)        W1 of tile t+2   (last read: tile t   phase 2)
-// A half-tile is restaged two phases after its last read (the reads of the lagging group are complete by then),
-// and global_load_lds results are only waited for once per tile: `s_waitcnt vmcnt(4)` in phase 4 leaves the two
-// youngest half-tiles in flight and retires everything tile t+1 needs; the barrier that follows publishes it.
-// Tiles past the end are staged from the zero line so that the counts stay uniform.
+// Schedule (per K-tile t, buffer t & 1): TWO phases of 32 MFMAs, each = { ds_read the register sub-tiles, issue two
+// half-tiles of global_load_lds, s_waitcnt lgkmcnt(0), s_barrier, 32 MFMAs (two quadrants x K = 64), s_barrier }.
+// Pixel group 1 runs one barrier behind group 0, so on every SIMD one wave is in its MFMA phase while the other one is
+// in its load phase.
+//   phase   reads (buffer t&1)   MFMA quadrants        stages (4 glds per thread)
+//     A     W0 + W1 + P0         (p0,w0) (p0,w1)       W1, P1 of tile t+1   (last read: tile t-1 phases A / B)
+//     B     P1                   (p1,w1) (p1,w0)       P0, W0 of tile t+2   (last read: tile t phase A)
+// Ablations on the FPN 3x3 shape (tools/probe/conv256_lab.hip): with 16 MFMAs per phase (the first form of this
+// kernel) a barrier interval costs ~120 cycles beyond its 16 x 16 MFMA cycles - the matrix pipe idles while the barrier
+// releases the partner wave - so MFMAs + barriers alone ran at 1490 TFLOP/s; 32 per phase halve the number of
+// intervals: 1650, and the whole kernel 1000 -> 1200 TFLOP/s with bit-identical results.  The reads of a phase are
+// retired (lgkmcnt(0)) BEFORE its first barrier, so a half-tile may be restaged one phase after its last read;
+// global_load_lds results are waited for once per tile, `s_waitcnt vmcnt(4)` before the first barrier of phase B: that
+// leaves phase B's own four loads in flight and retires everything tile t+1 needs, read one phase later (the barrier
+// in between publishes the other waves' loads).  Tiles past the end are staged from the zero line so that the counts
+// stay uniform.
 constexpr int TM = 256, TN = 256;
 constexpr int HALF_BYTES = 128 * BK * 2;          // 16 KiB
 constexpr int BUF_BYTES = 4 * HALF_BYTES;         // 64 KiB
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 #pragma unroll
                 for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 pf[4][2], wf[2][2];
+    bf16x8 pf[4][2], wf[2][2][2];
     auto read_pix = [&](int h, int buf) {
         const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
 #pragma unroll
@@ -427,25 +431,26 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[jt][ks] = *reinterpret_cast<const bf16x8*>(base + woff[jt][ks]);
+            for (int ks = 0; ks < 2; ++ks) wf[h][jt][ks] = *reinterpret_cast<const bf16x8*>(base + woff[jt][ks]);
     };
-#define OADG_QUADRANT(WH, PH_)                                                                               \
+#define OADG_MFMA32(W_FIRST, PH_)                                                                            \
     do {                                                                                                     \
-        asm volatile("s_barrier" ::: "memory");                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
-            _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                                 \
-                _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
-                    acc[WH][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jt][ks], pf[it][ks],   \
-                                                                                   acc[WH][jt][PH_][it], 0, 0, 0); \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+                _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                             \
+                    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                         \
+                        acc[hh ^ W_FIRST][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
+                            wf[hh ^ W_FIRST][jt][ks], pf[it][ks], acc[hh ^ W_FIRST][jt][PH_][it], 0, 0, 0);  \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         asm volatile("s_barrier" ::: "memory");                                                              \
     } while (0)
 
-    // ---- prologue: tile 0 complete, plus the two half-tiles of tile 1 that phases 3/4 of "tile -1" would stage
+    // ---- prologue: tile 0 complete in buffer 0, P0 + W0 of tile 1 in buffer 1 (what phase B of "tile -1" stages)
     TapState s1{0, 0, 0, 0, 0};
     stage_pix(0, s1, 0);
     stage_wgt(0, s1, 0);
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     stage_pix(1, s1, 0);
     advance(s1);                     // s1 = tile 1
     stage_pix(0, s1, 1);
-    stage_wgt(1, s1, 1);
+    stage_wgt(0, s1, 1);
     TapState s2 = s1;
     advance(s2);                     // s2 = tile 2
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -462,28 +467,23 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
-        // phase 1
+        // phase A
         read_wgt(0, buf);
-        read_pix(0, buf);
-        stage_pix(1, s1, buf ^ 1);
-        OADG_QUADRANT(0, 0);
-        // phase 2
         read_wgt(1, buf);
-        stage_wgt(0, s1, buf ^ 1);
-        OADG_QUADRANT(1, 0);
-        // phase 3
+        read_pix(0, buf);
+        stage_wgt(1, s1, buf ^ 1);
+        stage_pix(1, s1, buf ^ 1);
+        OADG_MFMA32(0, 0);
+        // phase B
         read_pix(1, buf);
         stage_pix(0, s2, buf);
-        OADG_QUADRANT(1, 1);
-        // phase 4
-        read_wgt(0, buf);
-        stage_wgt(1, s2, buf);
+        stage_wgt(0, s2, buf);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        OADG_QUADRANT(0, 1);
+        OADG_MFMA32(1, 1);
         s1 = s2;
         advance(s2);
     }
-#undef OADG_QUADRANT
+#undef OADG_MFMA32
     if (wr == 0) asm volatile("s_barrier" ::: "memory");     // balance the stagger
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-line stages of the tail have landed
     asm volatile("s_barrier" ::: "memory");
