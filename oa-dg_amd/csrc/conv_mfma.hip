@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
         }
         return out;
     };
-    bf16x8 df[4][2], xf[2][2];
+    bf16x8 df[4][2], xf[2][2][2];
     auto read_dy = [&](int h, int buf) {
         const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
 #pragma unroll
@@ -1039,19 +1039,21 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) xf[jt][ks] = frag(base, xoff[jt], ks);
+            for (int ks = 0; ks < 2; ++ks) xf[h][jt][ks] = frag(base, xoff[jt], ks);
     };
-#define OADG_WQUADRANT(XH, DH)                                                                               \
+    // two 32-MFMA phases per pixel chunk, reads retired before the phase's first barrier (see conv_igemm256_kernel)
+#define OADG_WMFMA32(X_FIRST, DH)                                                                            \
     do {                                                                                                     \
-        asm volatile("s_barrier" ::: "memory");                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
-            _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                                 \
-                _Pragma("unroll") for (int it = 0; it < 4; ++it)                                             \
-                    acc[XH][jt][DH][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[jt][ks], df[it][ks],    \
-                                                                                  acc[XH][jt][DH][it], 0, 0, 0); \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                     \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+                _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                             \
+                    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                         \
+                        acc[hh ^ X_FIRST][jt][DH][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(             \
+                            xf[hh ^ X_FIRST][jt][ks], df[it][ks], acc[hh ^ X_FIRST][jt][DH][it], 0, 0, 0);   \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         asm volatile("s_barrier" ::: "memory");                                                              \
@@ -1065,7 +1067,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
     stage_dy(1, s1, 0);
     advance(s1);
     stage_dy(0, s1, 1);
-    stage_x(1, s1, 1);
+    stage_x(0, s1, 1);
     s2 = s1;
     advance(s2);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -1074,24 +1076,23 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
 
     for (int t = 0; t < nk; ++t) {
         const int buf = t & 1;
+        // phase A: both x halves + dy half 0; stages x1, dy1 of chunk t+1
         read_x(0, buf);
-        read_dy(0, buf);
-        stage_dy(1, s1, buf ^ 1);
-        OADG_WQUADRANT(0, 0);
         read_x(1, buf);
-        stage_x(0, s1, buf ^ 1);
-        OADG_WQUADRANT(1, 0);
+        read_dy(0, buf);
+        stage_x(1, s1, buf ^ 1);
+        stage_dy(1, s1, buf ^ 1);
+        OADG_WMFMA32(0, 0);
+        // phase B: dy half 1; stages dy0, x0 of chunk t+2 (this buffer: read in phase A, retired before its barrier)
         read_dy(1, buf);
         stage_dy(0, s2, buf);
-        OADG_WQUADRANT(1, 1);
-        read_x(0, buf);
-        stage_x(1, s2, buf);
+        stage_x(0, s2, buf);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        OADG_WQUADRANT(0, 1);
+        OADG_WMFMA32(1, 1);
         s1 = s2;
         advance(s2);
     }
-#undef OADG_WQUADRANT
+#undef OADG_WMFMA32
     if (wr == 0) asm volatile("s_barrier" ::: "memory");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
