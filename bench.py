@@ -101,7 +101,7 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     gts = synthetic_boxes(rs, 20, H, W, 12, 200)
     labels = rs.randint(0, 8, 20).astype(np.int64)
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det.train()
     det.local_log_vars = True        # a CPU side model: never joins the (RCCL) process group's reductions
     opt = build_optimizer(det, cfg.optimizer)
@@ -175,7 +175,7 @@ def main():
         hip_conv.enable()
     set_random_seed(0)                       # identical initial weights on every rank
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     det.log_vars_on_host = False             # log_vars stay on the device (read at a log interval in training)
     engine = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=distributed, amp_dtype=amp)

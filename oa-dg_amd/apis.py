@@ -282,20 +282,24 @@ class TrainEngine:
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
 
 
-def train_detector(model, data_iter, cfg, distributed=False, max_iters=None, logger=print, amp_dtype=None):
+def train_detector(model, data_iter, cfg, distributed=False, max_iters=None, logger=print, amp_dtype=None,
+                   iters_per_epoch=None):
     """apis/train.py:71-212 reduced to the hot loop: build optimizer + schedule, iterate, log every
-    cfg.log_config.interval iterations."""
+    cfg.log_config.interval iterations.  ``iters_per_epoch`` (or ``len(data_iter)`` when it has one) drives the
+    epoch-based step decay of the LR schedule."""
     optimizer = build_optimizer(model, cfg.optimizer)
     sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
     engine = TrainEngine(model, optimizer, distributed, amp_dtype,
                          find_unused_parameters=cfg.get('find_unused_parameters', False))
     interval = cfg.get('log_config', {}).get('interval', 50)
     rank, _ = get_dist_info()
+    if iters_per_epoch is None and hasattr(data_iter, '__len__'):
+        iters_per_epoch = len(data_iter)
     t0 = time.time()
     for it, data in enumerate(data_iter):
         if max_iters is not None and it >= max_iters:
             break
-        sched.set(0, it)
+        sched.set(it // iters_per_epoch if iters_per_epoch else 0, it)
         out = engine.step(data)
         if rank == 0 and (it + 1) % interval == 0:
             lv = {k: (float(v) if not isinstance(v, float) else v) for k, v in out['log_vars'].items()}

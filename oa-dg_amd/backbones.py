@@ -105,8 +105,36 @@ class ResNet(nn.Module):
         self.feat_dim = inplanes
         self._freeze_stages()
 
-    def init_weights(self):
-        """resnet.py:405-424 defaults: Kaiming(fan_out, relu) convs, BN gamma 1, last BN of a block 0."""
+    def init_weights(self, allow_missing_pretrained=None):
+        """resnet.py:405-424 defaults: Kaiming(fan_out, relu) convs, BN gamma 1, last BN of a block 0 - then
+        ``init_cfg=dict(type='Pretrained', checkpoint=...)`` (BaseModule.init_weights -> PretrainedInit): the checkpoint
+        is loaded into the backbone (a detector checkpoint contributes its ``backbone.`` keys).  A configured
+        checkpoint that cannot be resolved raises, unless ``allow_missing_pretrained`` (or OADG_ALLOW_RANDOM_INIT=1:
+        synthetic benchmarks and tests, which are defined on random-init weights) downgrades it to a loud warning."""
+        self._random_init()
+        cfg = self.init_cfg
+        if isinstance(cfg, (list, tuple)):
+            cfg = next((c for c in cfg if c.get('type') == 'Pretrained'), None)
+        if cfg is None or cfg.get('type') != 'Pretrained' or not cfg.get('checkpoint'):
+            return
+        from .checkpoint import load_checkpoint, resolve_checkpoint
+        try:
+            path = resolve_checkpoint(cfg['checkpoint'])
+        except FileNotFoundError as e:
+            if allow_missing_pretrained is None:
+                allow_missing_pretrained = os.environ.get('OADG_ALLOW_RANDOM_INIT', '0') == '1'
+            if not allow_missing_pretrained:
+                raise
+            import warnings
+            warnings.warn(f'[oadg] backbone init_cfg: {e} -> RANDOM initialisation (frozen stem / stage 1 included)')
+            return
+        import torch as _t
+        keys = _t.load(path, map_location='cpu', weights_only=False)
+        keys = keys.get('state_dict', keys)
+        prefix = cfg.get('prefix') or ('backbone' if any(k.startswith('backbone.') for k in keys) else None)
+        load_checkpoint(self, path, prefix=prefix)
+
+    def _random_init(self):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 kaiming_init(m)

@@ -70,6 +70,8 @@ class CocoDataset:
             valid = self._filter_imgs()
             self.data_infos = [self.data_infos[i] for i in valid]
         self._pool = ThreadPoolExecutor(decode_workers, thread_name_prefix='oadg-decode')
+        # custom.py:209-221 _set_group_flag: images with aspect ratio > 1 form group 1 (the samplers group by it)
+        self.flag = np.array([1 if i['width'] / i['height'] > 1 else 0 for i in self.data_infos], dtype=np.uint8)
 
     # ---- coco.py:40-67
     def load_annotations(self, ann_file):
@@ -187,6 +189,8 @@ class RepeatDataset:
         self.dataset, self.times = dataset, times
         self.CLASSES = getattr(dataset, 'CLASSES', None)
         self._ori_len = len(dataset)
+        if hasattr(dataset, 'flag'):                      # dataset_wrappers.py:170-171
+            self.flag = np.tile(dataset.flag, times)
 
     def __len__(self):
         return self.times * self._ori_len

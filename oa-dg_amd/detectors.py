@@ -178,8 +178,10 @@ class TwoStageDetector(BaseDetector):
     with_rpn = property(lambda self: self.rpn_head is not None)
     with_neck = property(lambda self: self.neck is not None)
 
-    def init_weights(self):
-        self.backbone.init_weights()
+    def init_weights(self, allow_missing_pretrained=None):
+        """``allow_missing_pretrained=True``: a configured but unavailable backbone checkpoint (no network here) only
+        warns and the backbone stays randomly initialised - the synthetic benchmark / smoke / test contract."""
+        self.backbone.init_weights(allow_missing_pretrained)
 
     def extract_feat(self, img):
         x = self.backbone(img)

@@ -14,7 +14,7 @@ def train_step_smoke(dev):
     cfg = Config.fromfile(os.path.join(root, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
     set_random_seed(0)
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
     ds = SyntheticCityscapes(img_shape=(256, 512), num_boxes=8, box_size=(16, 120), device=dev)

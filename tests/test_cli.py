@@ -85,3 +85,40 @@ def test_bench_self_launches_n_ranks_when_no_launcher_is_present(monkeypatch):
     assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
     assert cmd[-6:] == ['--gpus', '8', '--steps', '3', '--warmup', '1'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+@pytest.mark.gpu
+def test_train_cli_shuffles_checkpoints_and_resumes_epoch_and_iter(tmp_path):
+    """tools/train.py end to end on synthetic samples: per-epoch shuffled order (GroupSampler), epoch checkpoints with
+    meta epoch / iter, and --resume-from continuing with the NEXT epoch at the saved iteration (EpochBasedRunner.resume)
+    instead of starting over."""
+    import subprocess
+    import torch
+    cfg = tmp_path / 'tiny.py'
+    cfg.write_text(
+        f"_base_ = ['{ROOT}/configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py']\n"
+        "data = dict(samples_per_gpu=2, train=dict(img_shape=(256, 512), num_boxes=6, box_size=(16, 120), length=8))\n"
+        "runner = dict(type='EpochBasedRunner', max_epochs=3)\n"
+        "checkpoint_config = dict(interval=1)\n"
+        "log_config = dict(interval=1, hooks=[dict(type='TextLoggerHook')])\n"
+        "lr_config = dict(policy='step', warmup=None, step=[1])\n")
+    env = dict(os.environ, OADG_ALLOW_RANDOM_INIT='1')
+    w1 = tmp_path / 'w1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train.py'), str(cfg), '--work-dir', str(w1), '--seed', '0'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('Epoch [')]
+    assert len(lines) == 12 and lines[0].startswith('Epoch [1][1/4]') and lines[-1].startswith('Epoch [3][4/4]')
+    assert 'lr: 1.000e-02' in lines[0] and 'lr: 1.000e-03' in lines[4]           # step decay at epoch index 1
+    ck = torch.load(str(w1 / 'epoch_2.pth'), map_location='cpu', weights_only=False)
+    assert ck['meta']['epoch'] == 2 and ck['meta']['iter'] == 8
+    w2 = tmp_path / 'w2'
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train.py'), str(cfg), '--work-dir', str(w2), '--seed', '0',
+                         '--resume-from', str(w1 / 'epoch_2.pth')], capture_output=True, text=True, env=env, timeout=900)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    assert 'resumed epoch 2, iter 8' in r2.stdout
+    lines2 = [l for l in r2.stdout.splitlines() if l.startswith('Epoch [')]
+    assert len(lines2) == 4 and lines2[0].startswith('Epoch [3][1/4]') and 'lr: 1.000e-03' in lines2[0]
+    ck2 = torch.load(str(w2 / 'epoch_3.pth'), map_location='cpu', weights_only=False)
+    assert ck2['meta']['epoch'] == 3 and ck2['meta']['iter'] == 12
+    assert not (w2 / 'epoch_1.pth').exists()                                          # earlier epochs are not redone

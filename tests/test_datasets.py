@@ -110,7 +110,7 @@ def test_real_files_through_the_reference_pipeline_and_a_train_step(dev, tmp_pat
     data = pipe(*ds.batch([0, 1]))
     assert data['img'].shape[0] == 2 and data['img'].shape[2] % 32 == 0 and data['img2'].shape == data['img'].shape
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     hip_conv.enable()
     out = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16).step(data)

@@ -28,7 +28,7 @@ def _worker(rank, world, port, q, torch_ddp=False):
     cfg = Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
     set_random_seed(0)
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det.train()
     eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=True)
     b = model_batch(10 + rank, 1, 192, 320, n_gt=6)          # different data on each rank

@@ -142,7 +142,7 @@ def test_r101_dc5_oadg_config_trains_one_step(dev):
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r101_dc5_1x_dwd_oadg.py'))
     set_random_seed(0)
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     assert sum(p.numel() for p in det.parameters()) == 184580783
     hip_conv.enable()

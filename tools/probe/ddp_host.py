@@ -18,7 +18,7 @@ dev = torch.device('cuda:0')
 hip_conv.enable()
 cfg = Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
 set_random_seed(0)
-det = build_detector(cfg.model); det.init_weights()
+det = build_detector(cfg.model); det.init_weights(allow_missing_pretrained=True)
 det = det.to(dev).to(memory_format=torch.channels_last).train(); det.log_vars_on_host = False
 ddp = os.environ.get('DDP', '1') == '1'
 if ddp:

@@ -53,7 +53,7 @@ def main():
         hip_conv.enable()
     cfg = Config.fromfile(os.path.join(ROOT, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
     det = build_detector(cfg.model)
-    det.init_weights()
+    det.init_weights(allow_missing_pretrained=True)
     det = det.to(dev).to(memory_format=torch.channels_last).train()
     set_random_seed(0)
     eng = TrainEngine(det, build_optimizer(det, cfg.optimizer),

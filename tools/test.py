@@ -32,6 +32,8 @@ def parse_args():
     p.add_argument('--local_rank', type=int, default=0)
     p.add_argument('--max-samples', type=int, default=None, help='stop after this many images (smoke runs)')
     p.add_argument('--amp', default='bf16', choices=['bf16', 'none'])
+    p.add_argument('--allow-partial-checkpoint', action='store_true',
+                   help='evaluate even if the checkpoint lacks (or mis-sizes) some model tensors')
     a = p.parse_args()
     os.environ.setdefault('LOCAL_RANK', str(a.local_rank))
     return a
@@ -94,10 +96,18 @@ def main():
     cfg.model.pop('pretrained', None)
     model = build_detector(cfg.model, test_cfg=cfg.get('test_cfg'))
     if a.checkpoint != 'none':
-        ck = torch.load(a.checkpoint, map_location='cpu')
-        model.load_state_dict(ck.get('state_dict', ck), strict=False)
+        from oadg_amd.checkpoint import load_checkpoint
+        rep = load_checkpoint(model, a.checkpoint, map_location='cpu', strict=False, logger=print)
+        print(f'{rep["path"]}: {rep["loaded"]} tensors loaded, {len(rep["missing"])} missing, '
+              f'{len(rep["unexpected"])} unexpected, {len(rep["mismatched"])} size-mismatched')
+        lost = [k for k in rep['missing'] + [m[0] for m in rep['mismatched']]
+                if k.startswith(('backbone.', 'neck.', 'rpn_head.', 'roi_head.'))]
+        if lost and not a.allow_partial_checkpoint:
+            raise RuntimeError(f'{len(lost)} model tensors are not provided by {a.checkpoint} (e.g. {lost[:4]}): they '
+                               f'would be evaluated at their random initial values; pass --allow-partial-checkpoint to '
+                               f'do that anyway')
     else:
-        model.init_weights()
+        model.init_weights(allow_missing_pretrained=True)
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
     amp = torch.bfloat16 if a.amp == 'bf16' else None
     if amp is not None:

@@ -53,6 +53,9 @@ def parse_args():
     p.add_argument('--debug_mode', action='store_true')
     p.add_argument('--max-iters', type=int, default=None, help='stop after this many iterations (smoke runs)')
     p.add_argument('--amp', default='bf16', choices=['bf16', 'none'])
+    p.add_argument('--allow-missing-pretrained', action='store_true',
+                   help='train from random weights (with a warning) when a configured pretrained / load_from '
+                        'checkpoint is not available locally, instead of stopping')
     a = p.parse_args()
     if 'LOCAL_RANK' not in os.environ:
         os.environ['LOCAL_RANK'] = str(a.local_rank)
@@ -95,23 +98,37 @@ def main():
     seed = init_random_seed(a.seed, device=dev)
     set_random_seed(seed, deterministic=a.deterministic)
     model = build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
-    model.init_weights()
+    from oadg_amd.checkpoint import load_checkpoint
+    log0 = print if rank == 0 else None
+    model.init_weights(allow_missing_pretrained=a.allow_missing_pretrained)
     model = model.to(dev).to(memory_format=torch.channels_last).train()
     resume = a.resume_from or (latest_checkpoint(work_dir) if a.auto_resume else None) or cfg.get('resume_from')
-    start_iter = 0
+    start_iter = start_epoch = 0
     optimizer = build_optimizer(model, cfg.optimizer)
     load_from = cfg.get('load_from')
     if resume:
-        ck = torch.load(resume, map_location=dev)
-        model.load_state_dict(ck['state_dict'])
+        # EpochBasedRunner.resume (mmcv/runner/base_runner.py): weights, optimizer state, epoch AND iteration
+        rep = load_checkpoint(model, resume, map_location=dev, strict=False, logger=log0)
+        ck = rep['checkpoint']
         if 'optimizer' in ck:
             optimizer.load_state_dict(ck['optimizer'])
-        start_iter = ck.get('meta', {}).get('iter', 0)
-    elif load_from and os.path.exists(str(load_from)):
-        ck = torch.load(load_from, map_location=dev)   # mmdet checkpoints: {'state_dict': ...}; same key names
-        missing, unexpected = model.load_state_dict(ck.get('state_dict', ck), strict=False)
+        start_iter = int(ck.get('meta', {}).get('iter', 0))
+        start_epoch = int(ck.get('meta', {}).get('epoch', 0))
         if rank == 0:
-            print(f'loaded {load_from}: {len(missing)} missing / {len(unexpected)} unexpected keys')
+            print(f'resumed epoch {start_epoch}, iter {start_iter} from {resume}', flush=True)
+    elif load_from:
+        # mmdet checkpoints ({'state_dict': ...}, same key names); a head trained for another class count is dropped
+        # key by key and reported, as mmcv.load_checkpoint does (apis/train.py:196-197)
+        try:
+            rep = load_checkpoint(model, load_from, map_location=dev, strict=False, logger=log0)
+            if rank == 0:
+                print(f'load_from {rep["path"]}: {rep["loaded"]} tensors loaded, {len(rep["missing"])} missing, '
+                      f'{len(rep["unexpected"])} unexpected, {len(rep["mismatched"])} size-mismatched', flush=True)
+        except FileNotFoundError as e:
+            if not a.allow_missing_pretrained:
+                raise
+            if rank == 0:
+                print(f'[oadg] WARNING load_from: {e} -> continuing WITHOUT it (--allow-missing-pretrained)', flush=True)
     amp = torch.bfloat16 if a.amp == 'bf16' else None
     engine = TrainEngine(model, optimizer, distributed=distributed, amp_dtype=amp,
                          find_unused_parameters=cfg.get('find_unused_parameters', False))
@@ -124,7 +141,10 @@ def main():
     pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32, one_scale_per_batch=True)
     bs = cfg.data.get('samples_per_gpu', 2)
     epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
-    iters_per_epoch = len(ds) // (bs * world)
+    from oadg_amd.samplers import batches, build_sampler
+    # shuffled, aspect-ratio-grouped training order (GroupSampler / DistributedGroupSampler, datasets/builder.py:128-160)
+    sampler = build_sampler(ds, bs, distributed, rank, world, seed)
+    iters_per_epoch = len(sampler) // bs
     interval = cfg.get('log_config', {}).get('interval', 50)
 
     def save_checkpoint(epoch, it):
@@ -141,10 +161,10 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
 
     def index_lists():
-        for epoch in range(epochs):
-            for k in range(iters_per_epoch):
-                base = (epoch * iters_per_epoch + k) * bs * world + rank * bs
-                yield epoch, k, [(base + j) % len(ds) for j in range(bs)]
+        for epoch in range(start_epoch, epochs):          # a resumed run continues with the epoch after the saved one
+            sampler.set_epoch(epoch)
+            for k, idx in enumerate(batches(sampler.indices(), bs)):
+                yield epoch, k, idx
 
     def load(item):
         torch.cuda.set_device(dev)
