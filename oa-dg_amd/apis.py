@@ -75,7 +75,9 @@ class StepLrSchedule:
         assert policy == 'step'
         self.opt, self.steps, self.gamma = optimizer, [step] if isinstance(step, int) else list(step), gamma
         self.warmup, self.warmup_iters, self.warmup_ratio = warmup, warmup_iters, warmup_ratio
-        self.base = [g['lr'] for g in optimizer.param_groups]
+        # mmcv LrUpdaterHook.before_run: the base rate lives in the param group ('initial_lr'), so it survives an
+        # optimizer.load_state_dict() of a checkpoint saved after a decay step
+        self.base = [g.setdefault('initial_lr', g['lr']) for g in optimizer.param_groups]
 
     def set(self, epoch, it):
         exp = sum(1 for s in self.steps if epoch >= s)

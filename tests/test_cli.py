@@ -122,3 +122,35 @@ def test_train_cli_shuffles_checkpoints_and_resumes_epoch_and_iter(tmp_path):
     ck2 = torch.load(str(w2 / 'epoch_3.pth'), map_location='cpu', weights_only=False)
     assert ck2['meta']['epoch'] == 3 and ck2['meta']['iter'] == 12
     assert not (w2 / 'epoch_1.pth').exists()                                          # earlier epochs are not redone
+
+
+@pytest.mark.gpu
+def test_test_cli_coco_style_eval_and_robustness_loop(tmp_path):
+    """tools/test.py --eval bbox mAP (COCO-style numbers + VOC AP50) and tools/analysis_tools/test_robustness.py
+    (corruption x severity loop, severity 0 once, P / mPC / rPC aggregation) on the synthetic test split."""
+    import json
+    import pickle
+    import subprocess
+    cfg = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
+    env = dict(os.environ, OADG_ALLOW_RANDOM_INIT='1')
+    wd = tmp_path / 'eval'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'test.py'), cfg, 'none', '--eval', 'bbox', 'mAP',
+                        '--max-samples', '2', '--work-dir', str(wd), '--out', str(tmp_path / 'r.pkl')],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ev = json.load(open(wd / 'eval.json'))
+    assert list(ev['bbox']) == ['AP', 'AP50', 'AP75', 'APs', 'APm', 'APl', 'AR1', 'AR10', 'AR100', 'ARs', 'ARm', 'ARl']
+    assert -1.0 <= ev['bbox']['AP'] <= 1.0 and 'mAP' in ev['mAP']
+    assert len(pickle.load(open(tmp_path / 'r.pkl', 'rb'))) == 2
+    out = tmp_path / 'rob.pkl'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'analysis_tools', 'test_robustness.py'), cfg, 'none',
+                        '--corruptions', 'fog', 'snow', '--severities', '0', '1', '--max-samples', '2', '--out', str(out),
+                        '--final-prints', 'P', 'mPC', 'rPC', '--final-prints-aggregate', 'all'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count('Testing ') == 3                       # fog 0, fog 1, snow 1 (snow 0 reuses fog 0)
+    agg = pickle.load(open(tmp_path / 'rob_results.pkl', 'rb'))
+    assert set(agg) == {'fog', 'snow'} and set(agg['snow']) == {0, 1} and agg['snow'][0] is agg['fog'][0] or \
+        agg['snow'][0] == agg['fog'][0]
+    summ = json.load(open(tmp_path / 'rob_summary.json'))
+    assert set(summ) == {'P', 'mPC', 'rPC'} and 'Mean Performance under Corruption [mPC] (bbox)' in r.stdout

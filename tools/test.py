@@ -4,8 +4,9 @@ apis/test.py): CONFIG CHECKPOINT [--out results.pkl] [--eval bbox] [--cfg-option
 
 Runs ``model(return_loss=False, rescale=True, **data)`` over the test split through the device test pipeline and
 collects one ``list[np.ndarray [k, 5]]`` (per class) per image, the format ``--out`` pickles in the reference.
-``--eval bbox`` reports VOC-style AP@0.5 (mmdet/core/evaluation/mean_ap.py ``eval_map``, area mode) against the
-dataset's boxes: the COCO-style Cityscapes evaluator needs pycocotools, which this image does not have.
+``--eval bbox`` reports the COCO-style numbers the reference's Cityscapes / COCO datasets report (AP@[.50:.95], AP50,
+AP75, APs/m/l, AR...: oadg_amd/evaluation.py, a restatement of pycocotools' COCOeval, which this image does not have);
+``--eval mAP`` the VOC-style AP@0.5 of mmdet/core/evaluation/mean_ap.py ``eval_map`` (area mode).
 """
 import argparse
 import os
@@ -26,7 +27,7 @@ def parse_args():
     p.add_argument('checkpoint', help="checkpoint file ('none' = random init, for smoke runs)")
     p.add_argument('--work-dir', help='the directory to save the evaluation metrics')
     p.add_argument('--out', help='output result file in pickle format')
-    p.add_argument('--eval', type=str, nargs='+', help="evaluation metrics: 'bbox'")
+    p.add_argument('--eval', type=str, nargs='+', help="evaluation metrics: 'bbox' (COCO style), 'mAP' (VOC style AP@0.5)")
     p.add_argument('--cfg-options', nargs='+', action=DictAction, help='override config entries, key=value')
     p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none')
     p.add_argument('--local_rank', type=int, default=0)
@@ -84,49 +85,79 @@ def eval_map(results, annotations, num_classes, iou_thr=0.5):
     return (float(np.mean(aps)) if aps else 0.0), aps
 
 
-def main():
-    a = parse_args()
-    from oadg_amd import Config, build_detector, hip_conv
-    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
-    cfg = Config.fromfile(a.config)
-    if a.cfg_options:
-        cfg.merge_from_dict(a.cfg_options)
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
-    dev = torch.device('cuda', torch.cuda.current_device())
+def build_model(cfg, checkpoint, dev, amp, allow_partial=False):
+    from oadg_amd import build_detector, hip_conv
     cfg.model.pop('pretrained', None)
     model = build_detector(cfg.model, test_cfg=cfg.get('test_cfg'))
-    if a.checkpoint != 'none':
+    if checkpoint != 'none':
         from oadg_amd.checkpoint import load_checkpoint
-        rep = load_checkpoint(model, a.checkpoint, map_location='cpu', strict=False, logger=print)
+        rep = load_checkpoint(model, checkpoint, map_location='cpu', strict=False, logger=print)
         print(f'{rep["path"]}: {rep["loaded"]} tensors loaded, {len(rep["missing"])} missing, '
               f'{len(rep["unexpected"])} unexpected, {len(rep["mismatched"])} size-mismatched')
         lost = [k for k in rep['missing'] + [m[0] for m in rep['mismatched']]
                 if k.startswith(('backbone.', 'neck.', 'rpn_head.', 'roi_head.'))]
-        if lost and not a.allow_partial_checkpoint:
-            raise RuntimeError(f'{len(lost)} model tensors are not provided by {a.checkpoint} (e.g. {lost[:4]}): they '
+        if lost and not allow_partial:
+            raise RuntimeError(f'{len(lost)} model tensors are not provided by {checkpoint} (e.g. {lost[:4]}): they '
                                f'would be evaluated at their random initial values; pass --allow-partial-checkpoint to '
                                f'do that anyway')
     else:
         model.init_weights(allow_missing_pretrained=True)
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
-    amp = torch.bfloat16 if a.amp == 'bf16' else None
     if amp is not None:
         hip_conv.enable()
+    return model
+
+
+def run_test(model, data_cfg, dev, amp, samples_per_gpu=1, max_samples=None):
+    """single_gpu_test (apis/test.py:15-70) over one test-split config: (results, dataset, seconds)"""
     from oadg_amd.datasets import build_dataset
-    dcfg = cfg.data.test
-    ds = build_dataset(dcfg, default_args=dict(seed=12345, device=dev, test_mode=True), synthetic_fallback=True)
-    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32)
-    n = len(ds) if a.max_samples is None else min(len(ds), a.max_samples)
-    bs = cfg.data.get('samples_per_gpu', 1)
-    results, annotations, t0 = [], [], time.time()
-    for i in range(0, n, bs):
-        imgs, boxes, labels = ds.batch(list(range(i, min(i + bs, n))))
+    from oadg_amd.pipelines import DevicePipeline
+    ds = build_dataset(data_cfg, default_args=dict(seed=12345, device=dev, test_mode=True), synthetic_fallback=True)
+    pipe = DevicePipeline(data_cfg['pipeline'], dtype=amp or torch.float32)
+    n = len(ds) if max_samples is None else min(len(ds), max_samples)
+    results, t0 = [], time.time()
+    for i in range(0, n, samples_per_gpu):
+        imgs, boxes, labels = ds.batch(list(range(i, min(i + samples_per_gpu, n))))
         data = pipe.test_batch(imgs)
         with torch.no_grad(), torch.autocast('cuda', dtype=amp, enabled=amp is not None):
             results.extend(model(return_loss=False, rescale=True, **data))
-        annotations.extend(zip([np.asarray(b) for b in boxes], [np.asarray(l) for l in labels]))
     torch.cuda.synchronize()
-    dt = time.time() - t0
+    return results, ds, time.time() - t0
+
+
+def evaluate(results, ds, metrics, num_classes):
+    """{'bbox': {AP, AP50, ...}} (COCO style) and / or {'mAP': ...} (VOC style AP@0.5)"""
+    from oadg_amd import evaluation as E
+    out = {}
+    idx = range(len(results))
+    if 'bbox' in metrics:
+        out['bbox'] = E.coco_eval_bbox(E.dataset_gt_anns(ds, idx), results, num_classes)
+    if 'mAP' in metrics:
+        anns = []
+        for i in idx:
+            if hasattr(ds, 'get_ann_info'):
+                a_ = ds.get_ann_info(i)
+                anns.append((a_['bboxes'], a_['labels']))
+            else:
+                anns.append(ds.boxes(i))
+        m, aps = eval_map(results, anns, num_classes)
+        out['mAP'] = dict(mAP=m, per_class=aps)
+    return out
+
+
+def main():
+    a = parse_args()
+    from oadg_amd import Config
+    cfg = Config.fromfile(a.config)
+    if a.cfg_options:
+        cfg.merge_from_dict(a.cfg_options)
+    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
+    dev = torch.device('cuda', torch.cuda.current_device())
+    amp = torch.bfloat16 if a.amp == 'bf16' else None
+    model = build_model(cfg, a.checkpoint, dev, amp, a.allow_partial_checkpoint)
+    dcfg = cfg.data.test
+    results, ds, dt = run_test(model, dcfg, dev, amp, cfg.data.get('samples_per_gpu', 1), a.max_samples)
+    n = len(results)
     print(f'{n} images in {dt:.2f} s ({n / dt:.1f} img/s), {sum(len(c) for r in results for c in r)} detections')
     if a.out:
         assert a.out.endswith(('.pkl', '.pickle')), 'The output file must be a pkl file.'
@@ -134,9 +165,20 @@ def main():
             pickle.dump(results, f)
         print(f'writing results to {a.out}')
     if a.eval:
-        assert a.eval == ['bbox'], "only --eval bbox is built"
-        m, aps = eval_map(results, annotations, len(getattr(ds, 'CLASSES', None) or range(dcfg.get('num_classes', 8))))
-        print(f'AP50 (eval_map, area): mAP {m:.4f}  per class ' + ' '.join(f'{v:.3f}' for v in aps))
+        assert set(a.eval) <= {'bbox', 'mAP'}, "--eval bbox (COCO style) and / or mAP (VOC style AP@0.5)"
+        nc = len(getattr(ds, 'CLASSES', None) or range(dcfg.get('num_classes', 8)))
+        ev = evaluate(results, ds, a.eval, nc)
+        if 'bbox' in ev:
+            print('bbox (COCO style): ' + '  '.join(f'{k} {v:.3f}' for k, v in ev['bbox'].items()))
+        if 'mAP' in ev:
+            print(f"AP50 (eval_map, area): mAP {ev['mAP']['mAP']:.4f}  per class " +
+                  ' '.join(f'{v:.3f}' for v in ev['mAP']['per_class']))
+        if a.work_dir:
+            import json
+            os.makedirs(a.work_dir, exist_ok=True)
+            with open(os.path.join(a.work_dir, 'eval.json'), 'w') as f:
+                json.dump({k: (v if k == 'bbox' else dict(mAP=v['mAP'], per_class=list(v['per_class'])))
+                           for k, v in ev.items()}, f, indent=1)
 
 
 if __name__ == '__main__':
