@@ -479,10 +479,19 @@ class RPNHead(AnchorHead):
         ids = torch.cat(id_l)[None].expand(n_img, -1)
         M = scores.shape[1]
         img_shape = img_metas[0]['img_shape']
-        assert all(tuple(m['img_shape'][:2]) == tuple(img_shape[:2]) for m in img_metas[:n_img]), \
-            'batched proposal decoding assumes one image shape per batch (true for padded synthetic batches)'
-        props = self.bbox_coder.decode(anchors.reshape(-1, 4), deltas.reshape(-1, 4),
-                                       max_shape=img_shape).view(n_img, M, 4)
+        if all(tuple(m['img_shape'][:2]) == tuple(img_shape[:2]) for m in img_metas[:n_img]):
+            props = self.bbox_coder.decode(anchors.reshape(-1, 4), deltas.reshape(-1, 4),
+                                           max_shape=img_shape).view(n_img, M, 4)
+        else:
+            # per-sample image shapes inside one padded batch (multi-scale Resize, transforms.py:177-243): every image
+            # clips its proposals to ITS img_shape (rpn_head.py:168-171 passes img_meta['img_shape'] per image)
+            props = self.bbox_coder.decode(anchors.reshape(-1, 4), deltas.reshape(-1, 4),
+                                           max_shape=None).view(n_img, M, 4)
+            if getattr(self.bbox_coder, 'clip_border', True):
+                lim = torch.tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas[:n_img]],
+                                   dtype=props.dtype).pin_memory().to(device, non_blocking=True)      # [I, (W, H)]
+                lim = lim.repeat(1, 2)[:, None, :]                                                   # x1 y1 x2 y2 limits
+                props = torch.minimum(props.clamp(min=0), lim)
         valid = torch.ones_like(scores, dtype=torch.bool)
         if cfg.min_bbox_size >= 0:
             w = props[..., 2] - props[..., 0]

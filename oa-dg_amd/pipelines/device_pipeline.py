@@ -96,9 +96,9 @@ class DevicePipeline:
     """Batched device execution of [OAMix,] Normalize, Pad, DefaultFormatBundle, Collect."""
 
     def __init__(self, pipeline_cfg, dtype=torch.float32, one_scale_per_batch=False):
-        """``one_scale_per_batch``: a multi-scale Resize draws its scale once per batch instead of once per sample
-        (deviation from the reference, which pads differently sized samples in collate; the batched device pipeline and
-        the batched proposal decoding need one image shape per batch)."""
+        """``one_scale_per_batch``: a multi-scale Resize draws its scale once per batch instead of once per sample - an
+        opt-in shortcut (one tensor shape per step).  The default follows the reference: one draw per sample
+        (transforms.py:177-243), differently sized samples padded into one batch tensor like mmcv's collate does."""
         self.one_scale_per_batch = one_scale_per_batch
         ts = Compose(pipeline_cfg).transforms
         self.test_aug = next((t for t in ts if isinstance(t, MultiScaleFlipAug)), None)
@@ -206,13 +206,20 @@ class DevicePipeline:
                 imgs.append(im)
                 boxes.append(bx)
                 geo_meta.append(meta)
-            if any(im.shape != imgs[0].shape for im in imgs):
-                raise NotImplementedError('multi-scale Resize produced different image shapes inside one batch; the '
-                                          'batched device pipeline needs one shape per batch (use one img_scale)')
-            imgs_u8, gt_bboxes = torch.stack(imgs), boxes
-        N, H, W = imgs_u8.shape[:3]
-        dev = imgs_u8.device
-        Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
+            imgs_u8 = torch.stack(imgs) if all(im.shape == imgs[0].shape for im in imgs) else imgs
+            gt_bboxes = boxes
+        # per-sample image shapes (the reference's multi-scale Resize draws a scale per SAMPLE, transforms.py:177-243):
+        # every image is padded to its own multiple of size_divisor (Pad, transforms.py:699-701) and the batch tensor
+        # takes the largest padded extent, zero-filled right / bottom - what mmcv's collate does with padded
+        # DataContainers; img_metas carry the per-image img_shape / pad_shape the RPN's valid flags and proposal
+        # clipping read
+        per_image = isinstance(imgs_u8, list)
+        N = len(imgs_u8)
+        shapes = [tuple(int(v) for v in im.shape[:2]) for im in imgs_u8]
+        pads = [self.pad.padded(h, w) if self.pad is not None else (h, w) for h, w in shapes]
+        Hp, Wp = max(p[0] for p in pads), max(p[1] for p in pads)
+        H, W = shapes[0]
+        dev = imgs_u8[0].device
         na = self.norm.as_args()
         mean = (ctypes.c_float * 3)(*na['mean'])
         stdinv = (ctypes.c_float * 3)(*na['stdinv'])
@@ -222,14 +229,15 @@ class DevicePipeline:
         out = dict()
         img = mk()
         for i in range(N):   # physical NHWC slice i is contiguous
-            check(L.oadg_oamix_normalize(ptr(imgs_u8[i]), H, W, mean, stdinv, int(na['to_rgb']),
+            check(L.oadg_oamix_normalize(ptr(imgs_u8[i].contiguous() if per_image else imgs_u8[i]), shapes[i][0],
+                                         shapes[i][1], mean, stdinv, int(na['to_rgb']),
                                          ctypes.c_void_p(img.data_ptr() + i * img.stride(0) * img.element_size()),
                                          dt, Hp, Wp, stream_ptr()), 'oadg_oamix_normalize')
         out['img'] = img
-        shape, pshape = (H, W, 3), (Hp, Wp, 3)
         # the host copies of the gt boxes travel in img_metas: the random-proposal generator and OA-Mix need
         # them on the host, and reading them back from the device would stall the stream
-        out['img_metas'] = [dict(img_shape=shape, pad_shape=pshape, ori_shape=shape, scale_factor=1.0, flip=False,
+        out['img_metas'] = [dict(img_shape=shapes[i] + (3,), pad_shape=pads[i] + (3,) if per_image else (Hp, Wp, 3),
+                                 ori_shape=shapes[i] + (3,), scale_factor=1.0, flip=False,
                                  gt_bboxes_np=np.ascontiguousarray(gt_bboxes[i], dtype=np.float32))
                             for i in range(N)]
         if geo_meta is not None:
@@ -245,7 +253,7 @@ class DevicePipeline:
             # saliency / mask profiles of every image are enqueued first, so the scores of image i are on the
             # host long before its object-aware mixing step needs them
             states = [_ImageState(imgs_u8[i].contiguous(), gt_bboxes[i], om.spatial_ratio, om.sigma_ratio)
-                      for i in range(N)]
+                      for i in range(N)]                  # (each with its own H x W)
             img2 = mk()
             ml, oa = [], []
             for i, st in enumerate(states):

@@ -292,6 +292,8 @@ class OAMix:
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
                      luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
                      gray=torch.empty((1,), dtype=torch.int64, device=dev))
+            while len(self._bufs) >= 3:          # per-sample multi-scale: a new shape per image; keep the latest few
+                self._bufs.pop(next(iter(self._bufs)))
             self._bufs[key] = b
         return b
 

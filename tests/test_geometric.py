@@ -136,3 +136,91 @@ def test_reference_pipeline_list_on_device(dev):
         assert np.array_equal(out['gt_bboxes'][0].cpu().numpy(), b)
         m = out['img_metas'][0]
         assert m['flip'] == flip and m['img_shape'] == (Hn, Wn, 3) and np.array_equal(m['scale_factor'], sf)
+
+
+@pytest.mark.gpu
+def test_per_sample_multiscale_batch_like_the_reference_collate(dev):
+    """The reference's train pipeline draws ONE SCALE PER SAMPLE (Resize._random_scale, transforms.py:177-243); Pad
+    rounds every sample up to a multiple of 32 on its own and mmcv's collate pads the batch to the largest sample.
+    DevicePipeline (default one_scale_per_batch=False) must do the same: per-image img_shape / pad_shape in img_metas,
+    zeros right / below every image; the RPN then ignores anchors outside an image's pad_shape (valid_flags,
+    anchor_head.py:171-199) and clips the proposals to ITS img_shape (rpn_head.py:168-171)."""
+    import os
+    from oadg_amd import Config, build_detector, hip_conv
+    from oadg_amd.apis import TrainEngine, build_optimizer, set_random_seed
+    from oadg_amd.detectors import integrate_data
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    from oadg_amd.pipelines.geometric import Resize
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg_multiscale.py'))
+    pipeline = [dict(t) for t in cfg.data.train.pipeline]
+    ri = next(i for i, t in enumerate(pipeline) if t['type'] == 'Resize')
+    pipeline[ri] = dict(type='Resize', img_scale=[(640, 200), (640, 320)], keep_ratio=True)
+    pipeline = [t for t in pipeline if t['type'] != 'RandomFlip']
+    ds = SyntheticCityscapes(img_shape=(256, 512), num_boxes=6, box_size=(16, 120), device=dev)
+    imgs, boxes, labels = ds.batch([0, 1, 2])
+    # the scales the reference would draw: one per sample, in sample order, from the global numpy stream
+    np.random.seed(5)
+    r = Resize(img_scale=[(640, 200), (640, 320)], keep_ratio=True)
+    scales = [r.draw_scale() for _ in range(3)]
+    assert len(set(scales)) > 1
+    np.random.seed(5)
+    pipe = DevicePipeline([t for t in pipeline if t['type'] != 'OAMix'], dtype=torch.float32)
+    data = pipe(imgs, boxes, labels)
+    metas = data['img_metas']
+    from oadg_amd.pipelines.geometric import rescale_size
+    for m, sc in zip(metas, scales):
+        wn, hn = rescale_size(512, 256, sc)
+        assert tuple(m['img_shape']) == (hn, wn, 3)
+        assert tuple(m['pad_shape']) == (-(-hn // 32) * 32, -(-wn // 32) * 32, 3)
+    Hb, Wb = data['img'].shape[2:]
+    assert (Hb, Wb) == (max(m['pad_shape'][0] for m in metas), max(m['pad_shape'][1] for m in metas))
+    assert len({tuple(m['img_shape']) for m in metas}) > 1, 'the case must mix image sizes'
+    for i, m in enumerate(metas):
+        h, w = m['img_shape'][:2]
+        assert float(data['img'][i, :, h:, :].abs().max() if h < Hb else 0) == 0.0
+        assert float(data['img'][i, :, :, w:].abs().max() if w < Wb else 0) == 0.0
+        assert float(data['img'][i, :, :h, :w].abs().max()) > 0
+        assert float(data['gt_bboxes'][i][:, 2].max()) <= w and float(data['gt_bboxes'][i][:, 3].max()) <= h
+    # the whole OA-DG step on such a batch
+    set_random_seed(0)
+    det = build_detector(cfg.model)
+    det.init_weights(allow_missing_pretrained=True)
+    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    np.random.seed(5)
+    full = DevicePipeline(pipeline, dtype=torch.bfloat16)
+    data = full(imgs, boxes, labels)
+    assert data['img2'].shape == data['img'].shape
+    eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
+    try:
+        out = eng.step(data)
+        assert np.isfinite(float(out['loss'])) and float(out['loss']) > 0
+        # proposals: clipped per image; RPN targets: nothing is sampled outside an image's own padded extent
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            d2 = integrate_data(full(imgs, boxes, labels), det.train_cfg)
+            x = det.extract_feat(d2['img'])
+            props = det.rpn_head.get_bboxes(*det.rpn_head(x), img_metas=d2['img_metas'], cfg=det.train_cfg.rpn_proposal)
+        for p, m in zip(props, d2['img_metas']):
+            h, w = m['img_shape'][:2]
+            assert len(p) > 0 and float(p[:, 2].max()) <= w and float(p[:, 3].max()) <= h and float(p[:, :4].min()) >= 0
+        # (the targets stored on the head belong to the LAST loss call = eng.step(data); integrate_data extended
+        #  data['img_metas'] in place to both views)
+        lw_l = det.rpn_head.rpn_targets[1]
+        stride0 = det.rpn_head.prior_generator.strides[0][0]
+        Hs, Ws = data['img'].shape[2:]
+        fh, fw = -(-Hs // stride0), -(-Ws // stride0)
+        assert len(data['img_metas']) == 2 * len(metas)
+        lw = lw_l[0].reshape(2 * len(metas), fh, fw, -1)
+        assert float(lw.abs().max()) > 0
+        mixed = 0
+        for i, m in enumerate(data['img_metas']):
+            vh, vw = -(-m['pad_shape'][0] // stride0), -(-m['pad_shape'][1] // stride0)
+            if vh < fh:
+                mixed += 1
+                assert float(lw[i, vh:].abs().max()) == 0.0
+            if vw < fw:
+                mixed += 1
+                assert float(lw[i, :, vw:].abs().max()) == 0.0
+        assert mixed > 0
+    finally:
+        hip_conv.enable(False)

@@ -53,6 +53,8 @@ def parse_args():
     p.add_argument('--debug_mode', action='store_true')
     p.add_argument('--max-iters', type=int, default=None, help='stop after this many iterations (smoke runs)')
     p.add_argument('--amp', default='bf16', choices=['bf16', 'none'])
+    p.add_argument('--one-scale-per-batch', action='store_true',
+                   help='multi-scale Resize: draw ONE scale per batch instead of the reference\'s one per sample')
     p.add_argument('--allow-missing-pretrained', action='store_true',
                    help='train from random weights (with a warning) when a configured pretrained / load_from '
                         'checkpoint is not available locally, instead of stopping')
@@ -138,7 +140,7 @@ def main():
     dcfg = cfg.data.train
     while 'dataset' in dcfg and dcfg.get('type') in ('RepeatDataset',):
         dcfg = dcfg.dataset
-    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32, one_scale_per_batch=True)
+    pipe = DevicePipeline(dcfg.pipeline, dtype=amp or torch.float32, one_scale_per_batch=a.one_scale_per_batch)
     bs = cfg.data.get('samples_per_gpu', 2)
     epochs = cfg.get('runner', dict(max_epochs=1)).get('max_epochs', 1)
     from oadg_amd.samplers import batches, build_sampler
