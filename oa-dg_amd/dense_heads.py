@@ -286,13 +286,8 @@ class AnchorHead(nn.Module):
         proposal_list = None
         if proposal_cfg is not None:
             with _rf('sec:rpn_get_bboxes'):
-                proposal_list = None
-                if padded_proposals and PROPOSAL_GRAPH and outs[0][0].is_cuda:
-                    proposal_list = self._proposals_from_graph(outs[0], outs[1], img_metas, proposal_cfg,
-                                                               num_proposal_imgs)
-                if proposal_list is None:
-                    proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
-                                                    num_imgs=num_proposal_imgs, padded=padded_proposals)
+                proposal_list = self.get_bboxes(*outs, img_metas=img_metas, cfg=proposal_cfg,
+                                                num_imgs=num_proposal_imgs, padded=padded_proposals)
         if after_proposals is not None:
             after_proposals(proposal_list)      # e.g. the RoI head's assignment + asynchronous count read
         with _rf('sec:rpn_loss'):
@@ -300,12 +295,6 @@ class AnchorHead(nn.Module):
         if proposal_cfg is None:
             return losses
         return losses, proposal_list
-
-
-# EXPERIMENTAL, off by default: replay the padded proposal generation from a hipGraph.  In isolation the replay equals
-# the eager path (tests/test_proposal_graph.py); inside the full step, beside the data-pipeline thread, it faulted
-# (HSA memory aperture violation) - not yet understood, so the eager path stays the default.
-PROPOSAL_GRAPH = os.environ.get('OADG_PROPOSAL_GRAPH', '0') == '1'
 
 
 class _SplitHeads(torch.autograd.Function):
@@ -396,45 +385,6 @@ class RPNHead(AnchorHead):
         losses = super().loss(cls_scores, bbox_preds, gt_bboxes, None, img_metas,
                               gt_bboxes_ignore=gt_bboxes_ignore)
         return dict(loss_rpn_cls=losses['loss_cls'], loss_rpn_bbox=losses['loss_bbox'])
-
-    def _proposals_from_graph(self, cls_scores, bbox_preds, img_metas, cfg, num_imgs):
-        """Padded proposal generation (sort / top-k / decode / NMS: ~190 small launches, no host read, static shapes)
-        replayed from a hipGraph: captured once per (map shapes, image shape, config), inputs copied into the graph's
-        static buffers, outputs are the graph's static tensors (valid until the next replay; the RoI head concatenates
-        them into its own tensors in the same step).  Returns None - eager path - if capture is not possible."""
-        n = cls_scores[0].shape[0] if num_imgs is None else min(num_imgs, cls_scores[0].shape[0])
-        key = (tuple(tuple(c.shape[1:]) for c in cls_scores), tuple(tuple(b.shape[1:]) for b in bbox_preds), n,
-               cls_scores[0].dtype, tuple(img_metas[0]['img_shape'][:2]), repr(sorted(dict(cfg).items())))
-        cache = self.__dict__.setdefault('_prop_graphs', {})
-        entry = cache.get(key)
-        if entry is None:
-            try:
-                sc = [torch.empty_like(c[:n]) for c in cls_scores]
-                bp = [torch.empty_like(b[:n]) for b in bbox_preds]
-                metas = [dict(img_shape=tuple(m['img_shape'])) for m in img_metas[:n]]
-                for d, c in zip(sc + bp, list(cls_scores) + list(bbox_preds)):
-                    d.copy_(c[:n])
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):          # warm-up outside the capture (anchor caches, workspaces)
-                    self.get_bboxes(sc, bp, img_metas=metas, cfg=cfg, num_imgs=n, padded=True)
-                torch.cuda.current_stream().wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                # thread_local: the data-pipeline worker thread keeps launching / allocating on its own stream meanwhile
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    out = self.get_bboxes(sc, bp, img_metas=metas, cfg=cfg, num_imgs=n, padded=True)
-                entry = cache[key] = (graph, sc, bp, out)
-            except Exception as e:      # capture unsupported for some op on this stack: stay eager for this key
-                import warnings
-                warnings.warn(f'proposal graph capture failed, staying eager: {e}')
-                entry = cache[key] = False
-        if entry is False:
-            return None
-        graph, sc, bp, out = entry
-        for d, c in zip(sc + bp, list(cls_scores) + list(bbox_preds)):
-            d.copy_(c[:n])
-        graph.replay()
-        return out
 
     def simple_test_rpn(self, x, img_metas):
         """dense_test_mixins.py:118-133"""
