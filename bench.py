@@ -220,6 +220,9 @@ def main():
     hip_ops.TIMERS = {'roi_align_bwd': []}
     if a.conv == 'mfma' and amp is not None:
         hip_conv.TIMERS = []
+        # HIP events around every launch of the dominant kernel family only (the 256-tile kernels); the per-family
+        # table of all convolution launches costs ~250 event records per step: OADG_BENCH_DIAG_CONV=1 turns it on
+        hip_conv.TIMERS_ONLY_VARIANT = None if os.environ.get('OADG_BENCH_DIAG_CONV') == '1' else 2
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()

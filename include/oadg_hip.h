@@ -154,10 +154,10 @@ int oadg_oamix_bbox_step(uint8_t* img, int H, int W, const double* minv_host, in
                          const float* My_row, const float* Mx_row, uint8_t* scratch, void* stream);
 /* bboxes_only_* for ALL gt boxes of an image in a handful of launches (bbox_augmentation.py:74-88 applies the boxes
  * one after the other; only boxes whose written rect meets another's read footprint are ordered).  steps_dev: the
- * boxes' steps sorted by dependency level; tile_prefix_*[i] = number of 256-pixel tiles before step i (n + 1 entries,
+ * boxes' steps sorted by dependency level; tile_prefix_*[i] = number of 1024-pixel tiles before step i (n + 1 entries,
  * device and host copies); level_first_host[l] .. level_first_host[l + 1] = steps of level l.  Two launches per
  * level (blend into scratch, copy back); rect = x0, y0, width, height; scratch_off = byte offset of the step's rect
- * inside `scratch` (rects of one level are disjoint, so H*W*3 bytes suffice). */
+ * inside `scratch`, a multiple of 4 (rects of one level are disjoint, so H*W*3 + 4*n + 16 bytes suffice). */
 typedef struct {
     double minv[6];        /* inverted affine (cv2.warpAffine) */
     int rect[4];

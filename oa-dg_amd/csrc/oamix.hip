@@ -307,6 +307,34 @@ __device__ __forceinline__ int find_step(const int* __restrict__ tile_prefix, in
     return lo;
 }
 
+// 8 source bytes = the two horizontally adjacent taps (3 + 3 bytes) of one source row in ONE unaligned 8-byte load
+__device__ __forceinline__ void tap_row(const uint8_t* __restrict__ img, long pix, int v0[3], int v1[3]) {
+    uint2 r;
+    __builtin_memcpy(&r, img + pix * 3, 8);
+    v0[0] = r.x & 255; v0[1] = (r.x >> 8) & 255; v0[2] = (r.x >> 16) & 255;
+    v1[0] = r.x >> 24; v1[1] = r.y & 255; v1[2] = (r.y >> 8) & 255;
+}
+
+// warped pixel (OpenCV remapBilinear, BORDER_CONSTANT 0) at 1/32-px coordinates (X, Y): the interior case reads its
+// four taps with two 8-byte loads, the border cases go through tap_fetch; identical integer arithmetic
+__device__ __forceinline__ void warp_pixel(const uint8_t* __restrict__ img, int H, int W, long X, long Y, int out[3]) {
+    const long sx = X >> 5, sy = Y >> 5;
+    if (sx >= 0 && sx + 2 < W && sy >= 0 && sy + 1 < H) {
+        const int fx = (int)(X & 31), fy = (int)(Y & 31);
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        int a0[3], a1[3], b0[3], b1[3];
+        tap_row(img, sy * W + sx, a0, a1);
+        tap_row(img, (sy + 1) * W + sx, b0, b1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = (a0[c] * w00 + a1[c] * w01 + b0[c] * w10 + b1[c] * w11 + (1 << 14)) >> 15;
+    } else {
+        const Tap t = make_tap(X, Y, H, W);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = tap_fetch(t, img, 3, c);
+    }
+}
+
+// one thread = 4 consecutive pixels of a rect (row-major inside the rect): 12 result bytes as three aligned dwords
 __global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __restrict__ img, int H, int W,
                                                                const oadg_bbox_step* __restrict__ steps,
                                                                const int* __restrict__ tile_prefix, int first,
@@ -318,39 +346,51 @@ __global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __
     const int s = find_step(tile_prefix, first, count, tile);
     const oadg_bbox_step st = steps[s];
     const int rw = st.rect[2], rh = st.rect[3];
-    const int i = (tile - tile_prefix[s]) * 256 + threadIdx.x;
-    if (i >= rw * rh) return;
-    const int yy = i / rw, xx = i - yy * rw;
-    const int x = st.rect[0] + xx, y = st.rect[1] + yy;
+    const int i0 = ((tile - tile_prefix[s]) * 256 + threadIdx.x) * 4;
+    if (i0 >= rw * rh) return;
     Warp wp;
 #pragma unroll
     for (int k = 0; k < 6; ++k) wp.m[k] = st.minv[k];
-    long X, Y;
-    warp_xy(wp, x, y, X, Y);
-    const Tap t = make_tap(X, Y, H, W);
-    const float b = My[(size_t)st.row * H + y] * Mx[(size_t)st.row * W + x];
-    const float m = 1.0f - b;
-    const float om = 1.0f - m;
-    const size_t p = ((size_t)y * W + x) * 3;
-    uint8_t* out = scratch + st.scratch_off + (size_t)i * 3;
+    const float* my = My + (size_t)st.row * H;
+    const float* mx = Mx + (size_t)st.row * W;
+    unsigned pk[3] = {0u, 0u, 0u};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float wv = (float)tap_fetch(t, img, 3, c);
-        const float v = (float)img[p + c] * m + wv * om;
-        out[c] = (uint8_t)v;
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        if (i >= rw * rh) break;
+        const int yy = i / rw, xx = i - yy * rw;
+        const int x = st.rect[0] + xx, y = st.rect[1] + yy;
+        long X, Y;
+        warp_xy(wp, x, y, X, Y);
+        int wv[3];
+        warp_pixel(img, H, W, X, Y, wv);
+        const float b = my[y] * mx[x];
+        const float m = 1.0f - b;
+        const float om = 1.0f - m;
+        const size_t p = ((size_t)y * W + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)img[p + c] * m + (float)wv[c] * om;
+            const unsigned byte = (unsigned)(uint8_t)v;
+            const int bi = u * 3 + c;
+            pk[bi >> 2] |= byte << ((bi & 3) * 8);
+        }
     }
+    unsigned* out = reinterpret_cast<unsigned*>(scratch + st.scratch_off + (size_t)i0 * 3);   // scratch_off % 4 == 0
+    out[0] = pk[0]; out[1] = pk[1]; out[2] = pk[2];
 }
 
+// one thread = one pixel (four workgroups per 1024-pixel tile of the blend kernel)
 __global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restrict__ img, int W,
                                                               const oadg_bbox_step* __restrict__ steps,
                                                               const int* __restrict__ tile_prefix, int first,
                                                               int count, int tile_base,
                                                               const uint8_t* __restrict__ scratch) {
-    const int tile = tile_base + blockIdx.x;
+    const int tile = tile_base + (blockIdx.x >> 2);
     const int s = find_step(tile_prefix, first, count, tile);
     const oadg_bbox_step st = steps[s];
     const int rw = st.rect[2], rh = st.rect[3];
-    const int i = (tile - tile_prefix[s]) * 256 + threadIdx.x;
+    const int i = (tile - tile_prefix[s]) * 1024 + (blockIdx.x & 3) * 256 + threadIdx.x;
     if (i >= rw * rh) return;
     const int yy = i / rw, xx = i - yy * rw;
     const size_t p = ((size_t)(st.rect[1] + yy) * W + st.rect[0] + xx) * 3;
@@ -584,35 +624,37 @@ __global__ __launch_bounds__(256) void normalize_kernel(const uint8_t* __restric
 // mean of uint8(map * 255).  All of it in LDS (64x64 complex fp64 = 64 KiB).
 constexpr int SN = 64;
 
-__device__ void fft64_rows_or_cols(double* re, double* im, bool cols, bool inverse) {
-    // 64 independent 64-point radix-2 DIT FFTs; thread t < 64 owns line t (stride 1 or 64)
-    const int t = threadIdx.x;
-    if (t < SN) {
-        const int stride = cols ? SN : 1, base = cols ? t : t * SN;
-        // bit reversal
-        for (int i = 0; i < SN; ++i) {
-            int j = 0;
-            for (int b = 0; b < 6; ++b) j |= ((i >> b) & 1) << (5 - b);
-            if (j > i) {
-                double a = re[base + i * stride]; re[base + i * stride] = re[base + j * stride]; re[base + j * stride] = a;
-                a = im[base + i * stride]; im[base + i * stride] = im[base + j * stride]; im[base + j * stride] = a;
-            }
-        }
-        for (int len = 2; len <= SN; len <<= 1) {
-            const double ang = (inverse ? 2.0 : -2.0) * 3.14159265358979323846 / (double)len;
-            for (int s = 0; s < SN; s += len) {
-                for (int k = 0; k < len / 2; ++k) {
-                    double wr, wi;
-                    sincos(ang * (double)k, &wi, &wr);
-                    const int i0 = base + (s + k) * stride, i1 = base + (s + k + len / 2) * stride;
-                    const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
-                    re[i1] = re[i0] - xr; im[i1] = im[i0] - xi;
-                    re[i0] = re[i0] + xr; im[i0] = im[i0] + xi;
-                }
-            }
+constexpr int SLD = SN + 1;     // row stride of the 64 x 64 complex image in LDS (doubles): odd, so a lane-per-row access
+                                // pattern (address = lane * 65 + i) spreads over all banks like lane-per-column does
+
+// 64 independent 64-point radix-2 DIT FFTs (rows: cols = false, or columns) by all 256 threads: four threads per line,
+// 8 butterflies each per stage, twiddles exp(-+ 2 pi i k / 64) from a table (tw_re / tw_im, k < 32, forward sign).
+__device__ void fft64_lines(double* re, double* im, const double* tw_re, const double* tw_im, bool cols, bool inverse) {
+    const int line = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int base = cols ? line : line * SLD, stride = cols ? SLD : 1;
+    for (int u = 0; u < 16; ++u) {                       // bit reversal: the owner of the smaller index swaps the pair
+        const int i = part * 16 + u;
+        int j = 0;
+        for (int bb = 0; bb < 6; ++bb) j |= ((i >> bb) & 1) << (5 - bb);
+        if (j > i) {
+            double t = re[base + i * stride]; re[base + i * stride] = re[base + j * stride]; re[base + j * stride] = t;
+            t = im[base + i * stride]; im[base + i * stride] = im[base + j * stride]; im[base + j * stride] = t;
         }
     }
     __syncthreads();
+    for (int len = 2; len <= SN; len <<= 1) {
+        const int half = len >> 1, tstep = SN / len;
+        for (int u = 0; u < 8; ++u) {
+            const int bfly = part * 8 + u;
+            const int k = bfly & (half - 1), s0 = (bfly / half) * len;
+            const double wr = tw_re[k * tstep], wi = inverse ? -tw_im[k * tstep] : tw_im[k * tstep];
+            const int i0 = base + (s0 + k) * stride, i1 = base + (s0 + k + half) * stride;
+            const double xr = re[i1] * wr - im[i1] * wi, xi = re[i1] * wi + im[i1] * wr;
+            re[i1] = re[i0] - xr; im[i1] = im[i0] - xi;
+            re[i0] = re[i0] + xr; im[i0] = im[i0] + xi;
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ void lin_axis(int d, int n_src, int n_dst, int& s0, int& s1, double& f) {
@@ -629,14 +671,20 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
                                                        const int* __restrict__ boxes, int min_side,
                                                        float* __restrict__ sal_maps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* re = reinterpret_cast<double*>(smem);            // [64*64]
-    double* im = re + SN * SN;                                // [64*64]
+    double* re = reinterpret_cast<double*>(smem);            // [64][65]
+    double* im = re + SN * SLD;                               // [64][65]
     __shared__ double red[16];
     __shared__ double s_max;
+    __shared__ double tw_re[32], tw_im[32];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int x1 = boxes[4 * b], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
     const int w = x2 - x1, h = y2 - y1;
     if (w < min_side || h < min_side) return;      // score -1 (saliency_mean_kernel)
+    if (tid < 32) {
+        double sn, cs;
+        sincos(-2.0 * 3.14159265358979323846 * (double)tid / 64.0, &sn, &cs);
+        tw_re[tid] = cs; tw_im[tid] = sn;
+    }
     // gray (cv::cvtColor BGR2GRAY fixed point) + bilinear to 64x64, rounded to uint8
     for (int i = tid; i < SN * SN; i += 256) {
         const int dy = i / SN, dx = i - dy * SN;
@@ -651,17 +699,18 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
         const double bot = gray(yb, xa) * (1.0 - fx) + gray(yb, xb) * fx;
         double v = floor(top * (1.0 - fy) + bot * fy + 0.5);
         v = fmin(fmax(v, 0.0), 255.0);
-        re[i] = v; im[i] = 0.0;
+        re[dy * SLD + dx] = v; im[dy * SLD + dx] = 0.0;
     }
     __syncthreads();
-    fft64_rows_or_cols(re, im, false, false);
-    fft64_rows_or_cols(re, im, true, false);
+    fft64_lines(re, im, tw_re, tw_im, false, false);
+    fft64_lines(re, im, tw_re, tw_im, true, false);
     // log amplitude in `sal`-free storage: keep angle in im, log-magnitude in re
     for (int i = tid; i < SN * SN; i += 256) {
-        const double mag = hypot(re[i], im[i]);
-        const double ang = atan2(im[i], re[i]);
-        re[i] = log(mag);
-        im[i] = ang;
+        const int p = (i >> 6) * SLD + (i & 63);
+        const double mag = hypot(re[p], im[p]);
+        const double ang = atan2(im[p], re[p]);
+        re[p] = log(mag);
+        im[p] = ang;
     }
     __syncthreads();
     // residual = exp(L - boxblur3(L)) ; needs L intact while reading neighbours -> stage result in registers
@@ -671,21 +720,25 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
         const int y = i / SN, x = i - y * SN;
         double s = 0.0;
         for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) s += re[reflect101(y + dy, SN) * SN + reflect101(x + dx, SN)];
-        resid[k] = exp(re[i] - s / 9.0);
+            for (int dx = -1; dx <= 1; ++dx) s += re[reflect101(y + dy, SN) * SLD + reflect101(x + dx, SN)];
+        resid[k] = exp(re[y * SLD + x] - s / 9.0);
     }
     __syncthreads();
     for (int k = 0; k < 16; ++k) {
         const int i = tid + k * 256;
+        const int p = (i >> 6) * SLD + (i & 63);
         double sn, cs;
-        sincos(im[i], &sn, &cs);
-        re[i] = resid[k] * cs;
-        im[i] = resid[k] * sn;
+        sincos(im[p], &sn, &cs);
+        re[p] = resid[k] * cs;
+        im[p] = resid[k] * sn;
     }
     __syncthreads();
-    fft64_rows_or_cols(re, im, false, true);
-    fft64_rows_or_cols(re, im, true, true);
-    for (int i = tid; i < SN * SN; i += 256) re[i] = hypot(re[i], im[i]);
+    fft64_lines(re, im, tw_re, tw_im, false, true);
+    fft64_lines(re, im, tw_re, tw_im, true, true);
+    for (int i = tid; i < SN * SN; i += 256) {
+        const int p = (i >> 6) * SLD + (i & 63);
+        re[p] = hypot(re[p], im[p]);
+    }
     __syncthreads();
     // 5x5 Gaussian sigma 8 (separable, reflect101): horizontal into im, vertical back into re
     double g[5];
@@ -697,17 +750,17 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     for (int i = tid; i < SN * SN; i += 256) {
         const int y = i / SN, x = i - y * SN;
         double s = 0.0;
-        for (int k = 0; k < 5; ++k) s += g[k] * re[y * SN + reflect101(x + k - 2, SN)];
-        im[i] = s;
+        for (int k = 0; k < 5; ++k) s += g[k] * re[y * SLD + reflect101(x + k - 2, SN)];
+        im[y * SLD + x] = s;
     }
     __syncthreads();
     double lmax = 0.0;
     for (int i = tid; i < SN * SN; i += 256) {
         const int y = i / SN, x = i - y * SN;
         double s = 0.0;
-        for (int k = 0; k < 5; ++k) s += g[k] * im[reflect101(y + k - 2, SN) * SN + x];
+        for (int k = 0; k < 5; ++k) s += g[k] * im[reflect101(y + k - 2, SN) * SLD + x];
         s = s * s;
-        re[i] = s;
+        re[y * SLD + x] = s;
         lmax = fmax(lmax, s);
     }
     for (int o = 32; o > 0; o >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, o, 64));
@@ -718,7 +771,7 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     __syncthreads();
     // the 64x64 saliency map leaves the workgroup here: the resize to w x h and the mean run on many workgroups per box
     float* sal_out = sal_maps + (size_t)b * SN * SN;
-    for (int i = tid; i < SN * SN; i += 256) sal_out[i] = (float)(re[i] / s_max);
+    for (int i = tid; i < SN * SN; i += 256) sal_out[i] = (float)(re[(i >> 6) * SLD + (i & 63)] / s_max);
 }
 
 // bilinear (float32, horizontal then vertical) of the 64x64 map to w x h; total of uint8(v * 255) per box.  The
@@ -815,7 +868,7 @@ int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int 
     hipStream_t st = (hipStream_t)stream;
     unsigned long long* totals = (unsigned long long*)workspace;          // [n], then the [n][64*64] float maps
     float* maps = (float*)(totals + n);
-    const size_t lds = (size_t)SN * SN * (8 + 8);
+    const size_t lds = (size_t)SN * SLD * (8 + 8);
     static bool attr_set = false;   // > 64 KiB of dynamic LDS must be opted into once (idempotent)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)saliency_kernel,
@@ -904,7 +957,7 @@ int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* step
         hipLaunchKernelGGL(bbox_blend_multi_kernel, dim3(tiles), dim3(256), 0, st, (const uint8_t*)img, H, W,
                            steps_dev, tile_prefix_dev, first, count, tile_base, My, Mx, scratch);
         OADG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles), dim3(256), 0, st, img, W, steps_dev,
+        hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles * 4), dim3(256), 0, st, img, W, steps_dev,
                            tile_prefix_dev, first, count, tile_base, (const uint8_t*)scratch);
         OADG_LAUNCH_CHECK();
     }

@@ -287,7 +287,8 @@ class OAMix:
         if b is None:
             dev, H, W = st.img.device, st.H, st.W
             u8 = lambda: torch.empty((H, W, 3), dtype=torch.uint8, device=dev)  # noqa: E731
-            b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()], scratch=u8(),
+            b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()],
+                     scratch=torch.empty((H * W * 3 + 4 * 8192 + 64,), dtype=torch.uint8, device=dev),
                      acc=torch.empty((H, W, 3), dtype=torch.float32, device=dev),
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
                      luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
@@ -498,10 +499,11 @@ class OAMix:
             self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n
         first = np.searchsorted(lv, np.arange(n_levels + 1)).astype(np.int32)
         # the rects of one level are disjoint, so their packed scratch images fit the H*W*3 scratch buffer
-        cum = np.cumsum(area) - area
-        steps['scratch_off'] = 3 * (cum - cum[first[:-1]][lv])
+        padded = (3 * area + 3) // 4 * 4                   # every rect starts on a 4-byte boundary of the scratch image
+        cum = np.cumsum(padded) - padded
+        steps['scratch_off'] = cum - cum[first[:-1]][lv]
         tiles = np.zeros((n + 1,), np.int32)
-        tiles[1:] = np.cumsum((area + 255) // 256)
+        tiles[1:] = np.cumsum((area + 1023) // 1024)        # one workgroup = 256 threads x 4 pixels
         dev = st.img.device
         keep = step.setdefault('keepalive', [])              # descriptor tensors live until the step's launches ran
         steps_dev = _upload(steps.view(np.uint8).reshape(-1), dev)
