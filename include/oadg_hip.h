@@ -214,10 +214,15 @@ int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bia
 /* data-gradient form with the producer's epilogue backward fused in: y = (conv(x, w) [+ residual]) * (mask > 0)
  * (mask [N,Ho,Wo,K] bf16 = the ReLU output the gradient flows into; torch threshold_backward) and
  * colsum_part [oadg_conv2d_pixel_tiles][K] = per-pixel-tile column sums of the stored y = partial bias / BN-shift
- * gradients of the producer (sum them with oadg_colsum_reduce).  mask / colsum_part may be NULL. */
+ * gradients of the producer (sum them with oadg_colsum_reduce).  mask / colsum_part may be NULL.
+ * mask_bits (may be NULL, instead of mask): the same ReLU mask as ONE BIT per element - [rows][K / 8] bytes, bit e of
+ * byte j = channel 8 j + e - i.e. 1/16 of the bf16 mask's bytes on these HBM-bound launches;  relu_bits_out (may be
+ * NULL): this launch additionally stores (y > 0) of what it writes in that format (the forward launch of the tensor
+ * whose gradient a later launch masks).  Both need K % 8 == 0. */
 int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual, void* y,
                              const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                             int dil, int relu, int variant, const void* mask, float* colsum_part, void* stream);
+                             int dil, int relu, int variant, const void* mask, float* colsum_part,
+                             const void* mask_bits, void* relu_bits_out, void* stream);
 long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                              int variant);
 int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream);
@@ -246,7 +251,7 @@ int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float*
 int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int pad, int dil,
                                   int relu, int out_h, int out_w, int OH, int OW, int osh, int osw, int oph, int opw,
-                                  const void* mask, float* colsum_part, void* stream);
+                                  const void* mask, float* colsum_part, const void* mask_bits, void* stream);
 
 /* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
  * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with

@@ -42,7 +42,7 @@ SIGNATURES = {
     'oadg_flip_u8': (ci, [vp, ci, ci, ci, vp, ci, vp]),
     'oadg_conv2d_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 11 + [vp]),
     'oadg_conv2d_auto_variant': (ci, [ci] * 10),
-    'oadg_conv2d_nhwc_bf16_ex': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp, vp, vp]),
+    'oadg_conv2d_nhwc_bf16_ex': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp, vp, vp, vp, vp]),
     'oadg_conv2d_pixel_tiles': (cl, [ci] * 11),
     'oadg_colsum_reduce': (ci, [vp, cl, ci, vp, vp]),
     'oadg_conv2d_nhwc_bf16_variant': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp]),
@@ -51,7 +51,7 @@ SIGNATURES = {
     'oadg_conv2d_wgrad_parts_nhwc_bf16': (ci, [vp, vp, vp, vp, cs] + [ci] * 10 + [POINTER(ci), vp]),
     'oadg_prep_conv_weights_bwd_parts': (ci, [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_prep_conv_weights': (ci, [vp, vp, vp, vp, vp, cf, vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
-    'oadg_conv2d_nhwc_bf16_scatter': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 18 + [vp, vp, vp]),
+    'oadg_conv2d_nhwc_bf16_scatter': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 18 + [vp, vp, vp, vp]),
     'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_relu_bias_bwd_workspace_bytes': (ctypes.c_size_t, [cl, ci]),
     'oadg_relu_bias_bwd': (ci, [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, cl, ci, vp]),

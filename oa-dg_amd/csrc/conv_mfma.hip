@@ -30,6 +30,9 @@ struct ConvArgs {
     unsigned short* y;            // [N,Ho,Wo,K] bf16
     const unsigned short* zeros;  // >= 16 bytes of zeros (source of padding / tail rows)
     const unsigned short* mask;   // [N,Ho,Wo,K] bf16 or null: y *= (mask > 0)  (ReLU backward of the tensor y feeds)
+    const unsigned char* bits_in; // the same mask as one BIT per element ([rows][K / 8] bytes, bit e of a byte = channel
+                                  // 8 j + e), written by the producer's forward launch: 1/16 of the bf16 mask's bytes
+    unsigned char* bits_out;      // or null: this launch also stores (y > 0) of what it writes, in that format
     float* colsum;                // [pixel tiles][K] fp32 partial column sums of the stored y, or null
     int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil, relu;
     long M;
@@ -51,7 +54,7 @@ __device__ __forceinline__ long out_row(const ConvArgs& a, long m) {
 // mask, bf16 rounding, and the running column sums of what is stored.
 template <bool POST>
 __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, const bf16x8 rv, const bf16x8 mv,
-                                               float* csum) {
+                                               float* csum, unsigned mbits = 0xffu, size_t off = 0) {
     if (POST) {
         float f[8];
 #pragma unroll
@@ -68,12 +71,23 @@ __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, cons
             for (int e = 0; e < 8; ++e)
                 if (!(bf16_to_f32((unsigned short)mv[e]) > 0.f)) f[e] = 0.f;
         }
+        if (a.bits_in) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (!((mbits >> e) & 1u)) f[e] = 0.f;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16(f[e]);
     }
     if (a.colsum) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += bf16_to_f32((unsigned short)v[e]);
+    }
+    if (a.bits_out) {
+        unsigned b = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b |= (bf16_to_f32((unsigned short)v[e]) > 0.f ? 1u : 0u) << e;
+        a.bits_out[off >> 3] = (unsigned char)b;
     }
     return v;
 }
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
     constexpr int SPR = TBN / 8;                       // 16-byte slots per tile row
     constexpr int NPIECE = (BM * TBN / 8) / 256;
     bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
+    unsigned mb[POST ? NPIECE : 1];
     if (POST) {
 #pragma unroll
         for (int it = 0; it < NPIECE; ++it) {
@@ -244,9 +259,11 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
             const size_t off = (size_t)out_row(a, m < a.M ? m : 0) * a.K + k0 + (q % SPR) * 8;
             rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mb[it] = (a.bits_in && m < a.M) ? a.bits_in[off >> 3] : 0xffu;
         }
     } else {
         rv[0] = mv[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        mb[0] = 0xffu;
     }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -258,7 +275,8 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
         const size_t off = (size_t)out_row(a, m) * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum,
+                                                                   mb[POST ? it : 0], off);
     }
     if (a.colsum) {       // 256 / SPR threads share a channel slot: combine through the idle second LDS stage
         float* red = reinterpret_cast<float*>(smem + TSTAGE);           // [256 / SPR][TBN] (8 KiB behind stage 0)
@@ -525,6 +543,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     // 128 accumulator registers are dead once the C image is written
     constexpr int NPIECE = (TM * TN / 8) / 512;
     bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
+    unsigned mb[POST ? NPIECE : 1];
     if (POST) {
 #pragma unroll
         for (int it = 0; it < NPIECE; ++it) {
@@ -533,9 +552,11 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
             const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
             rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mb[it] = (a.bits_in && m < a.M) ? a.bits_in[off >> 3] : 0xffu;
         }
     } else {
         rv[0] = mv[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        mb[0] = 0xffu;
     }
     __syncthreads();
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -547,7 +568,8 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
-        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum);
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum,
+                                                                   mb[POST ? it : 0], off);
     }
     if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
         float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
@@ -580,7 +602,8 @@ int auto_variant(long M, int H, int W, int C, int K, int nchunks) {
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
-                void* stream, const void* mask = nullptr, float* colsum_part = nullptr, const int* sc = nullptr) {
+                void* stream, const void* mask = nullptr, float* colsum_part = nullptr, const int* sc = nullptr,
+                const void* bits_in = nullptr, void* bits_out = nullptr) {
     // sc (optional, 8 ints): out_h, out_w = output extent of this launch; OH, OW, osh, osw, oph, opw = scatter map
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
@@ -590,6 +613,8 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
     a.mask = (const unsigned short*)mask; a.colsum = colsum_part;
+    a.bits_in = (const unsigned char*)bits_in; a.bits_out = (unsigned char*)bits_out;
+    if ((bits_in || bits_out) && K % 8 != 0) return OADG_EARG;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
     a.relu = relu;
     a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
@@ -604,7 +629,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     }
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
-    const bool post = residual != nullptr || mask != nullptr;
+    const bool post = residual != nullptr || mask != nullptr || bits_in != nullptr;
     if (variant == 0) variant = auto_variant(a.M, H, W, C, K, R * S * (C / BK));
     if (variant == 2 && ((long)H * W * C >= (1L << 31) || a.M >= (1L << 31))) variant = 1;
     if (variant == 2) {
@@ -672,9 +697,9 @@ extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R
 extern "C" int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual,
                                         void* y, const void* zeros16, int N, int H, int W, int C, int K, int R, int S,
                                         int stride, int pad, int dil, int relu, int variant, const void* mask,
-                                        float* colsum_part, void* stream) {
+                                        float* colsum_part, const void* mask_bits, void* relu_bits_out, void* stream) {
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, variant, stream,
-                       mask, colsum_part);
+                       mask, colsum_part, nullptr, mask_bits, relu_bits_out);
 }
 
 // One parity class of a strided data gradient (or any stride-1 convolution whose output pixels are written on a
@@ -685,10 +710,10 @@ extern "C" int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const
                                              void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
                                              int S, int pad, int dil, int relu, int out_h, int out_w, int OH, int OW,
                                              int osh, int osw, int oph, int opw, const void* mask,
-                                             float* colsum_part, void* stream) {
+                                             float* colsum_part, const void* mask_bits, void* stream) {
     const int sc[8] = {out_h, out_w, OH, OW, osh, osw, oph, opw};
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, 1, pad, dil, relu, 3, stream, mask,
-                       colsum_part, sc);
+                       colsum_part, sc, mask_bits, nullptr);
 }
 
 // rows of the colsum_part buffer for a problem / variant (0 = automatic)

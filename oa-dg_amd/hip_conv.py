@@ -34,10 +34,13 @@ def supported(x, weight, stride, padding, dilation):
             padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
 
 
-def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False):
+def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False, mask_bits=None,
+                 bits_out=None):
     """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last.
     ``mask`` (same shape as y): y *= (mask > 0); ``want_colsum``: also return sum of the stored y over (N,H,W)
-    (fp32 [K], deterministic) - the two together are the backward of a producer's bias + ReLU epilogue."""
+    (fp32 [K], deterministic) - the two together are the backward of a producer's bias + ReLU epilogue.
+    ``mask_bits`` (uint8 [rows * K / 8]): the same mask, one bit per element (1/16 of the bytes); ``bits_out``: a uint8
+    tensor of that size which receives (y > 0) - what a later data-gradient launch passes as ``mask_bits``."""
     L = _lib.lib()
     N, C, H, W = x.shape
     K, _, R, S = w.shape
@@ -56,17 +59,18 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         part = torch.empty((rows, K), dtype=torch.float32, device=x.device)
     check(L.oadg_conv2d_nhwc_bf16_ex(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N,
                                      H, W, C, K, R, S, stride, pad, dil, int(bool(relu)), int(variant), ptr(mask),
-                                     ptr(part), stream_ptr()),
+                                     ptr(part), ptr(mask_bits), ptr(bits_out), stream_ptr()),
           'oadg_conv2d_nhwc_bf16')
     if timed:
         e1.record()
         v = variant or L.oadg_conv2d_auto_variant(N, H, W, C, K, R, S, stride, pad, dil)
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
                        2.0 * (N * H * W * C + K * C * R * S +
-                              N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None))),
+                              N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None)) +
+                              N * Ho * Wo * K / 16.0 * ((mask_bits is not None) + (bits_out is not None))),
                        ('conv_igemm256_kernel<%s>' if v == 2 else
                         ('conv_igemm_kernel<%d, %%s, %d>' % (128 if K % 128 == 0 else 64, 1 if v == 3 else 2)))
-                       % ('true' if (residual is not None or mask is not None) else 'false'),
+                       % ('true' if (residual is not None or mask is not None or mask_bits is not None) else 'false'),
                        (N, H, W, C, K, R, stride, residual is not None, mask is not None)))
     if want_colsum:
         cs = torch.empty((K,), dtype=torch.float32, device=x.device)
@@ -78,7 +82,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
 _S2_CLASSES = ((0, 0, 1, 1, 0), (0, 1, 1, 2, 1), (1, 0, 2, 1, 3), (1, 1, 2, 2, 5))    # ph, pw, taps_h, taps_w, block offset
 
 
-def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False):
+def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=None):
     """dx of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0) as one stride-1 convolution over dy per output parity
     class, each written on its strided grid of dx (csrc oadg_conv2d_nhwc_bf16_scatter; ``wt`` = the class filters from
     ``_PrepWeights`` mode 2).  ``mask``: ReLU-backward mask (the convolution's input), ``want_colsum``: also return the
@@ -102,7 +106,7 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False):
         pptr = ctypes.c_void_p(part.data_ptr() + row * C * 4) if part is not None else None
         check(L.oadg_conv2d_nhwc_bf16_scatter(ptr(gy), wptr, None, None, ptr(gx), ptr(_zeros(gy.device)), N, Ho, Wo, K, C,
                                               th, tw, 0, 1, 0, ha, wa, H, W, 2, 2, ph, pw, ptr(mask), pptr,
-                                              stream_ptr()), 'oadg_conv2d_nhwc_bf16_scatter')
+                                              ptr(mask_bits), stream_ptr()), 'oadg_conv2d_nhwc_bf16_scatter')
         row += tiles
     if want_colsum:
         cs = torch.empty((C,), dtype=torch.float32, device=gy.device)
@@ -315,10 +319,19 @@ class GradToken:
     the ReLU mask (t > 0) and reduces the bias gradient in its epilogue, so P neither masks nor reduces again.
     ``grad_ptr`` identifies the tensor C returned: if autograd delivers anything else to P (an unexpected extra
     consumer), P falls back to masking itself - masking twice is harmless, skipping it would not be."""
-    __slots__ = ('extra', 'colsum', 'grad_ptr')
+    __slots__ = ('extra', 'colsum', 'grad_ptr', 'bits')
 
     def __init__(self):
-        self.extra = self.colsum = self.grad_ptr = None
+        self.extra = self.colsum = self.grad_ptr = self.bits = None
+
+
+RELU_BITS = os.environ.get('OADG_RELU_BITS', '1') == '1'
+
+
+def y_numel(x, w, stride, pad, dil):
+    N, _, H, W = x.shape
+    K, _, R, S = w.shape
+    return N * K * ((H + 2 * pad - dil * (R - 1) - 1) // stride + 1) * ((W + 2 * pad - dil * (S - 1) - 1) // stride + 1)
 
 
 class _Conv2dMFMA(torch.autograd.Function):
@@ -331,7 +344,13 @@ class _Conv2dMFMA(torch.autograd.Function):
     def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu, in_token, out_token, res_token):
         x16 = _nhwc_bf16(x)
         r16 = _nhwc_bf16(residual) if residual is not None else None
-        y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu)
+        bits = None
+        if relu and out_token is not None and RELU_BITS and wf.shape[0] % 8 == 0:
+            # (y > 0) as one bit per element beside y: the consumer's data-gradient launch reads these instead of the
+            # bf16 tensor for its ReLU-backward mask (1/16 of the bytes of an HBM-bound launch)
+            bits = out_token.bits = torch.empty((y_numel(x16, wf, stride, pad, dil) // 8,), dtype=torch.uint8,
+                                                device=x16.device)
+        y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu, bits_out=bits)
         ctx.save_for_backward(x16, wf, wt, y if relu else None)
         ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, residual.dtype if residual is not None else None)
         ctx.tokens = (in_token, out_token, res_token)
@@ -370,7 +389,9 @@ class _Conv2dMFMA(torch.autograd.Function):
         if need_x and wt is not None and stride == 2:
             # dx of the stride-2 layers (Bottleneck.conv2 / downsample of a stage's first block): parity-class convolutions
             if in_token is not None and extra is None:
-                gx, in_token.colsum = conv_dgrad_s2(gy, wt, x16.shape, R, mask=x16, want_colsum=True)
+                mb = in_token.bits
+                gx, in_token.colsum = conv_dgrad_s2(gy, wt, x16.shape, R, mask=None if mb is not None else x16,
+                                                    want_colsum=True, mask_bits=mb)
                 in_token.grad_ptr = gx.data_ptr()
             else:
                 gx = conv_dgrad_s2(gy, wt, x16.shape, R)
@@ -378,8 +399,9 @@ class _Conv2dMFMA(torch.autograd.Function):
         elif need_x and wt is not None:
             # dx = conv(dy, rot180(W)^T) [+ identity gradient] [* (x > 0), column sums -> producer's bias gradient]
             if in_token is not None:
+                mb = in_token.bits
                 gx, in_token.colsum = conv_forward(gy, wt, None, extra, 1, dil * (R - 1) - pad, dil, False,
-                                                   mask=x16, want_colsum=True)
+                                                   mask=None if mb is not None else x16, want_colsum=True, mask_bits=mb)
                 in_token.grad_ptr = gx.data_ptr()
                 extra = None
             else:

@@ -305,6 +305,16 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
         assert (cs.double() - rs).abs().max().item() <= 1e-5 * ref.double().abs().sum((0, 2, 3)).max().item()
         y2, cs2 = hip_conv.conv_forward(x, w, None, res, 1, 1, 1, False, variant=variant, mask=mask, want_colsum=True)
         assert torch.equal(cs, cs2) and torch.equal(y, y2)
+        # the same mask as one bit per element (what the producer's forward launch leaves behind, round 2): bits_out of
+        # a ReLU launch equals (y > 0) packed LSB-first over 8 consecutive channels, and mask_bits reproduces mask
+        bits = torch.full((N * H * W * K // 8,), 0xAA, dtype=torch.uint8, device=dev)
+        yr = hip_conv.conv_forward(x, w, None, res if variant != 1 else None, 1, 1, 1, True, variant=variant, bits_out=bits)
+        flags = (yr.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.uint8)
+        packed = (flags << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
+        assert torch.equal(bits, packed)
+        y3, cs3 = hip_conv.conv_forward(x, w, None, res, 1, 1, 1, False, variant=variant, mask=yr, want_colsum=True)
+        y4, cs4 = hip_conv.conv_forward(x, w, None, res, 1, 1, 1, False, variant=variant, mask_bits=bits, want_colsum=True)
+        assert torch.equal(y3, y4) and torch.equal(cs3, cs4)
 
 
 def test_rpn_head_fused_cls_reg_matches_separate_convs(dev):
@@ -458,6 +468,10 @@ def test_stride2_data_gradient_parity_classes(dev, N, C, H, W, K, R):
     assert (got_m.float() - refm).abs().max().item() <= 1e-2 * ref.abs().max().item() + 1e-6
     assert torch.equal(got_m == 0, (got_m == 0) | (x <= 0))
     assert torch.allclose(cs, got_m.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    flags = (x.permute(0, 2, 3, 1).reshape(-1, 8) > 0).to(torch.uint8)          # the bit form of the same mask
+    bits = (flags << torch.arange(8, device=dev, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    got_b, cs_b = hip_conv.conv_dgrad_s2(gy, wt, x.shape, R, want_colsum=True, mask_bits=bits)
+    assert torch.equal(got_b, got_m) and torch.equal(cs_b, cs)
 
 
 def test_downsample_stage_backward_on_own_stride2_kernels(dev, monkeypatch):

@@ -69,13 +69,13 @@ def test_state_dict_layout_and_param_counts(golden_dir):
 def test_host_logic_reproduces_reference_step(golden_dir, fold_bn, monkeypatch):
     """fold_bn=False: operation-for-operation the reference's network -> agreement to 1e-6.
     fold_bn=True (the default): eval-mode BN folded into the convolutions, same function, fp32 rounding
-    differs -> 1e-4, and the discrete decisions (sampled labels) must still be identical."""
+    differs -> 2e-3 on the RoI terms (1e-7 on the RPN terms), and the sampled labels must still be identical."""
     from oracle.backend import oracle_ops
     from oadg_amd import layers
     monkeypatch.setattr(layers, 'FOLD_EVAL_BN', fold_bn)
-    # folding changes fp32 rounding, which may flip a discrete decision (top-k / NMS / IoU threshold) and with
-    # it ~1/2048 of the RoI loss terms: the folded run is held to the GPU test's tolerances
-    tol_l, tol_g = (5e-3, 2e-2) if fold_bn else (1e-6, 1e-5)
+    # folding changes fp32 rounding: the RPN terms stay at 1e-7, but the order of two near-tied proposals flips and
+    # with it one sampled negative (loss_cls 7e-4, loss_cont 7e-5; measured).  Sampled labels must still be identical.
+    tol_l, tol_g = (2e-3, 2e-3) if fold_bn else (1e-6, 1e-5)
     g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
     det = build_and_load()
     data = make_data(g)
@@ -87,10 +87,7 @@ def test_host_logic_reproduces_reference_step(golden_dir, fold_bn, monkeypatch):
     for k, v in out['log_vars'].items():
         ref = float(g['lv_' + k])
         assert abs(v - ref) <= tol_l * abs(ref), (k, v, ref)
-    if fold_bn:
-        assert (det.roi_head.bbox_targets[0].numpy() == g['roi_labels']).mean() >= 0.99
-    else:
-        assert np.array_equal(det.roi_head.bbox_targets[0].numpy(), g['roi_labels'])
+    assert np.array_equal(det.roi_head.bbox_targets[0].numpy(), g['roi_labels'])
     for k, v in grad_groups(det).items():
         ref = float(g['gn_' + k])
         assert abs(v - ref) <= tol_g * ref, (k, v, ref)
@@ -98,7 +95,7 @@ def test_host_logic_reproduces_reference_step(golden_dir, fold_bn, monkeypatch):
     for k in g.files:
         if k.startswith('g_'):
             mine = params[k[2:]].grad.flatten()[:4096].numpy()
-            assert np.abs(mine - g[k]).max() <= (0.1 if fold_bn else 1e-5) * np.abs(g[k]).max() + 1e-9, k
+            assert np.abs(mine - g[k]).max() <= (1e-2 if fold_bn else 1e-5) * np.abs(g[k]).max() + 1e-9, k
 
 
 @pytest.mark.gpu
