@@ -81,6 +81,15 @@ int oadg_roi_align_bwd(float* const* dfeats_host, const int* heights_host, const
  * in argsort(keys) order keeps the feature rows / gradient lines of neighbouring RoIs in L2. */
 int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float finest_scale, long long* keys,
                         void* stream);
+/* The bf16 backward organised by OUTPUT tiles (8 x 8 pixels of one image on one level per workgroup): every element of
+ * the bf16 gradient maps dmaps[l] [N,H_l,W_l,C] is WRITTEN (no zero fill, no fp32 maps, no atomics, no cast pass) and the
+ * summation order is fixed by `order` (deterministic).  order [K] = RoI indices sorted by the oadg_roi_order_keys keys,
+ * range [levels * N + 1] (device int32) = first position in `order` of every (level, image) group.  PH, PW <= 8.
+ * Same arithmetic as oadg_roi_align_bwd (mmcv RoIAlign backward) up to the fp32 summation order. */
+int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* widths, const float* scales,
+                             int levels, int N, int C, float finest_scale, const float* rois, int K, int PH, int PW,
+                             int sampling_ratio, int aligned, const void* grad_out, const int* order, const int* range,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy NMS, batched over images

@@ -36,6 +36,8 @@ SIGNATURES = {
     'oadg_roi_align_bwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
                                 vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
+    'oadg_roi_align_bwd_tiles': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, cf, vp, ci, ci, ci,
+                                      ci, ci, vp, vp, vp, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_resize_bilinear_u8': (ci, [vp, ci, ci, ci, vp, ci, ci, vp]),

@@ -135,6 +135,11 @@ def _as_nhwc(x):
 
 
 ROI_LOCALITY_ORDER = os.environ.get('OADG_ROI_ORDER', '1') == '1'
+# bf16 backward by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no atomics, deterministic summation order).
+# Correct (tests/test_hip_roi_nms.py) but OFF by default: proposals cluster on objects, a hot 8 x 8 tile walks hundreds of
+# RoIs serially, and the launch takes ~3 ms at BASELINE config 2 against 1.4 ms (+ 0.6 ms of fill / cast) for the atomic
+# scatter.  Kept for runs that need bit-reproducible gradients.
+BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '0') == '1'
 
 
 class _RoIAlignFPN(torch.autograd.Function):
@@ -154,31 +159,48 @@ class _RoIAlignFPN(torch.autograd.Function):
         out = torch.empty((K, C, PH, PW), dtype=dt, device=rois.device,
                           memory_format=torch.channels_last)
         P, Hs, Ws, Ss = _pyramid_args(feats, scales)
-        order = None
-        if ROI_LOCALITY_ORDER and K >= 512:
+        order = rng_ = None
+        tiles = BWD_TILES and dt == torch.bfloat16 and PH <= 8 and PW <= 8 and K > 0
+        if ROI_LOCALITY_ORDER and (K >= 512 or tiles):
             # process the RoIs level by level, image by image, cell by cell (the result does not depend on the order):
             # neighbouring RoIs share feature rows and - backward - gradient lines while those are still in L2
             keys = torch.empty((K,), dtype=torch.int64, device=rois.device)
             check(L.oadg_roi_order_keys(ptr(rois), K, N, len(feats), float(finest_scale), ptr(keys), stream_ptr()),
                   'oadg_roi_order_keys')
-            order = keys.argsort().int()
+            if tiles:       # the tile-gather backward walks the RoIs of one (level, image) group: group boundaries
+                skeys, order = keys.sort()
+                order = order.int()
+                groups = torch.arange(len(feats) * N + 1, device=rois.device, dtype=torch.int64) << 20
+                rng_ = torch.searchsorted(skeys, groups).int()
+            else:
+                order = keys.argsort().int()
         check(_timed('roi_align_fwd', L.oadg_roi_align_fwd, P, Hs, Ws, Ss, len(feats), N, C,
                      0 if dt == torch.float32 else 1, float(finest_scale), ptr(rois), K, PH, PW,
                      int(sampling_ratio), int(bool(aligned)), ptr(out), ptr(order), stream_ptr()), 'oadg_roi_align_fwd')
-        ctx.save_for_backward(rois, order if order is not None else rois.new_zeros(0))
+        ctx.save_for_backward(rois, order if order is not None else rois.new_zeros(0),
+                              rng_ if rng_ is not None else rois.new_zeros(0))
         ctx.meta = ([tuple(f.shape) for f in feats], dt, tuple(scales), float(finest_scale),
                     int(sampling_ratio), int(bool(aligned)), (PH, PW))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        rois, order = ctx.saved_tensors
+        rois, order, rng_ = ctx.saved_tensors
         order = order if order.numel() else None
         shapes, dt, scales, finest_scale, sampling_ratio, aligned, (PH, PW) = ctx.meta
         L = _lib.lib()
         gout = gout.contiguous(memory_format=torch.channels_last)
         if gout.dtype != dt:
             gout = gout.to(dt)
+        if rng_.numel() and order is not None:
+            # bf16: every element of the gradient maps is written once by its output tile (csrc roi_align_bwd_tiles)
+            grads = [torch.empty(s, dtype=dt, device=rois.device, memory_format=torch.channels_last) for s in shapes]
+            N, C = shapes[0][:2]
+            P, Hs, Ws, Ss = _pyramid_args(grads, scales)
+            check(_timed('roi_align_bwd', L.oadg_roi_align_bwd_tiles, P, Hs, Ws, Ss, len(grads), N, C, finest_scale,
+                         ptr(rois), rois.shape[0], PH, PW, sampling_ratio, aligned, ptr(gout), ptr(order), ptr(rng_),
+                         stream_ptr()), 'oadg_roi_align_bwd_tiles')
+            return (None, None, None, None, None, None, *grads)
         grads = [torch.empty(s, dtype=torch.float32, device=rois.device,
                              memory_format=torch.channels_last).zero_() for s in shapes]
         N, C = shapes[0][:2]

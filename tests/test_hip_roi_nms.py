@@ -133,3 +133,38 @@ def test_nms_12000_through_the_split_thr_branch(dev, n_ids):
     mine = order[k[0, :int(kc[0])].long()].cpu()
     assert len(mine) == len(keep) == 2000
     assert torch.equal(mine, keep)
+
+
+@pytest.mark.parametrize('C,K', [(256, 300), (64, 37), (512, 900)])
+def test_roi_align_bf16_backward_by_tiles(dev, C, K, monkeypatch):
+    """The bf16 backward organised by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no atomics) against the
+    oracle's fp32 backward on the same bf16-rounded operands (bf16 output rounding: 2^-8 relative) and against the
+    atomic path; map sizes that are not multiples of the 8 x 8 tile, degenerate and out-of-image RoIs, empty levels;
+    two runs are bit-identical (fixed summation order)."""
+    from oadg_amd import hip_ops
+    rs = np.random.RandomState(C + K)
+    strides = [4, 8, 16, 32]
+    H, W = 136, 264                                  # 34 x 66, 17 x 33, ... : ragged tiles on every level
+    feats = [torch.tensor(rs.standard_normal((3, C, -(-H // s), -(-W // s))).astype(np.float32)).bfloat16() for s in strides]
+    rois = _rand_rois(rs, K, 3, W, H, big=(K < 100))
+    extra = np.array([[0, 5, 5, 5, 5], [1, 30, 30, 10, 10], [2, -500, -500, -400, -400], [1, 0, 0, W, H],
+                      [0, 100, 47, 256, 293]], np.float32)
+    rois = np.concatenate([rois, extra])
+    fc = [f.float().clone().requires_grad_(True) for f in feats]
+    oc = ORA.roi_align_fpn(fc, torch.tensor(rois), 7, strides)
+    gout = torch.tensor(rs.standard_normal(tuple(oc.shape)).astype(np.float32)).bfloat16()
+    (oc * gout.float()).sum().backward()
+
+    def run(tiles):
+        monkeypatch.setattr(hip_ops, 'BWD_TILES', tiles)
+        fg = [f.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for f in feats]
+        og = hip_ops.roi_align_fpn(fg, torch.tensor(rois, device=dev), 7, [1.0 / s for s in strides])
+        og.backward(gout.to(dev).contiguous(memory_format=torch.channels_last))
+        return [f.grad for f in fg]
+    g_tiles, g_tiles2, g_atomic = run(True), run(True), run(False)
+    for a, a2, b, ref in zip(g_tiles, g_tiles2, g_atomic, fc):
+        rg = ref.grad if ref.grad is not None else torch.zeros_like(ref)
+        scale = rg.abs().max().item() + 1e-6
+        assert a.dtype == torch.bfloat16 and torch.equal(a, a2)
+        assert (a.float().cpu() - rg).abs().max().item() <= 1e-2 * scale
+        assert (a.float() - b.float()).abs().max().item() <= 1e-2 * scale
