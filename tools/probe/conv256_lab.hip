@@ -428,10 +428,270 @@ __global__ __launch_bounds__(256, 1) void conv256w4_kernel(ConvArgs a) {
     }
 }
 
+template <bool POST>
+__global__ __launch_bounds__(512) void conv256late_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int n_tiles = a.K / TN;
+    const long m_tiles = (a.M + TM - 1) / TM;
+    const long bid = blockIdx.x;
+    long mt;
+    int nt;
+    {
+        const long xcd = bid & 7, j = bid >> 3;
+        const long per = (m_tiles + 7) >> 3;
+        nt = (int)(j % n_tiles);
+        mt = xcd * per + j / n_tiles;
+        if (j / n_tiles >= per || mt >= m_tiles) return;
+    }
+    const long m0 = mt * TM;
+    const int k0 = nt * TN;
+    const int nk = a.R * a.S * (a.C / BK);
+
+    // ---- loader geometry: piece q = i*512 + tid of a half-tile -> row = q >> 3 (0..127), 16-byte slot q & 7
+    const unsigned short* pb[4];      // [h*2+i]: image base of the pixel + channel slot
+    int hi0[4], wi0[4];
+    const unsigned short* wb[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * 512 + tid;
+            const int row = q >> 3, lslot = (q & 7) ^ ((row >> 1) & 7);
+            const long m = m0 + h * 128 + row;
+            if (m < a.M) {
+                const unsigned mu = (unsigned)m;                 // M < 2^31 (checked on the host): 32-bit divisions
+                const unsigned tq = mu / (unsigned)a.Wo;
+                const int wo = (int)(mu - tq * (unsigned)a.Wo);
+                const int n = (int)(tq / (unsigned)a.Ho);
+                const int ho = (int)(tq - (unsigned)n * (unsigned)a.Ho);
+                pb[h * 2 + i] = a.x + (size_t)n * a.H * a.W * a.C + lslot * 8;
+                hi0[h * 2 + i] = ho * a.stride - a.pad;
+                wi0[h * 2 + i] = wo * a.stride - a.pad;
+            } else {
+                pb[h * 2 + i] = a.x;
+                hi0[h * 2 + i] = -(1 << 28);            // fails every bounds test -> zero line
+                wi0[h * 2 + i] = 0;
+            }
+            wb[h * 2 + i] = a.w + (size_t)(k0 + h * 128 + row) * a.R * a.S * a.C + lslot * 8;
+        }
+
+    auto advance = [&](TapState& st) {
+        st.t++;
+        st.c0 += BK;
+        if (st.c0 == a.C) {
+            st.c0 = 0;
+            st.rs++;
+            if (++st.s == a.S) { st.s = 0; st.r++; }
+        }
+    };
+    auto stage_pix = [&](int h, const TapState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
+        const bool live = st.t < nk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hi = hi0[h * 2 + i] + st.r * a.dil, wi = wi0[h * 2 + i] + st.s * a.dil;
+            const bool ok = live && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            // offsets inside one image fit 32 bits (checked on the host)
+            const unsigned short* src = ok ? pb[h * 2 + i] + ((hi * a.W + wi) * a.C + st.c0) : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+    auto stage_wgt = [&](int h, const TapState& st, int buf) {
+        unsigned char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+        const bool live = st.t < nk;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned short* src = live ? wb[h * 2 + i] + (st.rs * a.C + st.c0) : a.zeros;
+            glds16(src, dst + i * 8192);
+        }
+    };
+
+    // fragment addresses inside a half-tile (the same for every buffer): row = base + (lane & 15),
+    // 16-byte slot = ks*4 + (lane >> 4), swizzled like the loader
+    const int fr = lane & 15, fq = lane >> 4;
+    int poff[4][2], woff[2][2];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wr * 64 + it * 16 + fr;
+            poff[it][ks] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = wc * 32 + jt * 16 + fr;
+            woff[jt][ks] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+        }
+
+    f32x4v acc[2][2][2][4];        // [w half][w tile][p half][p tile]
+#pragma unroll
+    for (int x0 = 0; x0 < 2; ++x0)
+#pragma unroll
+        for (int x1 = 0; x1 < 2; ++x1)
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+                for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 pf[4][2], wf[2][2][2];
+    auto read_pix = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pf[it][ks] = *reinterpret_cast<const bf16x8*>(base + poff[it][ks]);
+    };
+    auto read_wgt = [&](int h, int buf) {
+        const unsigned char* base = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[h][jt][ks] = *reinterpret_cast<const bf16x8*>(base + woff[jt][ks]);
+    };
+#define OADG_MFMA32L(W_FIRST, PH_, LATE)                                                                     \
+    do {                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                       \
+        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                   \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
+                _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                             \
+                    _Pragma("unroll") for (int it = 0; it < 4; ++it)                                         \
+                        acc[hh ^ W_FIRST][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
+                            wf[hh ^ W_FIRST][jt][ks], pf[it][ks], acc[hh ^ W_FIRST][jt][PH_][it], 0, 0, 0);  \
+            if (hh == 0) { __builtin_amdgcn_sched_barrier(0); LATE; __builtin_amdgcn_sched_barrier(0); }     \
+        }                                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        asm volatile("s_barrier" ::: "memory");                                                              \
+    } while (0)
+
+    // ---- prologue: tile 0 complete in buffer 0, P0 + W0 of tile 1 in buffer 1 (what phase B of "tile -1" stages)
+    TapState s1{0, 0, 0, 0, 0};
+    stage_pix(0, s1, 0);
+    stage_wgt(0, s1, 0);
+    stage_wgt(1, s1, 0);
+    stage_pix(1, s1, 0);
+    advance(s1);                     // s1 = tile 1
+    stage_pix(0, s1, 1);
+    stage_wgt(0, s1, 1);
+    TapState s2 = s1;
+    advance(s2);                     // s2 = tile 2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (wr == 1) asm volatile("s_barrier" ::: "memory");     // stagger: group 1 runs one barrier behind
+
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // phase A
+        read_wgt(0, buf);
+        read_wgt(1, buf);
+        read_pix(0, buf);
+        stage_wgt(1, s1, buf ^ 1);
+        OADG_MFMA32L(0, 0, stage_pix(1, s1, buf ^ 1));
+        // phase B
+        read_pix(1, buf);
+        stage_pix(0, s2, buf);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        OADG_MFMA32L(1, 1, stage_wgt(0, s2, buf));
+        s1 = s2;
+        advance(s2);
+    }
+#undef OADG_MFMA32L
+    if (wr == 0) asm volatile("s_barrier" ::: "memory");     // balance the stagger
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the zero-line stages of the tail have landed
+    asm volatile("s_barrier" ::: "memory");
+
+    // ---- epilogue: bf16 C image [256 pixels][256 channels] in LDS (16-byte slot ^ (pixel & 15): the 16 pixels of a
+    // ds_write_b64 lane group land on 16 different bank groups), then 16-byte row-contiguous stores
+    {
+        const int cq = lane >> 4;
+#pragma unroll
+        for (int wh = 0; wh < 2; ++wh)
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int ch = wh * 128 + wc * 32 + jt * 16 + 4 * cq;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[e] = a.bias[k0 + ch + e];
+                }
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int p = ph * 128 + wr * 64 + it * 16 + fr;
+                        unsigned short o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[wh][jt][ph][it][e] + bv[e];
+                            if (a.relu && !a.res) v = fmaxf(v, 0.f);
+                            o[e] = f32_to_bf16(v);
+                        }
+                        uint2 pk;
+                        pk.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+                        pk.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+                        *reinterpret_cast<uint2*>(smem + p * 512 + ((((ch >> 3) ^ (p & 15))) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                    }
+            }
+    }
+    // residual / mask pieces requested before the barrier, all 16 (x2) loads of the thread in flight together: the
+    // 128 accumulator registers are dead once the C image is written
+    constexpr int NPIECE = (TM * TN / 8) / 512;
+    bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
+    unsigned mb[POST ? NPIECE : 1];
+    if (POST) {
+#pragma unroll
+        for (int it = 0; it < NPIECE; ++it) {
+            const int q = it * 512 + tid;
+            const long m = m0 + (q >> 5);
+            const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
+            rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            mb[it] = (a.bits_in && m < a.M) ? a.bits_in[off >> 3] : 0xffu;
+        }
+    } else {
+        rv[0] = mv[0] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        mb[0] = 0xffu;
+    }
+    __syncthreads();
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NPIECE; ++it) {
+        const int q = it * 512 + tid;
+        const int p = q >> 5, sg = q & 31;             // sg = tid & 31 for every piece of this thread
+        const long m = m0 + p;
+        if (m >= a.M) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
+        const size_t off = (size_t)m * a.K + k0 + sg * 8;
+        *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum,
+                                                                   mb[POST ? it : 0], off);
+    }
+    if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
+        float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid >> 5) * TN + (tid & 31) * 8 + e] = csum[e];
+        __syncthreads();
+        if (tid < TN) {
+            float t = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) t += red[g * TN + tid];
+            a.colsum[(size_t)mt * a.K + k0 + tid] = t;
+        }
+    }
+}
+
+
 template <int KERN>
 float run(const ConvArgs& a, int iters) {
     const unsigned lds = KERN == 0 ? 2 * BUF_BYTES + 16384 : 2 * BUF_BYTES + 16384;
-    auto kern = KERN == 0 ? conv_igemm256_kernel<false> : (KERN == 1 ? conv3x3p_kernel<false> : conv256w4_kernel<false>);
+    auto kern = KERN == 0 ? conv_igemm256_kernel<false> : (KERN == 1 ? conv3x3p_kernel<false> : (KERN == 2 ? conv256w4_kernel<false> : conv256late_kernel<false>));
     const int threads = KERN == 2 ? 256 : 512;
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const long m_tiles = (a.M + TM - 1) / TM;
@@ -473,13 +733,13 @@ int main(int argc, char** argv) {
         a.Ho = H; a.Wo = W; a.M = (long)N * H * W; a.scatter = 0; a.OH = H; a.OW = W; a.osh = a.osw = 1; a.oph = a.opw = 0;
         const double gf = 2.0 * a.M * K * C * R * R / 1e9;
         const int it = 20;
-        const float t0 = run<0>(a, it), t1 = run<2>(a, it), t0b = run<0>(a, it), t1b = run<2>(a, it);
+        const float t0 = run<0>(a, it), t1 = run<3>(a, it), t0b = run<0>(a, it), t1b = run<3>(a, it);
         std::vector<unsigned short> y0(ny), y1(ny);
         run<0>(a, 1); hipMemcpy(y0.data(), y, ny * 2, hipMemcpyDeviceToHost);
         hipMemset(y, 0, ny * 2);
-        run<2>(a, 1); hipMemcpy(y1.data(), y, ny * 2, hipMemcpyDeviceToHost);
+        run<3>(a, 1); hipMemcpy(y1.data(), y, ny * 2, hipMemcpyDeviceToHost);
         size_t bad = 0; for (size_t i = 0; i < ny; ++i) bad += y0[i] != y1[i];
-        printf("%-18s per-tap %7.3f / %7.3f ms %7.1f TF/s | 4-wave %7.3f / %7.3f ms %7.1f TF/s | %zu of %zu outputs differ\n",
+        printf("%-18s per-tap %7.3f / %7.3f ms %7.1f TF/s | late-glds %7.3f / %7.3f ms %7.1f TF/s | %zu of %zu outputs differ\n",
                sh.name, t0, t0b, gf / (t0 < t0b ? t0 : t0b), t1, t1b, gf / (t1 < t1b ? t1 : t1b), bad, ny);
         hipFree(x); hipFree(w); hipFree(y); hipFree(z);
     }
