@@ -719,8 +719,11 @@ int main(int argc, char** argv) {
         const int N = sh.N, H = sh.H, W = sh.W, C = sh.C, K = sh.K, R = 3;
         const size_t nx = (size_t)N * H * W * C, nw = (size_t)K * R * R * C, ny = (size_t)N * H * W * K;
         std::vector<unsigned short> hx(nx), hw(nw);
+        const bool zero_data = argc > 1 && !strcmp(argv[1], "zero");
         srand(1);
+        if (!zero_data)
         for (auto& v : hx) v = lab_f2b((rand() / (float)RAND_MAX) * 2.f - 1.f);
+        if (!zero_data)
         for (auto& v : hw) v = lab_f2b(((rand() / (float)RAND_MAX) * 2.f - 1.f) / 48.f);
         unsigned short *x, *w, *y, *z;
         hipMalloc(&x, nx * 2); hipMalloc(&w, nw * 2); hipMalloc(&y, ny * 2); hipMalloc(&z, 256);

@@ -168,6 +168,35 @@ def main():
         print('idle on the main stream: %.2f ms total; gaps > 50 us:' % (sum(g for g, _, _ in gaps if g > 0) / 1e3))
         for g, a_, b_ in sorted(gaps, reverse=True)[:25]:
             print(f'  {g:8.1f} us  after {a_}  before {b_}')
+        # which host section launched the kernel that ENDS each gap?  (kernel -> launch call by correlation id -> section)
+        launch_ts = {e['args'].get('correlation'): e['ts'] for e in ev
+                     if e.get('cat') in ('cuda_runtime', 'cuda_driver') and 'aunch' in e['name']}
+        kcorr = {(e['ts'], e['name'][:60]): e['args'].get('correlation') for e in ks}
+        per_sec = collections.defaultdict(float)
+        for i in range(len(main) - 1):
+            g = main[i + 1][0] - main[i][1]
+            if g <= 5:
+                continue
+            ts = launch_ts.get(kcorr.get((main[i + 1][0], main[i + 1][2][:60])))
+            name = 'unknown'
+            if ts is not None:
+                inside = [sct for sct in secs if sct['ts'] <= ts <= sct['ts'] + sct['dur']]
+                name = min(inside, key=lambda q: q['dur'])['name'] if inside else 'outside sections'
+            per_sec[name] += g
+        if '--timeline' in sys.argv:      # the backward's host-bound stretch: kernels in time order with the gap before each
+            bsecs = sorted([q for q in secs if q['name'] == 'sec:backward'], key=lambda q: q['ts'])
+            if bsecs:
+                b0 = bsecs[-1]['ts']
+                first = next((i for i in range(len(main)) if (launch_ts.get(kcorr.get((main[i][0], main[i][2][:60]))) or 0) >= b0), None)
+                if first is not None:
+                    print('main-stream kernels from the start of the last backward (gap before, duration, name):')
+                    for i in range(first, len(main)):
+                        gap = main[i][0] - main[i - 1][1]
+                        if gap > 15 or i < first + 3:
+                            print(f'  #{i - first:4d} {gap:7.1f} {main[i][1] - main[i][0]:7.1f}  after {main[i - 1][2][:50]:50s} before {main[i][2][:60]}')
+        print('idle (gaps > 5 us) by the section that launched the kernel after the gap, ms per step:')
+        for nm, g in sorted(per_sec.items(), key=lambda kv: -kv[1]):
+            print(f'  {nm:28s} {g / 2e3:7.2f}')
         return
     pr = cProfile.Profile()
     pr.enable()
