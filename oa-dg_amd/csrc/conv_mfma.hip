@@ -43,6 +43,11 @@ struct ConvArgs {
 
 __device__ __forceinline__ long out_row(const ConvArgs& a, long m) {
     if (!a.scatter) return m;
+    if (a.M <= 0x7fffffffL) {                      // 32-bit divisions: a fraction of the 64-bit sequences
+        const unsigned t = (unsigned)m / (unsigned)a.Wo, wo = (unsigned)m - t * (unsigned)a.Wo;
+        const unsigned n = t / (unsigned)a.Ho, ho = t - n * (unsigned)a.Ho;
+        return ((long)n * a.OH + (long)ho * a.osh + a.oph) * a.OW + (long)wo * a.osw + a.opw;
+    }
     const long t = m / a.Wo;
     const int wo = (int)(m - t * a.Wo);
     const long n = t / a.Ho;
@@ -105,7 +110,9 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // NST = 2: two LDS stages (next chunk loads while this one computes), 2 workgroups per CU.  NST = 1: one stage
 // (32 KiB + 8 KiB), 4 workgroups per CU - for short reductions (1x1 convolutions with C <= 256) the latencies of a
 // workgroup (first HBM fetch, epilogue) are covered by the other three instead of by its own pipeline.
-template <int TBN, bool POST, int NST>
+// PW: pointwise launch (R = S = 1, stride 1, pad 0, no scatter map): pixel m of y is row m of x, so the 64-bit
+// pixel -> (n, ho, wo) divisions and the per-tap bounds tests - 12-15 % of an HBM-bound 1x1 launch - are compiled out.
+template <int TBN, bool POST, int NST, bool PW = false>
 __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WN = TBN / 64, WM = 4 / WN, AF = BM / WM / 32, NBP = TBN * 8 / 256;
@@ -145,11 +152,22 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         const int row = q >> 3, slot = q & 7;
         seg[i] = slot ^ ((row >> 1) & 7);
         const long m = m0 + row;
-        if (m < a.M) {
-            const int wo = (int)(m % a.Wo);
-            const long t = m / a.Wo;
-            const int ho = (int)(t % a.Ho);
-            const int n = (int)(t / a.Ho);
+        if (PW) {
+            a_base[i] = m < a.M ? a.x + (size_t)m * a.C : nullptr;
+            a_hi0[i] = a_wi0[i] = 0;
+        } else if (m < a.M) {
+            int wo, ho, n;
+            if (a.M <= 0x7fffffffL) {              // (uniform) 32-bit divisions where the pixel count allows
+                const unsigned t = (unsigned)m / (unsigned)a.Wo;
+                wo = (int)((unsigned)m - t * (unsigned)a.Wo);
+                n = (int)(t / (unsigned)a.Ho);
+                ho = (int)(t - (unsigned)n * (unsigned)a.Ho);
+            } else {
+                wo = (int)(m % a.Wo);
+                const long t = m / a.Wo;
+                ho = (int)(t % a.Ho);
+                n = (int)(t / a.Ho);
+            }
             a_base[i] = a.x + (size_t)n * a.H * a.W * a.C;
             a_hi0[i] = ho * a.stride - a.pad;
             a_wi0[i] = wo * a.stride - a.pad;
@@ -161,15 +179,20 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
     }
 
     auto stage = [&](int kc, int buf) {
-        const int rs = kc / cpc, c0 = (kc - rs * cpc) * BK;
-        const int r = rs / a.S, s = rs - r * a.S;
+        const int rs = PW ? 0 : kc / cpc, c0 = (kc - rs * cpc) * BK;
+        const int r = PW ? 0 : rs / a.S, s = rs - r * a.S;
         unsigned char* sa = smem + buf * TSTAGE;
         unsigned char* sb = sa + BM * BK * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int hi = a_hi0[i] + r * a.dil, wi = a_wi0[i] + s * a.dil;
-            const bool ok = a_base[i] != nullptr && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-            const unsigned short* src = ok ? a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0 + seg[i] * 8 : a.zeros;
+            const unsigned short* src;
+            if (PW) {
+                src = a_base[i] ? a_base[i] + c0 + seg[i] * 8 : a.zeros;
+            } else {
+                const int hi = a_hi0[i] + r * a.dil, wi = a_wi0[i] + s * a.dil;
+                const bool ok = a_base[i] != nullptr && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+                src = ok ? a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0 + seg[i] * 8 : a.zeros;
+            }
             glds16(src, sa + i * 4096 + wave * 1024);
         }
 #pragma unroll
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         for (int it = 0; it < NPIECE; ++it) {
             const int q = it * 256 + tid;
             const long m = m0 + q / SPR;
-            const size_t off = (size_t)out_row(a, m < a.M ? m : 0) * a.K + k0 + (q % SPR) * 8;
+            const size_t off = (size_t)(PW ? (m < a.M ? m : 0) : out_row(a, m < a.M ? m : 0)) * a.K + k0 + (q % SPR) * 8;
             rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mb[it] = (a.bits_in && m < a.M) ? a.bits_in[off >> 3] : 0xffu;
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         const long m = m0 + row;
         if (m >= a.M) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + row * TBN + sg * 8);
-        const size_t off = (size_t)out_row(a, m) * a.K + k0 + sg * 8;
+        const size_t off = (size_t)(PW ? m : out_row(a, m)) * a.K + k0 + sg * 8;
         *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum,
                                                                    mb[POST ? it : 0], off);
     }
@@ -662,7 +685,13 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
         hipStream_t st = (hipStream_t)stream;
 #define OADG_L128(TB, PO, NS, LDS) \
     hipLaunchKernelGGL((conv_igemm_kernel<TB, PO, NS>), dim3((unsigned)blocks), dim3(256), LDS, st, a)
-        if (tbn == BN) {
+#define OADG_L128PW(TB, PO, LDS) \
+    hipLaunchKernelGGL((conv_igemm_kernel<TB, PO, 1, true>), dim3((unsigned)blocks), dim3(256), LDS, st, a)
+        const bool pw = one && R == 1 && S == 1 && stride == 1 && pad == 0 && !a.scatter;
+        if (pw) {
+            if (tbn == BN) { if (post) OADG_L128PW(128, true, lds1); else OADG_L128PW(128, false, lds1); }
+            else { if (post) OADG_L128PW(64, true, lds1); else OADG_L128PW(64, false, lds1); }
+        } else if (tbn == BN) {
             if (one) { if (post) OADG_L128(128, true, 1, lds1); else OADG_L128(128, false, 1, lds1); }
             else { if (post) OADG_L128(128, true, 2, lds2); else OADG_L128(128, false, 2, lds2); }
         } else {
@@ -670,6 +699,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
             else { if (post) OADG_L128(64, true, 2, lds2); else OADG_L128(64, false, 2, lds2); }
         }
 #undef OADG_L128
+#undef OADG_L128PW
     }
     OADG_LAUNCH_CHECK();
     return OADG_OK;
