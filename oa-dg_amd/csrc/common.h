@@ -71,10 +71,9 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned)h) << 16);
 }
-// round-to-nearest-even f32 -> bf16 (NaN preserved as quiet NaN)
+// round-to-nearest-even f32 -> bf16 (NaN -> quiet NaN) on gfx950's v_cvt_pk_bf16_f32: neighbouring conversions are
+// paired by the compiler, 1/2 instruction per element where the integer rounding sequence took 6 - the epilogues of
+// the HBM-bound convolution launches were VALU-bound on it (tools/probe/conv1x1_lab.hip)
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
 }

@@ -851,10 +851,17 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_wgrad_kernel(Wgr
             lrow[i] = q >> 4;
             lslot[i] = (q & 15) ^ ((lrow[i] & 3) << 2);
             const long p = pbase + lrow[i];
-            lwo[i] = (int)(p % a.Wo);
-            const long t = p / a.Wo;
-            lho[i] = (int)(t % a.Ho);
-            ln[i] = (int)(t / a.Ho);
+            if (p <= 0x7fffffffL) {                    // 32-bit divisions (a fraction of the 64-bit sequences)
+                const unsigned t = (unsigned)p / (unsigned)a.Wo;
+                lwo[i] = (int)((unsigned)p - t * (unsigned)a.Wo);
+                ln[i] = (int)(t / (unsigned)a.Ho);
+                lho[i] = (int)(t - (unsigned)ln[i] * (unsigned)a.Ho);
+            } else {
+                lwo[i] = (int)(p % a.Wo);
+                const long t = p / a.Wo;
+                lho[i] = (int)(t % a.Ho);
+                ln[i] = (int)(t / a.Ho);
+            }
         }
     }
     const int adv_h = WP / a.Wo, adv_w = WP - adv_h * a.Wo;     // 64 pixels = adv_h rows + adv_w columns
