@@ -1185,27 +1185,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
 }
 
 // Kernel / split choice (tools/bench_conv.py --wgrad sweeps it; times vs MIOpen's igemm_wrw on MI355X):
-//  - 3x3 over >= 200k pixels, K and C multiples of 256: the 256-tile phase pipeline (1.2x at P2, 1.1x at P3);
+//  - K and C multiples of 256, 3x3 with >= 16 K-tiles per workgroup or 1x1 over >= 200k pixels: the 256-tile phase
+//    pipeline (1.2x at P2, 1.1x at P3; round 2: also layer3 / layer4 / P4 3x3 and the P2 / P3 lateral 1x1, 1.4-1.6x);
 //  - other 3x3: 128-tile, ONE LDS stage at 4 workgroups per CU, ~1024 workgroups (1.06-1.2x);
 //  - 1x1: 128-tile, two stages, ~512 workgroups - the fp32 partial tiles (splits x K x C x 4 bytes, written and read
 //    back by the reduction) are the cost that matters there (1.15x on layer2, 1.6x on layer3 / layer4).
+// One workgroup of the 256-tile kernel per CU.  Large reductions (>= 128 K-tiles per workgroup at two rounds): ~512
+// workgroups; otherwise ONE round of <= 256 - half the partial tiles to write and read back, and the shapes with 36
+// K-tiles per workgroup (layer3 / layer4 / P4 3x3) still run at 780-810 TFLOP/s against 530-580 on the 128-tile
+// kernel, whose single-stage workgroups spend half their time waiting for L2 (tools/probe/wgrad_lab.hip).
+long wgrad256_splits(long P, int K, int C, int RS) {
+    const long tiles = (long)(K / 256) * (C / 256) * RS;
+    const long nchunks = (P + WP - 1) / WP;
+    long s = (512 + tiles - 1) / tiles;
+    if (s < 1) s = 1;
+    if (nchunks / s < 128) s = 256 / tiles;
+    if (s >= 8 && s * tiles > 256) s = s / 8 * 8;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return s;
+}
 bool wgrad_use256(long P, int K, int C, int RS) {
-    return K % 256 == 0 && C % 256 == 0 && RS > 1 && P >= 200000;
+    if (K % 256 != 0 || C % 256 != 0) return false;
+    const long nchunks = (P + WP - 1) / WP;
+    if (RS == 1) return P >= 200000;           // the 1x1 layers of layer3 / layer4 gain less than the extra partials cost
+    return nchunks / wgrad256_splits(P, K, C, RS) >= 16;
 }
 int wgrad_stages(int RS) { return RS > 1 ? 1 : 2; }
 
 int wgrad_splits(long P, int K, int C, int RS) {
-    if (wgrad_use256(P, K, C, RS)) {
-        // one workgroup per CU: aim at ~2 rounds of 256 workgroups, at least 8 K-tiles each
-        const long tiles = (long)(K / 256) * (C / 256) * RS;
-        const long nchunks = (P + WP - 1) / WP;
-        long s = (512 + tiles - 1) / tiles;
-        if (s > nchunks / 8) s = nchunks / 8;
-        if (s >= 8) s = s / 8 * 8;
-        if (s < 1) s = 1;
-        if (s > 256) s = 256;
-        return (int)s;
-    }
+    if (wgrad_use256(P, K, C, RS)) return (int)wgrad256_splits(P, K, C, RS);
     const long tiles = (long)(K / 128) * (C / 128) * RS;
     const long nchunks = (P + WP - 1) / WP;
     const long target = RS > 1 ? 1024 : 512;
