@@ -216,7 +216,10 @@ int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* bias, const
  * (transposing LDS reads + split-K partials in `workspace`, summed in fixed order).  C % 128 == 0, K % 128 == 0. */
 /* same contract; `variant` picks the kernel: 0 automatic (what oadg_conv2d_nhwc_bf16 does), 1 = 128x128x64 tile
  * (4 waves, two 32 KiB LDS stages, 2 workgroups per CU), 2 = 256x256x64 tile (8 waves, 128 KiB LDS,
- * phase-pipelined; needs K % 256 == 0), 3 = 128-tile with ONE LDS stage at 4 workgroups per CU */
+ * phase-pipelined; needs K % 256 == 0), 3 = 128-tile with ONE LDS stage at 4 workgroups per CU, 4 = the streaming
+ * pointwise kernel (1x1 / stride 1 / pad 0, C in {64, 128, 256}, K % 256 == 0, N*H*W a multiple of 32 and large
+ * enough: weights stationary in registers, pixels through an LDS-DMA ring, residual / mask bits prefetched one
+ * sub-tile ahead; no bf16 mask operand, not mask_bits together with relu_bits_out; OADG_EARG when not eligible) */
 int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride,
                                   int pad, int dil, int relu, int variant, void* stream);
@@ -235,7 +238,10 @@ int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, co
 long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                              int variant);
 int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream);
-/* the variant (2 or 3) variant 0 resolves to for a problem; 0 = shape not covered */
+/* the variant (2, 3 or 4) variant 0 resolves to for a problem BY ITS GEOMETRY; 0 = shape not covered.  A launch with a
+ * bf16 mask operand (or mask_bits together with relu_bits_out) runs 3 where this says 4: callers that need
+ * colsum_part pass the variant they resolved explicitly, to oadg_conv2d_pixel_tiles (variant 4: one row per pixel
+ * range) and to the launch. */
 int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);
 int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,

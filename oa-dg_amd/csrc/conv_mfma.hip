@@ -16,6 +16,7 @@
 // 16-byte bank slots.  Algorithmic work: 2*M*K*R*S*C FLOP; HBM bytes: M*C*2 (input, taps re-read from L2) +
 // M*K*2 (output) + K*R*S*C*2 (weights).
 #include "common.h"
+#include <type_traits>
 #include "oadg_hip.h"
 
 namespace {
@@ -133,7 +134,10 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
         const long xcd = bid & 7, j = bid >> 3;              // j-th workgroup of this XCD
         const long per = (m_tiles + 7) >> 3;                 // pixel tiles per XCD
         nt = (int)(j % n_tiles);
-        mt = xcd * per + j / n_tiles;
+        // pointwise launches have no halo to share: pixel tiles are dealt round-robin to the XCDs, so at any moment
+        // the whole chip streams through ONE compact window of x / y / residual (DRAM page locality: +15-20 % on the
+        // HBM-bound 1x1 layers, tools/probe/conv1x1_lab.hip) instead of eight windows an eighth of the tensor apart
+        mt = PW ? (j / n_tiles) * 8 + xcd : xcd * per + j / n_tiles;
         if (j / n_tiles >= per || mt >= m_tiles) return;     // padding of the last XCD range
     }
     const long m0 = mt * BM;
@@ -315,6 +319,233 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
     }
 }
 
+
+// ================================================================================================ pointwise, streaming
+// HBM-bound 1x1 / stride 1 convolutions with C <= 256 (ResNet conv3 and its mirror, the data gradient of conv1; the
+// P2 lateral): y[M][K] = x[M][C] * w[K][C]^T moves M * (C + K * (1 + residual)) * 2 bytes for 2 * M * C * K FLOP - 64 to
+// 200 FLOP per byte.  The tile kernels above spend a workgroup's life on serial phases (stage -> MFMA -> epilogue loads ->
+// stores); here every memory stream of the launch stays in flight while the matrix pipe works:
+//   * persistent workgroups (256 threads, 2 per CU); wave v keeps the weights of 64 output channels x C in REGISTERS for
+//     the whole launch (the A operand of v_mfma_f32_16x16x32_bf16, channels on the rows so that a lane ends up with 4
+//     consecutive channels of a pixel); K / 256 workgroup columns share a pixel range through their XCD's L2;
+//   * pixels stream through an LDS ring of NS sub-tiles (32 pixels, 16 for C = 256) filled by global_load_lds, NS - 1
+//     sub-tiles ahead; L2 -> LDS traffic per output byte is C / 256 (the 128-tile kernel: (C + C) / 128);
+//   * the residual / mask-bit pieces of sub-tile i + 1 are requested into a second register set before the MFMAs of
+//     sub-tile i; waits are counted (s_waitcnt vmcnt(N): loads, LDS-DMA and stores retire in issue order on gfx9);
+//   * sub-tile i of a workgroup is number i * ranges + range - a grid-stride order: the chip works inside ONE compact
+//     window of x / y / residual at any moment.  With one contiguous range per workgroup (512 far-apart streams) the same
+//     kernel ran 15-20 % slower (DRAM page locality; tools/probe/conv1x1_lab.hip).
+// Epilogue per wave: accumulators + bias -> bf16 rows [pixel][64 channels] in a private staging area (padded rows) ->
+// 16-byte pieces -> finish_piece (residual, ReLU, mask bits, column sums, bits out) -> 128-byte row segments to HBM.
+// Results equal the 128-tile kernel's bit for bit (same products, same fp32 summation order per output).
+template <int C>
+struct PwGeo {
+    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = 4, NP = SP / 8, SLOTS = C / 8;
+    static constexpr int SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
+    static constexpr int RT = KPW / 16, CT = SP / 16, KS = C / 32, STG_STRIDE = KPW * 2 + 16, STG_BYTES = SP * STG_STRIDE;
+    static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES + 4 * KPW * 4;
+    static constexpr int GRID = 512;
+};
+
+#define OADG_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int C, bool RES, bool BIN, bool BOUT>
+__global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int ncol) {
+    using Geo = PwGeo<C>;
+    constexpr int KPW = Geo::KPW, SP = Geo::SP, NS = Geo::NS, NP = Geo::NP, SLOTS = Geo::SLOTS, SUB_BYTES = Geo::SUB_BYTES;
+    constexpr int G = Geo::G, RT = Geo::RT, CT = Geo::CT, KS = Geo::KS, STG_STRIDE = Geo::STG_STRIDE, STG_BYTES = Geo::STG_BYTES;
+    // vector-memory operations per sub-tile and wave: G LDS-DMA loads, R operand loads, S stores
+    constexpr int R = (RES ? NP : 0) + (BIN ? NP : 0), S = NP + (BOUT ? NP : 0);
+    constexpr bool POST = RES || BIN;
+    static_assert((NS - 2) * G + (NS - 1) * (R + S) <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7), j = (int)(bid >> 3);            // workgroup b runs on XCD b % 8 (speed only)
+    const int col = j % ncol;                                       // the columns of a range sit on one XCD
+    const long ranges = (gridDim.x >> 3) / ncol * 8;
+    const long range = (long)(j / ncol) * 8 + xcd;
+    const long n_sub = a.M / SP;                                    // the host guarantees M % SP == 0
+    const int n_it = range < n_sub ? (int)((n_sub - range + ranges - 1) / ranges) : 0;
+    const int kcol = col * (4 * KPW) + wave * KPW;                  // this wave's first output channel
+    unsigned char* ring = smem;
+    unsigned char* stg = smem + NS * SUB_BYTES + wave * STG_BYTES;
+    float* sbias = reinterpret_cast<float*>(smem + NS * SUB_BYTES + 4 * STG_BYTES) + wave * KPW;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+
+    if (n_it > 0) {
+        // ---- stationary operands: weights in registers, this wave's 64 biases in LDS
+        bf16x8 wf[RT][KS];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                wf[rt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(kcol + rt * 16 + fr) * C + ks * 32 + fq * 8);
+        sbias[lane] = a.bias ? a.bias[kcol + lane] : 0.f;
+
+        // ---- loader geometry (constant over sub-tiles).  The LDS image of an LDS-DMA instruction is lane-linear, so the
+        // bank-conflict swizzle (16-byte slot ^ f(pixel)) is applied on the global source address
+        int goff[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int L = (g * 4 + wave) * 64 + lane;
+            const int px = L / SLOTS, sl = L % SLOTS;
+            goff[g] = px * C + (C == 64 ? (sl ^ ((px >> 1) & 7)) : (sl ^ (px & 15))) * 8;
+        }
+        auto stage = [&](long sub, int slot) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const unsigned short* src = sub < n_sub ? a.x + (size_t)sub * (SP * C) + goff[g] : a.zeros;
+                glds16(src, ring + slot * SUB_BYTES + (g * 4 + wave) * 1024);
+            }
+        };
+        // slot (ks * 4 + fq) ^ f(px) = (ks * 4) ^ (fq ^ f(px)): one base per 16-pixel tile, the k-step is an XOR constant
+        int bbase[CT], bsw[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int px = ct * 16 + fr;
+            bbase[ct] = px * (C * 2);
+            bsw[ct] = (fq ^ (C == 64 ? ((px >> 1) & 7) : (px & 15))) << 4;
+        }
+        // epilogue pieces of this lane: pixel lane / 8 + 8 * jj, 16-byte slot lane % 8 of the wave's 64 channels
+        const int ppx = lane >> 3, psl = lane & 7;
+        bf16x8 rv[2][NP];
+        unsigned mb[2][NP];
+        auto request = [&](long sub, int set) {     // residual / mask bits of sub-tile `sub` -> register set `set`
+            if (!POST) return;
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const long m = sub < n_sub ? sub * SP + ppx + 8 * jj : 0;       // past the end: any valid row
+                const size_t off = (size_t)m * a.K + kcol + psl * 8;
+                // asm: the compiler must not see these loads, or it would wait for ALL vector memory (the LDS-DMA
+                // prefetches included) at their first use
+                if (RES) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[set][jj]) : "v"(a.res + off) : "memory");
+                if (BIN) asm volatile("global_load_ubyte %0, %1, off" : "=v"(mb[set][jj]) : "v"(a.bits_in + (off >> 3)) : "memory");
+            }
+        };
+
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p) stage(range + p * ranges, p);
+        request(range, 0);
+
+        // issue order per sub-tile i: [DMA of i + NS - 1] [operands of i + 1] MFMAs(i) [stores of i]
+        auto body = [&](int i, auto set_c) {
+            constexpr int set = decltype(set_c)::value;
+            const long sub = range + i * ranges;
+            // sub-tile i landed: everything issued after its DMA may stay in flight (pipeline fill: drain)
+            if (i < NS - 1) OADG_VMCNT(0); else OADG_VMCNT((NS - 2) * G + (NS - 1) * (R + S));
+            asm volatile("s_barrier" ::: "memory");     // ... for every wave; and slot (i - 1) % NS has been read by all
+            stage(sub + (NS - 1) * ranges, (i + NS - 1) % NS);
+            request(sub + ranges, set ^ 1);
+            const unsigned char* at = ring + (i % NS) * SUB_BYTES;
+            f32x4 acc[RT][CT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 pf[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    pf[ct] = *reinterpret_cast<const bf16x8*>(at + bbase[ct] + (bsw[ct] ^ (ks * 64)));
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][ks], pf[ct], acc[rt][ct], 0, 0, 0);
+            }
+            // accumulators (+ bias, fp32) -> bf16 rows [pixel][64 channels] in this wave's staging area
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + rt * 16 + fq * 4);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[rt][ct][r] + bv[r];
+                        if (a.relu && !RES) v = fmaxf(v, 0.f);
+                        o[r] = (short)f32_to_bf16(v);
+                    }
+                    *reinterpret_cast<bf16x4*>(stg + (ct * 16 + fr) * STG_STRIDE + (rt * 16 + fq * 4) * 2) = o;
+                }
+            }
+            if (POST) {
+                // the operands of THIS sub-tile (requested one sub-tile ago); what was issued since stays in flight
+                OADG_VMCNT(S + G + R);
+#pragma unroll
+                for (int jj = 0; jj < NP; ++jj) {   // ties the registers to the wait: no use may be scheduled above it
+                    if (RES) asm volatile("" : "+v"(rv[set][jj]));
+                    if (BIN) asm volatile("" : "+v"(mb[set][jj]));
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {
+                const int px = ppx + 8 * jj;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + px * STG_STRIDE + psl * 16);
+                const size_t off = (size_t)(sub * SP + px) * a.K + kcol + psl * 8;
+                v = finish_piece<POST>(a, v, RES ? rv[set][jj] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0},
+                                       csum, BIN ? mb[set][jj] : 0xffu, off);
+                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.y + off), "v"(v) : "memory");
+            }
+        };
+        for (int i = 0; i < n_it; i += 2) {         // two bodies per trip: the register set index is a constant
+            body(i, std::integral_constant<int, 0>{});
+            if (i + 1 < n_it) body(i + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    if (a.colsum) {     // one row of partial column sums per pixel range: lanes l, l + 8, ... share a channel slot
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = csum[e];
+            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            csum[e] = t;
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a.colsum[(size_t)range * a.K + kcol + lane * 8 + e] = csum[e];
+        }
+    }
+}
+
+// geometry test of the streaming pointwise kernel (the operands are tested by the launcher): pixel ranges, or 0
+long pw_stream_ranges(long M, int C, int K, int R, int S, int stride, int pad) {
+    if (R != 1 || S != 1 || stride != 1 || pad != 0 || (C != 64 && C != 128 && C != 256) || K % 256 != 0) return 0;
+    const int ncol = K / 256, sp = C >= 256 ? 16 : 32;
+    if (ncol > 64 || (64 % ncol) != 0 || M % sp != 0) return 0;
+    const long ranges = 512 / ncol;
+    return (M / sp) >= 8 * ranges ? ranges : 0;                 // at least 8 sub-tiles per workgroup
+}
+
+template <int C>
+int launch_pw_stream(const ConvArgs& a, hipStream_t st) {
+    using Geo = PwGeo<C>;
+    const int ncol = a.K / 256;
+    const bool res = a.res != nullptr, bin = a.bits_in != nullptr, bout = a.bits_out != nullptr;
+#define OADG_PWS(RE, BI, BO)                                                                                       \
+    do {                                                                                                           \
+        static bool attr = false;                                                                                  \
+        if (!attr) {                                                                                               \
+            hipError_t e = hipFuncSetAttribute((const void*)conv_pw_stream_kernel<C, RE, BI, BO>,                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS);              \
+            if (e != hipSuccess) return (int)e;                                                                    \
+            attr = true;                                                                                           \
+        }                                                                                                          \
+        hipLaunchKernelGGL((conv_pw_stream_kernel<C, RE, BI, BO>), dim3(Geo::GRID), dim3(256), Geo::LDS, st, a, ncol); \
+    } while (0)
+    if (res && bin && !bout) OADG_PWS(true, true, false);
+    else if (res && !bin && bout) OADG_PWS(true, false, true);
+    else if (res && !bin && !bout) OADG_PWS(true, false, false);
+    else if (!res && bin && !bout) OADG_PWS(false, true, false);
+    else if (!res && !bin && bout) OADG_PWS(false, false, true);
+    else if (!res && !bin && !bout) OADG_PWS(false, false, false);
+    else return OADG_EARG;                  // (mask bits in AND bits out: no caller)
+#undef OADG_PWS
+    return OADG_OK;
+}
 
 // ================================================================================================ 256 x 256 tile
 // Deep-pipelined variant for the large layers: 256 pixels x 256 channels x 64 per 512-thread workgroup, 8 waves as
@@ -617,10 +848,13 @@ namespace {
 //  - otherwise the single-stage 128-tile kernel at 4 workgroups per CU (variant 3): 1.15-1.4x the 256-tile kernel on
 //    the 1x1 layers with C <= 256, 850 TFLOP/s even on 3x3 (the two-stage variant 1: 710) - it is never slower than
 //    the two-stage kernel, which stays selectable for comparison.
-int auto_variant(long M, int H, int W, int C, int K, int nchunks) {
+//  - pointwise launches with C <= 256 and K a multiple of 256 (ResNet conv3 / the data gradient of conv1, P2 lateral):
+//    the streaming kernel (variant 4), 1.1-1.2x the 128-tile kernel there (4.2-5.3 TB/s of HBM traffic).
+int auto_variant(long M, int H, int W, int C, int K, int nchunks, int R = 0, int S = 0, int stride = 0, int pad = 0) {
     const long big = ((M + TM - 1) / TM) * (K / TN);
     const bool ok256 = K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
-    return (ok256 && nchunks >= 12) ? 2 : 3;
+    if (ok256 && nchunks >= 12) return 2;
+    return pw_stream_ranges(M, C, K, R, S, stride, pad) > 0 ? 4 : 3;
 }
 
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
@@ -631,7 +865,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % 64 != 0) return OADG_EARG;   // other shapes stay on the library path
-    if (variant < 0 || variant > 3 || (variant == 2 && K % TN != 0)) return OADG_EARG;
+    if (variant < 0 || variant > 4 || (variant == 2 && K % TN != 0)) return OADG_EARG;
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
@@ -653,8 +887,22 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (a.Ho < 1 || a.Wo < 1) return OADG_EARG;
     a.M = (long)N * a.Ho * a.Wo;
     const bool post = residual != nullptr || mask != nullptr || bits_in != nullptr;
-    if (variant == 0) variant = auto_variant(a.M, H, W, C, K, R * S * (C / BK));
+    if (variant == 0) {
+        variant = auto_variant(a.M, H, W, C, K, R * S * (C / BK), R, S, stride, pad);
+        // the streaming kernel takes mask BITS only, and not together with bits out
+        if (variant == 4 && (sc || mask || (bits_in && bits_out))) variant = 3;
+    }
     if (variant == 2 && ((long)H * W * C >= (1L << 31) || a.M >= (1L << 31))) variant = 1;
+    if (variant == 4) {
+        if (sc || mask || (bits_in && bits_out) || pw_stream_ranges(a.M, C, K, R, S, stride, pad) == 0) return OADG_EARG;
+        int rc = OADG_EARG;
+        if (C == 64) rc = launch_pw_stream<64>(a, (hipStream_t)stream);
+        else if (C == 128) rc = launch_pw_stream<128>(a, (hipStream_t)stream);
+        else if (C == 256) rc = launch_pw_stream<256>(a, (hipStream_t)stream);
+        if (rc != OADG_OK) return rc;
+        OADG_LAUNCH_CHECK();
+        return OADG_OK;
+    }
     if (variant == 2) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -712,13 +960,14 @@ extern "C" int oadg_conv2d_nhwc_bf16(const void* x, const void* w, const float* 
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, stride, pad, dil, relu, 0, stream);
 }
 
-// which kernel the automatic choice takes for a problem (1 or 2; 0 for unsupported shapes) - for profiling
+// which kernel the automatic choice takes for a problem by its geometry (2, 3 or 4; 0 for unsupported shapes).  A launch
+// with a bf16 mask operand, an output scatter map, or mask bits in AND bits out takes 3 where this says 4.
 extern "C" int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil) {
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return 0;
     if (C % BK != 0 || K % 64 != 0) return 0;
     const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     if (Ho < 1 || Wo < 1) return 0;
-    return auto_variant((long)N * Ho * Wo, H, W, C, K, R * S * (C / BK));
+    return auto_variant((long)N * Ho * Wo, H, W, C, K, R * S * (C / BK), R, S, stride, pad);
 }
 
 // Data-gradient form with the backward of the producer's epilogue fused in:  y = (conv(x, w) [+ residual]) * (mask > 0)
@@ -753,10 +1002,12 @@ extern "C" long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R
     if (variant == 0) return 0;
     const int Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     const long M = (long)N * Ho * Wo;
+    if (variant == 4) return pw_stream_ranges(M, C, K, R, S, stride, pad);      // one row per pixel range
     return variant == 2 ? (M + TM - 1) / TM : (M + BM - 1) / BM;
 }
 
-// same, with the kernel variant chosen by the caller: 0 = automatic, 1 = 128 x 128 tile, 2 = 256 x 256 tile
+// same, with the kernel variant chosen by the caller: 0 = automatic, 1 = 128 x 128 tile (two LDS stages), 2 = 256 x 256
+// tile, 3 = 128 x 128 tile (one stage, 4 workgroups per CU), 4 = streaming pointwise kernel (EARG unless eligible)
 extern "C" int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bias, const void* residual,
                                              void* y, const void* zeros16, int N, int H, int W, int C, int K, int R,
                                              int S, int stride, int pad, int dil, int relu, int variant,

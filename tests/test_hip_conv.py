@@ -321,6 +321,52 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
         assert torch.equal(y3, y4) and torch.equal(cs3, cs4)
 
 
+@pytest.mark.parametrize('N,C,H,W,K', [
+    (4, 64, 128, 256, 256),       # layer1 conv3 form: one workgroup column, 8 sub-tiles per workgroup
+    (4, 64, 128, 264, 256),       # uneven: some workgroups run 9 sub-tiles, some 8
+    (2, 128, 128, 256, 512),      # layer2 conv3 / conv1 data gradient: two columns share a pixel range
+    (2, 256, 64, 128, 1024),      # layer3: 16-pixel sub-tiles, four columns
+])
+def test_streaming_pointwise_kernel_equals_the_tile_kernel(dev, N, C, H, W, K):
+    """csrc conv_pw_stream_kernel (variant 4: weights in registers, LDS-DMA pixel ring, operands one sub-tile ahead)
+    against the 128-tile kernel (variant 3) on every operand combination its callers use - same products, same fp32
+    summation order: outputs and mask bits bit-identical, column sums equal up to the order of the partial rows -
+    and against the fp32 reference convolution."""
+    from oadg_amd import hip_conv, _lib
+    L = _lib.lib()
+    assert L.oadg_conv2d_auto_variant(N, H, W, C, K, 1, 1, 1, 0, 1) == 4
+    g = torch.Generator(device=dev).manual_seed(N * C + K)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(**cl)
+    w = (torch.randn(K, C, 1, 1, device=dev, generator=g) / C ** 0.5).bfloat16().contiguous(**cl)
+    b = torch.randn(K, device=dev, generator=g)
+    res = torch.randn(N, K, H, W, device=dev, generator=g).bfloat16().contiguous(**cl)
+    flags = torch.rand(N * H * W * K // 8, device=dev, generator=g)
+    bits = (flags * 256).to(torch.uint8)
+
+    def run(variant, **kw):
+        return hip_conv.conv_forward(x, w, kw.pop('bias', None), kw.pop('res', None), 1, 0, 1, kw.pop('relu', False),
+                                     variant=variant, **kw)
+    ref = F.conv2d(x.float(), w.float(), b)
+    y4 = run(4, bias=b)
+    assert (y4.float() - ref).abs().max().item() <= 8e-3 * ref.abs().max().item()
+    for kw in (dict(), dict(bias=b, relu=True), dict(bias=b, res=res, relu=True)):
+        assert torch.equal(run(4, **kw), run(3, **kw)), kw
+    bo3, bo4 = (torch.full_like(bits, 0xAA) for _ in range(2))
+    assert torch.equal(run(4, bias=b, res=res, relu=True, bits_out=bo4), run(3, bias=b, res=res, relu=True, bits_out=bo3))
+    assert torch.equal(bo3, bo4)
+    for kw in (dict(mask_bits=bits), dict(res=res, mask_bits=bits)):
+        y3, c3 = run(3, want_colsum=True, **kw)
+        y4, c4 = run(4, want_colsum=True, **kw)
+        assert torch.equal(y3, y4)
+        assert (c3 - c4).abs().max().item() <= 1e-4 * y3.float().abs().sum((0, 2, 3)).max().item()
+        assert torch.equal(run(4, want_colsum=True, **kw)[1], c4)              # deterministic
+    assert L.oadg_conv2d_pixel_tiles(N, H, W, C, K, 1, 1, 1, 0, 1, 4) == 512 // (K // 256)   # one row per pixel range
+    # the automatic choice falls back to the tile kernel for operands the streaming kernel does not take
+    ym = hip_conv.conv_forward(x, w, None, None, 1, 0, 1, False, mask=res)
+    assert torch.equal(ym, hip_conv.conv_forward(x, w, None, None, 1, 0, 1, False, variant=3, mask=res))
+
+
 def test_rpn_head_fused_cls_reg_matches_separate_convs(dev):
     """rpn_cls + rpn_reg as one zero-padded 1x1 conv on the MFMA kernel (with the GradToken hand-off to rpn_conv)
     against the module-by-module path through the library convolutions: outputs and every parameter gradient."""

@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256) void stream_kernel(ConvArgs a) {
 // one sub-tile ahead into registers; stores follow.  Every memory stream of the launch is in flight while the MFMAs run.
 template <int C>
 struct PwGeo {
-    static constexpr int KPW = 64, SP = 32, NS = (C >= 256 ? 3 : 4), SLOTS = C / 8, SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
+    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = 4, NP = SP / 8, SLOTS = C / 8, SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
     static constexpr int RT = KPW / 16, CT = SP / 16, KS = C / 32, STG_STRIDE = KPW * 2 + 16, STG_BYTES = SP * STG_STRIDE;
-    static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES;
+    static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES + 4 * KPW * 4;
 };
 
 #define PW_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
     using Geo = PwGeo<C>;
     constexpr int KPW = Geo::KPW, SP = Geo::SP, NS = Geo::NS, SLOTS = Geo::SLOTS, SUB_BYTES = Geo::SUB_BYTES, G = Geo::G;
     constexpr int RT = Geo::RT, CT = Geo::CT, KS = Geo::KS, STG_STRIDE = Geo::STG_STRIDE, STG_BYTES = Geo::STG_BYTES;
-    constexpr int R = (RES ? 4 : 0) + (BIN ? 4 : 0), S = 4 + (BOUT ? 4 : 0);
+    constexpr int NP = Geo::NP;
+    constexpr int R = (RES ? NP : 0) + (BIN ? NP : 0), S = NP + (BOUT ? NP : 0);
     constexpr bool POST = RES || BIN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -206,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
     const int col = j % ncol;
     const long range = (long)xcd * ((gridDim.x >> 3) / ncol) + j / ncol;
     const long n_sub = (a.M + SP - 1) / SP;
-    const long s0 = range * per;
-    const long s1 = s0 + per < n_sub ? s0 + per : n_sub;
-    if (s0 >= s1) return;
-    const int n_it = (int)(s1 - s0);
+    // sub-tile i of this workgroup is number i * ranges + range: at any moment the whole chip works inside one compact
+    // window of the tensors (DRAM page locality), like a grid-stride loop
+    const long ranges = (gridDim.x >> 3) / ncol * 8;
+    if (range >= n_sub) return;
+    const int n_it = (int)((n_sub - range + ranges - 1) / ranges);
+    const long s1 = n_sub;
     const int kcol = col * (4 * KPW) + wave * KPW;          // this wave's first output channel
     unsigned char* ring = smem;
     unsigned char* stg = smem + NS * SUB_BYTES + wave * STG_BYTES;
@@ -222,11 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             wf[rt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(kcol + rt * 16 + fr) * C + ks * 32 + fq * 8);
-    float bias[RT][4];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bias[rt][r] = a.bias ? a.bias[kcol + rt * 16 + fq * 4 + r] : 0.f;
+    float* sbias = reinterpret_cast<float*>(smem + NS * SUB_BYTES + 4 * STG_BYTES) + wave * KPW;   // this wave's 64 biases
+    sbias[lane] = a.bias ? a.bias[kcol + lane] : 0.f;
 
     // ---- loader geometry (constant over sub-tiles)
     int goff[G], gpx[G];
@@ -248,23 +248,23 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
         }
     };
     // fragment read offsets inside a sub-tile
-    int boff[CT][KS];
+    // slot (ks * 4 + fq) ^ f(px) = (ks * 4) ^ (fq ^ f(px)): one base per 16-pixel tile, the k-step is an XOR constant
+    int bbase[CT], bsw[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int px = ct * 16 + fr, sl = ks * 4 + fq;
-            boff[ct][ks] = px * (C * 2) + ((C == 64 ? (sl ^ ((px >> 1) & 7)) : (sl ^ (px & 15))) << 4);
-        }
+    for (int ct = 0; ct < CT; ++ct) {
+        const int px = ct * 16 + fr;
+        bbase[ct] = px * (C * 2);
+        bsw[ct] = (fq ^ (C == 64 ? ((px >> 1) & 7) : (px & 15))) << 4;
+    }
     // epilogue pieces of this lane: pixel lane/8 + 8*jj, 16-byte slot lane%8 of the wave's 64 channels
     const int ppx = lane >> 3, psl = lane & 7;
-    bf16x8 rv[2][4];
-    unsigned mb[2][4];
+    bf16x8 rv[2][NP];
+    unsigned mb[2][NP];
     auto request = [&](long sub, int set) {     // residual / mask bits of sub-tile `sub` -> register set
         if (!POST) return;
         const long m0 = sub * SP;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             long m = m0 + ppx + 8 * jj;
             if (m >= a.M || sub >= s1) m = 0;
             const size_t off = (size_t)m * a.K + kcol + psl * 8;
@@ -275,17 +275,17 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
 
     // ---- prologue
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p) stage(s0 + p, p);
-    request(s0, 0);
+    for (int p = 0; p < NS - 1; ++p) stage(range + p * ranges, p);
+    request(range, 0);
 
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto body = [&](int i, auto set_c) {
         constexpr int set = decltype(set_c)::value;
-        const long sub = s0 + i;
+        const long sub = range + i * ranges;
         if (i < NS - 1) PW_WAIT(0); else PW_WAIT((NS - 2) * G + (NS - 1) * (R + S));
         asm volatile("s_barrier" ::: "memory");
-        stage(sub + NS - 1, (i + NS - 1) % NS);
-        request(sub + 1, set ^ 1);
+        stage(sub + (NS - 1) * ranges, (i + NS - 1) % NS);
+        request(sub + ranges, set ^ 1);
         const unsigned char* at = ring + (i % NS) * SUB_BYTES;
         f32x4 acc[RT][CT];
 #pragma unroll
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
         for (int ks = 0; ks < KS; ++ks) {
             bf16x8 pf[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) pf[ct] = *reinterpret_cast<const bf16x8*>(at + boff[ct][ks]);
+            for (int ct = 0; ct < CT; ++ct) pf[ct] = *reinterpret_cast<const bf16x8*>(at + bbase[ct] + (bsw[ct] ^ (ks * 64)));
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -309,9 +309,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 bf16x4 o;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + rt * 16 + fq * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[rt][ct][r] + bias[rt][r];
+                    float v = acc[rt][ct][r] + bv[r];
                     if (a.relu && !RES) v = fmaxf(v, 0.f);
                     o[r] = (short)f32_to_bf16(v);
                 }
@@ -319,18 +320,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol
             }
         if (POST) {
             // the operands of THIS sub-tile (requested one iteration ago): everything issued since may stay in flight
-            if (RES && BIN)
-                asm volatile("s_waitcnt vmcnt(%8)" : "+v"(rv[set][0]), "+v"(rv[set][1]), "+v"(rv[set][2]), "+v"(rv[set][3]),
-                             "+v"(mb[set][0]), "+v"(mb[set][1]), "+v"(mb[set][2]), "+v"(mb[set][3]) : "n"(S + G + R) : "memory");
-            else if (RES)
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rv[set][0]), "+v"(rv[set][1]), "+v"(rv[set][2]), "+v"(rv[set][3])
-                             : "n"(S + G + R) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(mb[set][0]), "+v"(mb[set][1]), "+v"(mb[set][2]), "+v"(mb[set][3])
-                             : "n"(S + G + R) : "memory");
+            PW_WAIT(S + G + R);
+#pragma unroll
+            for (int jj = 0; jj < NP; ++jj) {       // ties the operand registers to the wait (no use may move above it)
+                if (RES) asm volatile("" : "+v"(rv[set][jj]));
+                if (BIN) asm volatile("" : "+v"(mb[set][jj]));
+            }
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < NP; ++jj) {
             const int px = ppx + 8 * jj;
             const long m = sub * SP + px;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + px * STG_STRIDE + psl * 16);
@@ -405,7 +403,10 @@ int main(int argc, char** argv) {
                             {"l3 dgrad1 256->1024 +res+bits", 8, 64, 128, 256, 1024, 1, 1},
                             {"l2 conv1 512->128", 8, 128, 256, 512, 128, 0, 0},
                             {"l2 dgrad3 512->128 +bits", 8, 128, 256, 512, 128, 0, 1},
-                            {"lat 256->256 P2", 8, 256, 512, 256, 256, 0, 0}};
+                            {"lat 256->256 P2", 8, 256, 512, 256, 256, 0, 0},
+                            {"l3 conv1 1024->256", 8, 64, 128, 1024, 256, 0, 0}, {"l3 dgrad3 1024->256 +bits", 8, 64, 128, 1024, 256, 0, 1},
+                            {"l4 conv1 2048->512", 8, 32, 64, 2048, 512, 0, 0}, {"l3 down 512->1024 (s1 form)", 8, 64, 128, 512, 1024, 0, 0},
+                            {"l4 conv3 512->2048 +res", 8, 32, 64, 512, 2048, 1, 0}, {"lat P3 512->256", 8, 128, 256, 512, 256, 0, 0}};
     for (const Shape& sh : shapes) {
         const int N = sh.N, H = sh.H, W = sh.W, C = sh.C, K = sh.K;
         const size_t M = (size_t)N * H * W, nx = M * C, nw = (size_t)K * C, ny = M * K;
