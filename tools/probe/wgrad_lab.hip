@@ -194,7 +194,7 @@ int main(int argc, char** argv) {
         if (K % 256 == 0 && C % 256 == 0) {
             hipFuncSetAttribute((const void*)conv_wgrad256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
             const long tiles = (long)(K / 256) * (C / 256) * R * R;
-            for (int target : {256, 512}) {
+            for (int target : {216, 256, 288, 512}) {
                 WgradArgs b = a;
                 long sp = target / tiles; if (sp < 1) sp = 1;
                 if (sp > nchunks / 4) sp = nchunks / 4;
