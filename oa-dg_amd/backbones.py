@@ -34,24 +34,31 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x
-        if self.downsample is not None:
-            identity = conv_bn(x, self.downsample[0], self.downsample[1])
         # GradTokens (hip_conv): the backward of each fused bias+ReLU epilogue - mask, bias gradient, and for the
-        # block input the identity-path gradient add - is folded into the data-gradient kernel of the tensor's only
-        # consumer.  t_in rides on x when the previous block produced it for this block alone.
-        t_in = getattr(x, '_oadg_token', None) if self.downsample is None else None
+        # block input the identity-path gradient add - is folded into the data-gradient kernel of the tensor's
+        # consumer.  t_in rides on x when the previous block produced it.  In a stage's first block x has several
+        # consumers: conv1 finishes its gradient, the downsample convolution (run AFTER conv2 here, so that autograd
+        # runs its backward BEFORE conv1's) and the FPN lateral deposit theirs on the token (hip_conv.GradToken).
+        t_in = getattr(x, '_oadg_token', None)
         if hip_conv.tokens_ok(x, self.conv1, self.conv2, self.conv3) and not (self.bn1.training or self.bn2.training
                                                                               or self.bn3.training):
             t_a, t_b, t_out = hip_conv.GradToken(), hip_conv.GradToken(), hip_conv.GradToken()
-            if not x.requires_grad:
+            if not x.requires_grad or (self.downsample is not None and
+                                       not hip_conv.tokens_ok(x, self.downsample[0])):
                 t_in = None
             out = conv_bn(x, self.conv1, self.bn1, relu=True, in_token=t_in, out_token=t_a)
             out = conv_bn(out, self.conv2, self.bn2, relu=True, in_token=t_a, out_token=t_b)
-            out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity, in_token=t_b, out_token=t_out,
-                          res_token=t_in)
+            if self.downsample is not None:
+                identity = conv_bn(x, self.downsample[0], self.downsample[1], dep_token=t_in)
+                out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity, in_token=t_b, out_token=t_out)
+            else:
+                out = conv_bn(out, self.conv3, self.bn3, relu=True, residual=x, in_token=t_b, out_token=t_out,
+                              res_token=t_in)
             out._oadg_token = t_out
             return out
+        identity = x
+        if self.downsample is not None:
+            identity = conv_bn(x, self.downsample[0], self.downsample[1])
         out = conv_bn(x, self.conv1, self.bn1, relu=True)
         out = conv_bn(out, self.conv2, self.bn2, relu=True)
         return conv_bn(out, self.conv3, self.bn3, relu=True, residual=identity)   # relu(bn3(conv3) + identity)
@@ -185,8 +192,10 @@ class ResNet(nn.Module):
         for i, name in enumerate(self.res_layers):
             x = getattr(self, name)(x)
             if i in self.out_indices:
-                if hasattr(x, '_oadg_token'):
-                    x._oadg_token = None        # a stage output has other consumers (the neck): no hand-off
+                # a stage output has other consumers (the neck): they may deposit on its token (necks.FPN), but the LAST
+                # stage's output has no convolution here to finish its gradient
+                if hasattr(x, '_oadg_token') and i == len(self.res_layers) - 1:
+                    x._oadg_token = None
                 outs.append(x)
         return tuple(outs)
 

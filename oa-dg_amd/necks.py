@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import hip_ops
+from . import hip_ops, layers
 
 from .layers import ConvModule, xavier_init
 from .registry import NECKS
@@ -46,9 +46,19 @@ class FPN(nn.Module):
             if isinstance(m, nn.Conv2d):
                 xavier_init(m, distribution='uniform')
 
+    @staticmethod
+    def _lateral(conv, x):
+        # a backbone stage output carries the GradToken of the next stage's first convolution, which finishes its
+        # gradient: the lateral's data gradient is deposited there instead of returned (hip_conv.GradToken)
+        tok = getattr(x, '_oadg_token', None)
+        if tok is not None and not (conv.with_norm or conv.with_activation):
+            c = conv.conv
+            return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok)
+        return conv(x)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [conv(inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        laterals = [self._lateral(conv, inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
         n = len(laterals)
         for i in range(n - 1, 0, -1):   # fpn.py:166-175
             if 'scale_factor' in self.upsample_cfg:

@@ -370,6 +370,67 @@ def test_streaming_pointwise_kernel_equals_the_tile_kernel(dev, N, C, H, W, K):
     assert torch.equal(ym, hip_conv.conv_forward(x, w, None, None, 1, 0, 1, False, variant=3, mask=res))
 
 
+def test_stage_output_gradients_deposited_in_dgrad_epilogues(dev, monkeypatch):
+    """A stage output feeds the next stage's conv1, its stride-2 downsample convolution and the FPN lateral.  With
+    hip_conv.DEPOSIT the lateral and the downsample leave their data gradients on the tensor's GradToken (each adding
+    what is there in its own epilogue; the 1x1 / stride-2 one in place on its strided grid) and conv1 finishes the sum
+    with the ReLU mask and the bias-gradient column sums - against autograd's accumulation passes (DEPOSIT off) and
+    against the plain path without any token: same outputs, parameter gradients within bf16 rounding of each other."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import ResNet
+    from oadg_amd.necks import FPN
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(0)
+        bb = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                    norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+        neck = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)
+        neck.init_weights()
+        net = torch.nn.ModuleList([bb, neck]).to(dev).to(memory_format=torch.channels_last)
+        net.train()
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+                torch.nn.init.normal_(m.bias, 0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.2)
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn(2, 3, 128, 192, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        gys = None
+        res = {}
+        deposits = []
+        orig = hip_conv.conv_dgrad_s2
+        monkeypatch.setattr(hip_conv, 'conv_dgrad_s2',
+                            lambda *a, **k: (deposits.append(k.get('accumulate') is not None), orig(*a, **k))[1])
+        for mode in ('deposit', 'accumulate', 'plain'):
+            monkeypatch.setattr(hip_conv, 'DEPOSIT', mode == 'deposit')
+            if mode == 'plain':
+                monkeypatch.setattr(hip_conv, 'tokens_ok', lambda *a, **k: False)
+            net.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                outs = neck(bb(x))
+            if gys is None:
+                gys = [torch.randn(o.shape, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
+                       for o in outs]
+            torch.autograd.backward(list(outs), gys)
+            res[mode] = ([o.detach().float() for o in outs],
+                         {n: p.grad.float().clone() for n, p in net.named_parameters() if p.grad is not None})
+        assert sum(deposits[:len(deposits) // 3]) == 2          # layer3 / layer4 downsample: in-place deposits
+        assert set(res['deposit'][1]) == set(res['plain'][1])
+        for a, b in zip(res['deposit'][0], res['plain'][0]):
+            assert torch.equal(a, b)
+
+        def close(a, b, what, tol):
+            d = (a - b).abs()
+            assert d.max().item() <= tol * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
+            assert d.mean().item() <= tol / 4 * b.abs().mean().item() + 1e-7, (what, d.mean().item(), b.abs().mean().item())
+        for n in res['plain'][1]:
+            close(res['deposit'][1][n], res['accumulate'][1][n], n, 3e-2)
+            close(res['deposit'][1][n], res['plain'][1][n], n, 6e-2)
+    finally:
+        hip_conv.enable(False)
+
+
 def test_rpn_head_fused_cls_reg_matches_separate_convs(dev):
     """rpn_cls + rpn_reg as one zero-padded 1x1 conv on the MFMA kernel (with the GradToken hand-off to rpn_conv)
     against the module-by-module path through the library convolutions: outputs and every parameter gradient."""
