@@ -349,7 +349,9 @@ class RPNHead(AnchorHead):
             # instead of two library convolutions forward and four backward, and - through the GradToken - the ReLU
             # mask and the bias gradient of rpn_conv come out of that convolution's data-gradient epilogue.
             tok = hip_conv.GradToken()
-            x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok)
+            # (in_token: an FPN level whose gradient this convolution finishes - necks.FPN._fpn_conv)
+            x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok,
+                       in_token=getattr(x, '_oadg_token', None))
             if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
                 w, b = self._fused_head_params()
                 y = conv2d(x, w, b, 1, 0, 1, in_token=tok)

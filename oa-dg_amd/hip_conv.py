@@ -338,11 +338,12 @@ class GradToken:
     closes the token.  Autograd's accumulation passes over the activation (13 per step, 0.8 ms) disappear.  Any other
     order stays correct: a depositor that finds the token closed (or never armed) returns its gradient as usual, autograd
     adds it, P then sees a tensor other than ``grad_ptr`` and masks / reduces itself."""
-    __slots__ = ('extra', 'colsum', 'grad_ptr', 'bits', 'armed', 'closed')
+    __slots__ = ('extra', 'colsum', 'grad_ptr', 'bits', 'armed', 'closed', 'masked')
 
-    def __init__(self):
+    def __init__(self, masked=True):
         self.extra = self.colsum = self.grad_ptr = self.bits = None
         self.armed = self.closed = False
+        self.masked = masked        # False: t = P(...) without a ReLU (an FPN output): sums and column sums only
 
 
 RELU_BITS = os.environ.get('OADG_RELU_BITS', '1') == '1'
@@ -433,7 +434,7 @@ class _Conv2dMFMA(torch.autograd.Function):
             need_x = False
         if need_x and wt is not None and stride == 2:
             # dx of the stride-2 layers (Bottleneck.conv2 / downsample of a stage's first block): parity-class convolutions
-            if in_token is not None and extra is None:
+            if in_token is not None and extra is None and in_token.masked:
                 mb = in_token.bits
                 gx, in_token.colsum = conv_dgrad_s2(gy, wt, x16.shape, R, mask=None if mb is not None else x16,
                                                     want_colsum=True, mask_bits=mb)
@@ -444,9 +445,10 @@ class _Conv2dMFMA(torch.autograd.Function):
         elif need_x and wt is not None:
             # dx = conv(dy, rot180(W)^T) [+ identity gradient] [* (x > 0), column sums -> producer's bias gradient]
             if in_token is not None:
-                mb = in_token.bits
+                mb = in_token.bits if in_token.masked else None
                 gx, in_token.colsum = conv_forward(gy, wt, None, extra, 1, dil * (R - 1) - pad, dil, False,
-                                                   mask=None if mb is not None else x16, want_colsum=True, mask_bits=mb)
+                                                   mask=x16 if (mb is None and in_token.masked) else None,
+                                                   want_colsum=True, mask_bits=mb)
                 in_token.grad_ptr = gx.data_ptr()
                 extra = None
             else:

@@ -145,8 +145,9 @@ BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '0') == '1'
 class _RoIAlignFPN(torch.autograd.Function):
 
     @staticmethod
-    def forward(ctx, rois, out_size, scales, finest_scale, sampling_ratio, aligned, *feats):
+    def forward(ctx, rois, out_size, scales, finest_scale, sampling_ratio, aligned, tokens, *feats):
         require_cuda(rois, *feats)
+        ctx.tokens = tokens
         L = _lib.lib()
         dt = feats[0].dtype
         if dt not in (torch.float32, torch.bfloat16):
@@ -200,7 +201,7 @@ class _RoIAlignFPN(torch.autograd.Function):
             check(_timed('roi_align_bwd', L.oadg_roi_align_bwd_tiles, P, Hs, Ws, Ss, len(grads), N, C, finest_scale,
                          ptr(rois), rois.shape[0], PH, PW, sampling_ratio, aligned, ptr(gout), ptr(order), ptr(rng_),
                          stream_ptr()), 'oadg_roi_align_bwd_tiles')
-            return (None, None, None, None, None, None, *grads)
+            return (None, None, None, None, None, None, None, *_deposit(ctx.tokens, grads))
         grads = [torch.empty(s, dtype=torch.float32, device=rois.device,
                              memory_format=torch.channels_last).zero_() for s in shapes]
         N, C = shapes[0][:2]
@@ -209,7 +210,7 @@ class _RoIAlignFPN(torch.autograd.Function):
                      0 if dt == torch.float32 else 1, finest_scale, ptr(rois), rois.shape[0], PH, PW,
                      sampling_ratio, aligned, ptr(gout), ptr(order), stream_ptr()), 'oadg_roi_align_bwd')
         grads = [g if dt == torch.float32 else g.to(dt) for g in grads]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *_deposit(ctx.tokens, grads))
 
 
 def roi_align_fpn(feats, rois, out_size, scales, finest_scale=56, sampling_ratio=0, aligned=True):
@@ -217,8 +218,25 @@ def roi_align_fpn(feats, rois, out_size, scales, finest_scale=56, sampling_ratio
     single_level_roi_extractor.py:36-55.  Returns [K,C,PH,PW] (channels_last memory)."""
     if isinstance(out_size, int):
         out_size = (out_size, out_size)
+    tokens = tuple(getattr(f, '_oadg_token', None) for f in feats)
     return _RoIAlignFPN.apply(rois, tuple(out_size), tuple(scales), finest_scale, sampling_ratio,
-                              aligned, *feats)
+                              aligned, tokens if any(t is not None for t in tokens) else None, *feats)
+
+
+def _deposit(tokens, grads):
+    """A map whose gradient another operation finishes (hip_conv.GradToken armed by the RPN convolution's forward and
+    not yet closed): leave this part on the token - that launch adds it in its epilogue - and return nothing."""
+    if tokens is None:
+        return grads
+    from . import hip_conv
+    out = []
+    for tok, g in zip(tokens, grads):
+        if tok is not None and hip_conv.DEPOSIT and tok.armed and not tok.closed and g.dtype == torch.bfloat16:
+            tok.extra = g if tok.extra is None else tok.extra + g
+            out.append(None)
+        else:
+            out.append(g)
+    return out
 
 
 # ------------------------------------------------------------------------------- FPN top-down

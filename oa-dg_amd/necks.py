@@ -56,6 +56,23 @@ class FPN(nn.Module):
             return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok)
         return conv(x)
 
+    @staticmethod
+    def _fpn_conv(conv, x, token):
+        # an output level is read by the RPN convolution and by RoIAlign: the RPN convolution's data gradient finishes
+        # the level's gradient (RoIAlign deposits its part on the token, hip_ops.roi_align_fpn) and hands this
+        # convolution its bias gradient as the column sums of that launch.  Not for the level the extra levels are
+        # subsampled from (a third consumer).
+        from . import hip_conv
+        if token and not (conv.with_norm or conv.with_activation) and hip_conv.ENABLED and x.is_cuda and \
+                torch.is_grad_enabled() and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
+            c = conv.conv
+            tok = hip_conv.GradToken(masked=False)
+            y = layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, out_token=tok)
+            if getattr(y.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
+                y._oadg_token = tok
+            return y
+        return conv(x)
+
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
         laterals = [self._lateral(conv, inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
@@ -70,7 +87,7 @@ class FPN(nn.Module):
             else:
                 laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                                   **self.upsample_cfg)
-        outs = [self.fpn_convs[i](laterals[i]) for i in range(n)]
+        outs = [self._fpn_conv(self.fpn_convs[i], laterals[i], token=i < n - 1 or self.num_outs == n) for i in range(n)]
         for _ in range(self.num_outs - len(outs)):   # fpn.py:184-188
             # fpn.py:177-181 `F.max_pool2d(outs[-1], 1, stride=2)`: a kernel-1 pool is a strided subsample - the same
             # values without the pooling library (whose kernels are compiled per shape)

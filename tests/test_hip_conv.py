@@ -431,6 +431,68 @@ def test_stage_output_gradients_deposited_in_dgrad_epilogues(dev, monkeypatch):
         hip_conv.enable(False)
 
 
+def test_fpn_level_gradients_finished_by_the_rpn_convolution(dev, monkeypatch):
+    """An FPN output level is read by the RPN convolution and by RoIAlign.  With hip_conv.DEPOSIT RoIAlign's backward
+    leaves its gradient map on the level's GradToken, the RPN convolution's data gradient adds it in its epilogue and
+    hands the FPN convolution its bias gradient as column sums (no ReLU mask: GradToken(masked=False)); against
+    autograd's accumulation (DEPOSIT off): same parameter gradients up to bf16 rounding of the sums, and the level the
+    extra level is subsampled from (a third consumer) keeps the plain path."""
+    from oadg_amd import hip_conv, hip_ops
+    from oadg_amd.necks import FPN
+    from oadg_amd.dense_heads import RPNHead
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(0)
+        neck = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)
+        neck.init_weights()
+        head = RPNHead(in_channels=256, feat_channels=256,
+                       anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0],
+                                             strides=[4, 8, 16, 32, 64]),
+                       bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0.0] * 4, target_stds=[1.0] * 4),
+                       loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                       loss_bbox=dict(type='L1Loss', loss_weight=1.0))
+        head.init_weights()
+        net = torch.nn.ModuleList([neck, head]).to(dev).to(memory_format=torch.channels_last)
+        g = torch.Generator(device=dev).manual_seed(1)
+        H, W = 128, 192
+        feats = [torch.randn(2, c, H // s, W // s, device=dev, generator=g).bfloat16().contiguous(
+            memory_format=torch.channels_last).requires_grad_(True) for c, s in zip((256, 512, 1024, 2048), (4, 8, 16, 32))]
+        rs = np.random.RandomState(0)
+        x1 = rs.uniform(0, W - 40, 96); y1 = rs.uniform(0, H - 40, 96)
+        rois = torch.tensor(np.stack([rs.randint(0, 2, 96), x1, y1, x1 + rs.uniform(4, 120, 96), y1 + rs.uniform(4, 100, 96)], 1),
+                            dtype=torch.float32, device=dev)
+        res = {}
+        for mode in ('deposit', 'accumulate'):
+            monkeypatch.setattr(hip_conv, 'DEPOSIT', mode == 'deposit')
+            net.zero_grad(set_to_none=True)
+            for f in feats:
+                f.grad = None
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                outs = neck(feats)
+                toks = [getattr(o, '_oadg_token', None) for o in outs]
+                cls, reg = head(outs)
+                pooled = hip_ops.roi_align_fpn(list(outs[:4]), rois, 7, [1 / 4., 1 / 8., 1 / 16., 1 / 32.])
+            loss = sum((c.float() ** 2).mean() + (r.float() ** 2).mean() for c, r in zip(cls, reg)) + \
+                (pooled.float() ** 2).mean() * 50
+            loss.backward()
+            res[mode] = ({n: p.grad.float().clone() for n, p in net.named_parameters()}, [f.grad.float().clone() for f in feats],
+                         toks)
+        toks = res['deposit'][2]
+        assert [t is not None for t in toks] == [True, True, True, False, False]     # P5 feeds P6: plain path
+        assert all(t.closed and t.extra is None for t in toks[:3])
+
+        def close(a, b, what):
+            d = (a - b).abs()
+            assert d.max().item() <= 3e-2 * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
+            assert d.mean().item() <= 8e-3 * b.abs().mean().item() + 1e-7, (what, d.mean().item(), b.abs().mean().item())
+        for n in res['accumulate'][0]:
+            close(res['deposit'][0][n], res['accumulate'][0][n], n)
+        for i, (a, b) in enumerate(zip(res['deposit'][1], res['accumulate'][1])):
+            close(a, b, f'C{i + 2}')
+    finally:
+        hip_conv.enable(False)
+
+
 def test_rpn_head_fused_cls_reg_matches_separate_convs(dev):
     """rpn_cls + rpn_reg as one zero-padded 1x1 conv on the MFMA kernel (with the GradToken hand-off to rpn_conv)
     against the module-by-module path through the library convolutions: outputs and every parameter gradient."""
