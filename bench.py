@@ -270,6 +270,18 @@ def main():
                                            'ms_per_step': round(sum(r[0] for r in v) / a.steps, 2),
                                            'achieved': round(sum(r[1] for r in v) / sum(r[0] for r in v) / 1e9, 1)}
                                        for k, v in per_kernel.items() if k != name}}
+        # the family mixes shapes (3x3 at P2 ... P4 / layer3 and a few HBM-bound 1x1 launches): its heaviest shape alone
+        shp_ = {}
+        for t in conv_timers:
+            if t[4] == name:
+                e = shp_.setdefault(t[5], [0, 0.0, 0.0])
+                e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]
+        if shp_:
+            k_, e = max(shp_.items(), key=lambda kv: kv[1][1])
+            roof['heaviest_shape'] = {'N,H,W,C,K,R,stride': list(k_[:7]), 'launches_per_step': round(e[0] / a.steps, 1),
+                                      'avg_launch_ms': round(e[1] / e[0], 4),
+                                      'achieved': round(e[2] / e[1] / 1e9, 1),
+                                      'frac': round(e[2] / e[1] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
         roof.update(pmc_traffic(name))
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':      # per-shape table of the conv launches (stderr)
             shp = {}
