@@ -1222,9 +1222,16 @@ __device__ __forceinline__ bf16x8 tr_frag16(const unsigned char* half, int pix0,
     return out;
 }
 
+// Loader state of one K-tile (64-pixel chunk).  Everything a stage needs per piece is carried incrementally - the
+// input offset of the piece's pixel and its tap coordinates - so that a load phase issues adds and compares only: with
+// the offsets recomputed from (n, ho, wo) every time (seven quarter-rate 32-bit multiplies and two 64-bit multiply-adds
+// per x piece) the load phase of one wave group was longer than the 32-MFMA phase of its partner (round-2 ISA count:
+// 84 + 61 + 30 VALU per K-tile against 30 + 28 in the forward kernel).
 struct PixState {
-    long ch;              // K-tile (64-pixel chunk) index
-    int n[2], ho[2], wo[2];
+    long ch;              // K-tile (64-pixel chunk) index (uniform)
+    int ho[2], wo[2];     // output pixel of the piece's row
+    int hi[2], wi[2];     // its input coordinates for this workgroup's tap
+    long xoff[2];         // element offset of input pixel (n, ho * stride, wo * stride)
 };
 
 __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
@@ -1263,6 +1270,22 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
         lslot[i] = (q & 15) ^ (((lrow[i] & 3) << 2) | (((lrow[i] >> 3) & 1) << 1));
     }
     const int adv_h = WP / a.Wo, adv_w = WP - adv_h * a.Wo;     // 64 pixels = adv_h rows + adv_w columns
+    // element strides of x per output column / output row / image, and what one chunk / one wrap adds (uniform)
+    const long dW = (long)a.stride * a.C, dH = (long)a.stride * a.W * a.C, dN = (long)a.H * a.W * a.C;
+    const long add_chunk = adv_w * dW + adv_h * dH, add_wrap_w = dH - a.Wo * dW, add_wrap_h = dN - a.Ho * dH;
+    const int hi_chunk = adv_h * a.stride, wi_chunk = adv_w * a.stride, wi_wrap = a.Wo * a.stride, hi_wrap = a.Ho * a.stride;
+    const long chunk_dy = (long)WP * a.K;
+    // per-piece bases: the tap offset and the channel slot are folded into the pointers (integer arithmetic: a tap
+    // offset may point before x for pieces whose bounds test fails - those read the zero line)
+    uintptr_t xb[2], dyb[2];
+    {
+        const long toff = ((long)(r * a.dil - a.pad) * a.W + (s * a.dil - a.pad)) * a.C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xb[i] = (uintptr_t)a.x + (uintptr_t)((toff + c0 + lslot[i] * 8) * 2);
+            dyb[i] = (uintptr_t)(a.dy + (size_t)lrow[i] * a.K + k0 + lslot[i] * 8);
+        }
+    }
     auto init_state = [&](PixState& st, long ch) {
         st.ch = ch;
 #pragma unroll
@@ -1271,39 +1294,50 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
             st.wo[i] = (int)(p % a.Wo);
             const long t = p / a.Wo;
             st.ho[i] = (int)(t % a.Ho);
-            st.n[i] = (int)(t / a.Ho);
+            const long n = t / a.Ho;
+            st.hi[i] = st.ho[i] * a.stride - a.pad + r * a.dil;
+            st.wi[i] = st.wo[i] * a.stride - a.pad + s * a.dil;
+            st.xoff[i] = n * dN + st.ho[i] * dH + st.wo[i] * dW;
         }
     };
     auto advance = [&](PixState& st) {
         st.ch++;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            st.wo[i] += adv_w;
-            st.ho[i] += adv_h;
-            if (st.wo[i] >= a.Wo) { st.wo[i] -= a.Wo; ++st.ho[i]; }
-            while (st.ho[i] >= a.Ho) { st.ho[i] -= a.Ho; ++st.n[i]; }
+            st.wo[i] += adv_w; st.wi[i] += wi_chunk;
+            st.ho[i] += adv_h; st.hi[i] += hi_chunk;
+            st.xoff[i] += add_chunk;
+            if (st.wo[i] >= a.Wo) {
+                st.wo[i] -= a.Wo; st.wi[i] -= wi_wrap;
+                ++st.ho[i]; st.hi[i] += a.stride;
+                st.xoff[i] += add_wrap_w;
+            }
+            while (st.ho[i] >= a.Ho) {          // next image (several for maps smaller than a chunk)
+                st.ho[i] -= a.Ho; st.hi[i] -= hi_wrap;
+                st.xoff[i] += add_wrap_h;
+            }
         }
     };
     auto stage_dy = [&](int h, const PixState& st, int buf) {
         unsigned char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
+        const long left = a.P - st.ch * WP;                       // pixels from this chunk's first to the end (uniform)
+        const int rows = st.ch < ch1 ? (left < WP ? (int)left : WP) : 0;
+        const uintptr_t off = (uintptr_t)(st.ch * chunk_dy + h * 128) * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long p = st.ch * WP + lrow[i];
-            const unsigned short* src = (st.ch < ch1 && p < a.P)
-                                            ? a.dy + (size_t)p * a.K + k0 + h * 128 + lslot[i] * 8 : a.zeros;
-            glds16(src, dst + i * 8192);
+            const uintptr_t src = lrow[i] < rows ? dyb[i] + off : (uintptr_t)a.zeros;
+            glds16((const void*)src, dst + i * 8192);
         }
     };
     auto stage_x = [&](int h, const PixState& st, int buf) {
         unsigned char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
+        const long left = a.P - st.ch * WP;
+        const int rows = st.ch < ch1 ? (left < WP ? (int)left : WP) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const long p = st.ch * WP + lrow[i];
-            const int hi = st.ho[i] * a.stride - a.pad + r * a.dil, wi = st.wo[i] * a.stride - a.pad + s * a.dil;
-            const bool ok = st.ch < ch1 && p < a.P && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const unsigned short* src =
-                ok ? a.x + (((size_t)st.n[i] * a.H + hi) * a.W + wi) * a.C + c0 + h * 128 + lslot[i] * 8 : a.zeros;
-            glds16(src, dst + i * 8192);
+            const bool ok = lrow[i] < rows && (unsigned)st.hi[i] < (unsigned)a.H && (unsigned)st.wi[i] < (unsigned)a.W;
+            const uintptr_t src = ok ? xb[i] + (uintptr_t)((st.xoff[i] + h * 128) * 2) : (uintptr_t)a.zeros;
+            glds16((const void*)src, dst + i * 8192);
         }
     };
 
@@ -1442,31 +1476,27 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
 }
 
 // Kernel / split choice (tools/bench_conv.py --wgrad sweeps it; times vs MIOpen's igemm_wrw on MI355X):
-//  - K and C multiples of 256, 3x3 with >= 16 K-tiles per workgroup or 1x1 over >= 200k pixels: the 256-tile phase
-//    pipeline (1.2x at P2, 1.1x at P3; round 2: also layer3 / layer4 / P4 3x3 and the P2 / P3 lateral 1x1, 1.4-1.6x);
+//  - K and C multiples of 256 and >= 8 K-tiles per workgroup at one round of workgroups: the 256-tile phase pipeline
+//    (round 2, with the incremental loader: 1000-1115 TFLOP/s on the 3x3 layers from P2 to layer4, 45 us against 63 on
+//    the 1x1 layers of layer3 / layer4);
 //  - other 3x3: 128-tile, ONE LDS stage at 4 workgroups per CU, ~1024 workgroups (1.06-1.2x);
 //  - 1x1: 128-tile, two stages, ~512 workgroups - the fp32 partial tiles (splits x K x C x 4 bytes, written and read
 //    back by the reduction) are the cost that matters there (1.15x on layer2, 1.6x on layer3 / layer4).
-// One workgroup of the 256-tile kernel per CU.  Large reductions (>= 128 K-tiles per workgroup at two rounds): ~512
-// workgroups; otherwise ONE round of <= 256 - half the partial tiles to write and read back, and the shapes with 36
-// K-tiles per workgroup (layer3 / layer4 / P4 3x3) still run at 780-810 TFLOP/s against 530-580 on the 128-tile
-// kernel, whose single-stage workgroups spend half their time waiting for L2 (tools/probe/wgrad_lab.hip).
+// One workgroup of the 256-tile kernel per CU, ONE round of <= 256 workgroups: half the partial tiles of two rounds to
+// write and read back, and since the loader carries its addresses incrementally (round 2) one round is as fast as two
+// on every shape (P2 3x3: 1109 us with 24 splits against 1125 with 56; P3: 293 / 303; layer3 / P4: 85 / 90).  Split
+// counts >= 8 are rounded down to a multiple of 8: the taps of a pixel range then share an XCD (and its L2).
 long wgrad256_splits(long P, int K, int C, int RS) {
     const long tiles = (long)(K / 256) * (C / 256) * RS;
-    const long nchunks = (P + WP - 1) / WP;
-    long s = (512 + tiles - 1) / tiles;
+    long s = 256 / tiles;
+    if (s >= 8) s = s / 8 * 8;
     if (s < 1) s = 1;
-    if (nchunks / s < 128) s = 256 / tiles;
-    if (s >= 8 && s * tiles > 256) s = s / 8 * 8;
-    if (s < 1) s = 1;
-    if (s > 256) s = 256;
     return s;
 }
 bool wgrad_use256(long P, int K, int C, int RS) {
     if (K % 256 != 0 || C % 256 != 0) return false;
     const long nchunks = (P + WP - 1) / WP;
-    if (RS == 1) return P >= 200000;           // the 1x1 layers of layer3 / layer4 gain less than the extra partials cost
-    return nchunks / wgrad256_splits(P, K, C, RS) >= 16;
+    return nchunks / wgrad256_splits(P, K, C, RS) >= 8;      // at least 8 K-tiles per workgroup
 }
 int wgrad_stages(int RS) { return RS > 1 ? 1 : 2; }
 

@@ -112,6 +112,28 @@ def main():
         for (name, shp), n in sorted(big.items(), key=lambda kv: -kv[1]):
             print(f'{n:4d} {name:28s} {shp}')
         return
+    if '--copies' in sys.argv:
+        # dtype / layout copies (aten::_to_copy, aten::clone, aten::contiguous, aten::copy_) of >= 256k elements per step
+        from torch.profiler import ProfilerActivity, profile
+        import collections
+        with profile(activities=[ProfilerActivity.CPU], record_shapes=True) as p:
+            data = nxt.get()
+            eng.step(data)
+            torch.cuda.synchronize()
+        agg = collections.Counter()
+        for e in p.events():
+            if e.name in ('aten::_to_copy', 'aten::clone', 'aten::contiguous', 'aten::copy_'):
+                n = 0
+                for shp in (e.input_shapes or []):
+                    m = 1
+                    for d in (shp or [0]):
+                        m *= d
+                    n = max(n, m)
+                if n >= 262144:
+                    agg[(e.name, str(e.input_shapes)[:80])] += 1
+        for (name, shp), n in sorted(agg.items(), key=lambda kv: -kv[1]):
+            print(f'{n:4d} {name:18s} {shp}')
+        return
     if '--torchprof' in sys.argv:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p:
