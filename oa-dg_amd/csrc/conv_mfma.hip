@@ -1097,54 +1097,101 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_wgrad_kernel(Wgr
     const long ch0 = (long)split * a.chunks_per_split;
     const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
 
-    // per-thread loader state: the 4 pieces a thread fetches per tile sit on rows (i*256 + tid) >> 4; their
-    // (n, ho, wo) is decomposed once and advanced by 64 pixels per chunk (no per-chunk divisions)
-    int ln[4], lho[4], lwo[4], lslot[4], lrow[4];
+    // per-thread loader state: the 4 pieces a thread fetches per tile sit on rows (i*256 + tid) >> 4.  Their pixel is
+    // decomposed once; per chunk the input offset and the tap coordinates advance by additions only (round 2: the
+    // per-chunk 64-bit multiplies - 48 multiply instructions among 200 VALU per 16 MFMAs - made these kernels
+    // VALU-bound at 430-550 TFLOP/s), and the dy offset is a uniform scalar.
+    // State per piece: tap coordinates (hi, wi) and the input offset.  Row i*16 + tid/16 and the swizzled slot
+    // (tid & 15) ^ ((row & 3) << 2) - the same for the four pieces - give one x base and one dy base per thread.
+    int lhi[4], lwi[4];
+    unsigned lxoff[4];          // element offsets into x, modulo 2^32 (the host checks N*H*W*C < 2^32)
+    const int lrow0 = tid >> 4;
+    const long dW = (long)a.stride * a.C, dH = (long)a.stride * a.W * a.C, dN = (long)a.H * a.W * a.C;
+    uintptr_t xb, dyb0;
     {
         const long pbase = ch0 * WP;
+        const long toff = ((long)(r * a.dil - a.pad) * a.W + (s * a.dil - a.pad)) * a.C;
+        const int lslot = (tid & 15) ^ ((lrow0 & 3) << 2);
+        xb = (uintptr_t)a.x + (uintptr_t)((toff + c0 + lslot * 8) * 2);
+        dyb0 = (uintptr_t)(a.dy + (size_t)lrow0 * a.K + k0 + lslot * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = i * 256 + tid;
-            lrow[i] = q >> 4;
-            lslot[i] = (q & 15) ^ ((lrow[i] & 3) << 2);
-            const long p = pbase + lrow[i];
+            const long p = pbase + lrow0 + i * 16;
+            long n;
+            int ho, wo;
             if (p <= 0x7fffffffL) {                    // 32-bit divisions (a fraction of the 64-bit sequences)
                 const unsigned t = (unsigned)p / (unsigned)a.Wo;
-                lwo[i] = (int)((unsigned)p - t * (unsigned)a.Wo);
-                ln[i] = (int)(t / (unsigned)a.Ho);
-                lho[i] = (int)(t - (unsigned)ln[i] * (unsigned)a.Ho);
+                wo = (int)((unsigned)p - t * (unsigned)a.Wo);
+                n = t / (unsigned)a.Ho;
+                ho = (int)(t - (unsigned)n * (unsigned)a.Ho);
             } else {
-                lwo[i] = (int)(p % a.Wo);
+                wo = (int)(p % a.Wo);
                 const long t = p / a.Wo;
-                lho[i] = (int)(t % a.Ho);
-                ln[i] = (int)(t / a.Ho);
+                ho = (int)(t % a.Ho);
+                n = t / a.Ho;
             }
+            lhi[i] = ho * a.stride - a.pad + r * a.dil;
+            lwi[i] = wo * a.stride - a.pad + s * a.dil;
+            lxoff[i] = (unsigned)(n * dN + ho * dH + wo * dW);
         }
     }
     const int adv_h = WP / a.Wo, adv_w = WP - adv_h * a.Wo;     // 64 pixels = adv_h rows + adv_w columns
+    const unsigned add_chunk = (unsigned)(adv_w * dW + adv_h * dH), add_wrap_w = (unsigned)(dH - a.Wo * dW),
+                   add_wrap_h = (unsigned)(dN - a.Ho * dH);
+    const int hi_chunk = adv_h * a.stride, wi_chunk = adv_w * a.stride, wi_wrap = a.Wo * a.stride, hi_wrap = a.Ho * a.stride;
+    // wo >= Wo <=> wi >= wi_lim, ho >= Ho <=> hi >= hi_lim (the tap shift is the same on both sides)
+    const int wi_lim = wi_wrap - a.pad + s * a.dil, hi_lim = hi_wrap - a.pad + r * a.dil;
+    const long chunk_dy = (long)WP * a.K, row16_dy = 16L * a.K;
 
     auto stage = [&](long ch, int buf) {
         unsigned char* sa = smem + buf * WSTAGE;        // dy tile [64][128]
         unsigned char* sb = sa + WP * 256;              // x tile  [64][128]
+        const long left = a.P - ch * WP;
+        const int rows = left < WP ? (int)left : WP;    // (uniform) valid rows of this chunk
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long p = ch * WP + lrow[i];
-            const unsigned short* sdy = a.zeros;
-            const unsigned short* sx = a.zeros;
-            if (p < a.P) {
-                sdy = a.dy + (size_t)p * a.K + k0 + lslot[i] * 8;
-                const int hi = lho[i] * a.stride - a.pad + r * a.dil, wi = lwo[i] * a.stride - a.pad + s * a.dil;
-                if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-                    sx = a.x + (((size_t)ln[i] * a.H + hi) * a.W + wi) * a.C + c0 + lslot[i] * 8;
-            }
-            glds16(sdy, sa + i * 4096 + wave * 1024);
-            glds16(sx, sb + i * 4096 + wave * 1024);
+            const bool in = lrow0 + i * 16 < rows;
+            const bool ok = in && (unsigned)lhi[i] < (unsigned)a.H && (unsigned)lwi[i] < (unsigned)a.W;
+            const uintptr_t sdy = in ? dyb0 + (uintptr_t)((ch * chunk_dy + i * row16_dy) * 2) : (uintptr_t)a.zeros;
+            const uintptr_t sx = ok ? xb + ((uintptr_t)lxoff[i] << 1) : (uintptr_t)a.zeros;
+            glds16((const void*)sdy, sa + i * 4096 + wave * 1024);
+            glds16((const void*)sx, sb + i * 4096 + wave * 1024);
             // advance this row's pixel by one chunk
-            lwo[i] += adv_w;
-            lho[i] += adv_h;
-            if (lwo[i] >= a.Wo) { lwo[i] -= a.Wo; ++lho[i]; }
-            while (lho[i] >= a.Ho) { lho[i] -= a.Ho; ++ln[i]; }
+            lwi[i] += wi_chunk;
+            lhi[i] += hi_chunk;
+            lxoff[i] += add_chunk;
+            if (lwi[i] >= wi_lim) {
+                lwi[i] -= wi_wrap;
+                lhi[i] += a.stride;
+                lxoff[i] += add_wrap_w;
+            }
+            while (lhi[i] >= hi_lim) {
+                lhi[i] -= hi_wrap;
+                lxoff[i] += add_wrap_h;
+            }
         }
+    };
+    // fragment addresses: row & 3 and the channel term do not depend on the k-step or on which 4-pixel half is read, so
+    // one byte offset per 32-channel fragment is precomputed and every ds_read_b64_tr_b16 is base + immediate
+    int faoff[2], fboff[2];
+    {
+        const int g = lane >> 4, s16 = lane & 15;
+        const int rowb = (g >> 1) * 8 + (s16 >> 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ca = wm * 64 + i * 32 + (g & 1) * 16 + (s16 & 3) * 4, cb = wn * 64 + i * 32 + (g & 1) * 16 + (s16 & 3) * 4;
+            faoff[i] = rowb * 256 + (((ca >> 3) ^ ((rowb & 3) << 2)) << 4) + (ca & 7) * 2;
+            fboff[i] = rowb * 256 + (((cb >> 3) ^ ((rowb & 3) << 2)) << 4) + (cb & 7) * 2;
+        }
+    }
+    auto frag = [&](const unsigned char* tile, int off, int t) -> bf16x8 {
+        bf16x8 out;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const v4s rr = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(tile + off + (t * 16 + u * 4) * 256));
+            out[u * 4 + 0] = rr[0]; out[u * 4 + 1] = rr[1]; out[u * 4 + 2] = rr[2]; out[u * 4 + 3] = rr[3];
+        }
+        return out;
     };
 
     f32x16 acc[2][2];
@@ -1168,9 +1215,9 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_wgrad_kernel(Wgr
             for (int t = 0; t < WP / 16; ++t) {
                 bf16x8 fa[2], fb[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = tr_frag(sa, t * 16, wm * 64 + i * 32, lane);
+                for (int i = 0; i < 2; ++i) fa[i] = frag(sa, faoff[i], t);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = tr_frag(sb, t * 16, wn * 64 + j * 32, lane);
+                for (int j = 0; j < 2; ++j) fb[j] = frag(sb, fboff[j], t);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1527,6 +1574,7 @@ int wgrad_launch(const void* x, const void* dy, float* dw, const void* zeros16, 
                  int* splits_out, void* stream) {
     if (!x || !dy || !zeros16 || !workspace) return OADG_EARG;
     if (C % 128 != 0 || K % 128 != 0 || N < 1 || R < 1 || S < 1) return OADG_EARG;
+    if ((double)N * H * W * C >= 4294967296.0) return OADG_EARG;      // the 128-tile loader keeps 32-bit element offsets
     WgradArgs a;
     a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.part = (float*)workspace;
     a.zeros = (const unsigned short*)zeros16;

@@ -455,7 +455,7 @@ class _Conv2dMFMA(torch.autograd.Function):
                 gx = conv_forward(gy, wt, None, None, 1, dil * (R - 1) - pad, dil, False)
             need_x = False
         gw = None
-        if need_w and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
+        if need_w and x16.numel() < 2 ** 32 and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
             wtok = ctx.wtoken
             if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
                 wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
