@@ -173,39 +173,50 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
                 ho = (int)(t % a.Ho);
                 n = (int)(t / a.Ho);
             }
-            a_base[i] = a.x + (size_t)n * a.H * a.W * a.C;
             a_hi0[i] = ho * a.stride - a.pad;
             a_wi0[i] = wo * a.stride - a.pad;
+            // the piece's pixel at tap (0, 0) with its channel slot (integer arithmetic: padding may put it before x -
+            // such taps fail the bounds test and read the zero line)
+            a_base[i] = a.x + ((long)n * a.H * a.W + (long)a_hi0[i] * a.W + a_wi0[i]) * a.C + seg[i] * 8;
         } else {
             a_base[i] = nullptr;
-            a_hi0[i] = a_wi0[i] = 0;
+            a_hi0[i] = -(1 << 28);                  // fails every bounds test
+            a_wi0[i] = 0;
         }
-        b_base[i] = a.w + (size_t)(k0 + (row < TBN ? row : 0)) * a.R * a.S * a.C;
+        b_base[i] = a.w + (size_t)(k0 + (row < TBN ? row : 0)) * a.R * a.S * a.C + seg[i] * 8;
     }
 
+    // chunk-major K order (taps inner): the R*S taps of a 128-byte input line follow each other, see the 256-tile kernel.
+    // The stages are issued in chunk order, so tap and channel chunk are counters and a stage adds one uniform offset per
+    // operand to the per-piece bases (round 2: divisions by R*S / S and 64-bit multiplies per piece made the loop of the
+    // 3x3 launches as long in VALU + SALU issue as in MFMA cycles).
+    int st_r = 0, st_s = 0, st_rs = 0, st_c0 = 0;
     auto stage = [&](int kc, int buf) {
-        // chunk-major K order (taps inner): the R*S taps of a 128-byte input line follow each other, see the 256-tile kernel
-        const int RS = a.R * a.S;
-        const int cc = PW ? kc : kc / RS, rs = PW ? 0 : kc - cc * RS, c0 = cc * BK;
-        const int r = PW ? 0 : rs / a.S, s = rs - r * a.S;
         unsigned char* sa = smem + buf * TSTAGE;
         unsigned char* sb = sa + BM * BK * 2;
+        if (PW) {
+            const int c0 = kc * BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds16(a_base[i] ? a_base[i] + c0 + seg[i] * 8 : a.zeros, sa + i * 4096 + wave * 1024);
+#pragma unroll
+            for (int i = 0; i < NBP; ++i) glds16(b_base[i] + c0, sb + i * 4096 + wave * 1024);
+            return;
+        }
+        const int dr = st_r * a.dil, ds = st_s * a.dil;
+        const long aoff = ((long)dr * a.W + ds) * a.C + st_c0;           // uniform
+        const long boff = (long)st_rs * a.C + st_c0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned short* src;
-            if (PW) {
-                src = a_base[i] ? a_base[i] + c0 + seg[i] * 8 : a.zeros;
-            } else {
-                const int hi = a_hi0[i] + r * a.dil, wi = a_wi0[i] + s * a.dil;
-                const bool ok = a_base[i] != nullptr && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-                src = ok ? a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0 + seg[i] * 8 : a.zeros;
-            }
-            glds16(src, sa + i * 4096 + wave * 1024);
+            const bool ok = (unsigned)(a_hi0[i] + dr) < (unsigned)a.H && (unsigned)(a_wi0[i] + ds) < (unsigned)a.W;
+            glds16(ok ? a_base[i] + aoff : a.zeros, sa + i * 4096 + wave * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < NBP; ++i) {
-            const unsigned short* src = b_base[i] + (size_t)rs * a.C + c0 + seg[i] * 8;
-            glds16(src, sb + i * 4096 + wave * 1024);
+        for (int i = 0; i < NBP; ++i) glds16(b_base[i] + boff, sb + i * 4096 + wave * 1024);
+        ++st_rs;
+        if (++st_s == a.S) {
+            st_s = 0;
+            if (++st_r == a.R) { st_r = 0; st_rs = 0; st_c0 += BK; }
         }
     };
 
