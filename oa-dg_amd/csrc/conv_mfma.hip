@@ -59,6 +59,11 @@ __device__ __forceinline__ long out_row(const ConvArgs& a, long m) {
 
 // Last step of both epilogues for one 16-byte piece (8 channels of a pixel): residual add, ReLU, ReLU-backward
 // mask, bf16 rounding, and the running column sums of what is stored.
+// The operands are run-time (uniform) flags.  `OADG_UNIFORM_BRANCH` keeps each block behind a real scalar branch: left
+// alone the compiler if-converts them - it computed the ReLU select, the column sums and the (y > 0) bits of EVERY
+// piece and threw the results away with v_cndmask (round-2 ISA count: 191 selects + 64 compares + 96 adds per two
+// sub-tiles of the streaming kernel with only a residual operand).
+#define OADG_UNIFORM_BRANCH() asm volatile("" ::: "memory")
 template <bool POST>
 __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, const bf16x8 rv, const bf16x8 mv,
                                                float* csum, unsigned mbits = 0xffu, size_t off = 0) {
@@ -67,18 +72,23 @@ __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = bf16_to_f32((unsigned short)v[e]);
         if (a.res) {
+            OADG_UNIFORM_BRANCH();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                f[e] += bf16_to_f32((unsigned short)rv[e]);
-                if (a.relu) f[e] = fmaxf(f[e], 0.f);
+            for (int e = 0; e < 8; ++e) f[e] += bf16_to_f32((unsigned short)rv[e]);
+            if (a.relu) {
+                OADG_UNIFORM_BRANCH();
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
             }
         }
         if (a.mask) {
+            OADG_UNIFORM_BRANCH();
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (!(bf16_to_f32((unsigned short)mv[e]) > 0.f)) f[e] = 0.f;
         }
         if (a.bits_in) {
+            OADG_UNIFORM_BRANCH();
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (!((mbits >> e) & 1u)) f[e] = 0.f;
@@ -87,10 +97,12 @@ __device__ __forceinline__ bf16x8 finish_piece(const ConvArgs& a, bf16x8 v, cons
         for (int e = 0; e < 8; ++e) v[e] = (short)f32_to_bf16(f[e]);
     }
     if (a.colsum) {
+        OADG_UNIFORM_BRANCH();
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[e] += bf16_to_f32((unsigned short)v[e]);
     }
     if (a.bits_out) {
+        OADG_UNIFORM_BRANCH();
         unsigned b = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) b |= (bf16_to_f32((unsigned short)v[e]) > 0.f ? 1u : 0u) << e;
@@ -425,14 +437,16 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
         }
         // epilogue pieces of this lane: pixel lane / 8 + 8 * jj, 16-byte slot lane % 8 of the wave's 64 channels
         const int ppx = lane >> 3, psl = lane & 7;
+        // element offset of a piece = (uniform) sub-tile and piece-row terms + this lane's term: no vector multiplies
+        const size_t lane_off = (size_t)ppx * a.K + kcol + psl * 8;
+        const size_t sub_stride = (size_t)SP * a.K, row8 = (size_t)8 * a.K;
         bf16x8 rv[2][NP];
         unsigned mb[2][NP];
         auto request = [&](long sub, int set) {     // residual / mask bits of sub-tile `sub` -> register set `set`
             if (!POST) return;
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                const long m = sub < n_sub ? sub * SP + ppx + 8 * jj : 0;       // past the end: any valid row
-                const size_t off = (size_t)m * a.K + kcol + psl * 8;
+                const size_t off = (sub < n_sub ? (size_t)sub * sub_stride + jj * row8 : 0) + lane_off;   // past the end: any valid row
                 // asm: the compiler must not see these loads, or it would wait for ALL vector memory (the LDS-DMA
                 // prefetches included) at their first use
                 if (RES) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[set][jj]) : "v"(a.res + off) : "memory");
@@ -500,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
             for (int jj = 0; jj < NP; ++jj) {
                 const int px = ppx + 8 * jj;
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + px * STG_STRIDE + psl * 16);
-                const size_t off = (size_t)(sub * SP + px) * a.K + kcol + psl * 8;
+                const size_t off = (size_t)sub * sub_stride + jj * row8 + lane_off;
                 v = finish_piece<POST>(a, v, RES ? rv[set][jj] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0},
                                        csum, BIN ? mb[set][jj] : 0xffu, off);
                 asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.y + off), "v"(v) : "memory");

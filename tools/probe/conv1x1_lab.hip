@@ -177,200 +177,7 @@ __global__ __launch_bounds__(256) void stream_kernel(ConvArgs a) {
 }
 
 
-// ================================================================================== weights-stationary pointwise kernel
-// Persistent workgroups (256 threads, 2 per CU).  Wave v keeps the weights of 64 output channels x C in REGISTERS
-// (MFMA A operand, v_mfma_f32_16x16x32_bf16 with channels on the rows); pixels stream through an LDS ring of
-// 32-pixel sub-tiles filled by global_load_lds (NS - 1 sub-tiles ahead); residual / mask-bit operands are requested
-// one sub-tile ahead into registers; stores follow.  Every memory stream of the launch is in flight while the MFMAs run.
-template <int C>
-struct PwGeo {
-    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = 4, NP = SP / 8, SLOTS = C / 8, SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
-    static constexpr int RT = KPW / 16, CT = SP / 16, KS = C / 32, STG_STRIDE = KPW * 2 + 16, STG_BYTES = SP * STG_STRIDE;
-    static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES + 4 * KPW * 4;
-};
-
-#define PW_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-
-template <int C, bool RES, bool BIN, bool BOUT>
-__global__ __launch_bounds__(256, 2) void conv_pw_ws_kernel(ConvArgs a, int ncol, int per) {
-    using Geo = PwGeo<C>;
-    constexpr int KPW = Geo::KPW, SP = Geo::SP, NS = Geo::NS, SLOTS = Geo::SLOTS, SUB_BYTES = Geo::SUB_BYTES, G = Geo::G;
-    constexpr int RT = Geo::RT, CT = Geo::CT, KS = Geo::KS, STG_STRIDE = Geo::STG_STRIDE, STG_BYTES = Geo::STG_BYTES;
-    constexpr int NP = Geo::NP;
-    constexpr int R = (RES ? NP : 0) + (BIN ? NP : 0), S = NP + (BOUT ? NP : 0);
-    constexpr bool POST = RES || BIN;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long bid = blockIdx.x;
-    const int xcd = (int)(bid & 7), j = (int)(bid >> 3);
-    const int col = j % ncol;
-    const long range = (long)xcd * ((gridDim.x >> 3) / ncol) + j / ncol;
-    const long n_sub = (a.M + SP - 1) / SP;
-    // sub-tile i of this workgroup is number i * ranges + range: at any moment the whole chip works inside one compact
-    // window of the tensors (DRAM page locality), like a grid-stride loop
-    const long ranges = (gridDim.x >> 3) / ncol * 8;
-    if (range >= n_sub) return;
-    const int n_it = (int)((n_sub - range + ranges - 1) / ranges);
-    const long s1 = n_sub;
-    const int kcol = col * (4 * KPW) + wave * KPW;          // this wave's first output channel
-    unsigned char* ring = smem;
-    unsigned char* stg = smem + NS * SUB_BYTES + wave * STG_BYTES;
-
-    // ---- stationary operands
-    const int fr = lane & 15, fq = lane >> 4;
-    bf16x8 wf[RT][KS];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            wf[rt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(kcol + rt * 16 + fr) * C + ks * 32 + fq * 8);
-    float* sbias = reinterpret_cast<float*>(smem + NS * SUB_BYTES + 4 * STG_BYTES) + wave * KPW;   // this wave's 64 biases
-    sbias[lane] = a.bias ? a.bias[kcol + lane] : 0.f;
-
-    // ---- loader geometry (constant over sub-tiles)
-    int goff[G], gpx[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int L = (g * 4 + wave) * 64 + lane;
-        const int px = L / SLOTS, sl = L % SLOTS;
-        const int src = C == 64 ? (sl ^ ((px >> 1) & 7)) : (sl ^ (px & 15));
-        gpx[g] = px;
-        goff[g] = px * C + src * 8;
-    }
-    auto stage = [&](long sub, int slot) {
-        const long m0 = sub * SP;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const bool ok = sub < s1 && m0 + gpx[g] < a.M;
-            const unsigned short* src = ok ? a.x + (size_t)m0 * C + goff[g] : a.zeros;
-            glds16(src, ring + slot * SUB_BYTES + (g * 4 + wave) * 1024);
-        }
-    };
-    // fragment read offsets inside a sub-tile
-    // slot (ks * 4 + fq) ^ f(px) = (ks * 4) ^ (fq ^ f(px)): one base per 16-pixel tile, the k-step is an XOR constant
-    int bbase[CT], bsw[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int px = ct * 16 + fr;
-        bbase[ct] = px * (C * 2);
-        bsw[ct] = (fq ^ (C == 64 ? ((px >> 1) & 7) : (px & 15))) << 4;
-    }
-    // epilogue pieces of this lane: pixel lane/8 + 8*jj, 16-byte slot lane%8 of the wave's 64 channels
-    const int ppx = lane >> 3, psl = lane & 7;
-    bf16x8 rv[2][NP];
-    unsigned mb[2][NP];
-    auto request = [&](long sub, int set) {     // residual / mask bits of sub-tile `sub` -> register set
-        if (!POST) return;
-        const long m0 = sub * SP;
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            long m = m0 + ppx + 8 * jj;
-            if (m >= a.M || sub >= s1) m = 0;
-            const size_t off = (size_t)m * a.K + kcol + psl * 8;
-            if (RES) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[set][jj]) : "v"(a.res + off) : "memory");
-            if (BIN) asm volatile("global_load_ubyte %0, %1, off" : "=v"(mb[set][jj]) : "v"(a.bits_in + (off >> 3)) : "memory");
-        }
-    };
-
-    // ---- prologue
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p) stage(range + p * ranges, p);
-    request(range, 0);
-
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto body = [&](int i, auto set_c) {
-        constexpr int set = decltype(set_c)::value;
-        const long sub = range + i * ranges;
-        if (i < NS - 1) PW_WAIT(0); else PW_WAIT((NS - 2) * G + (NS - 1) * (R + S));
-        asm volatile("s_barrier" ::: "memory");
-        stage(sub + (NS - 1) * ranges, (i + NS - 1) % NS);
-        request(sub + ranges, set ^ 1);
-        const unsigned char* at = ring + (i % NS) * SUB_BYTES;
-        f32x4 acc[RT][CT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 pf[CT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) pf[ct] = *reinterpret_cast<const bf16x8*>(at + bbase[ct] + (bsw[ct] ^ (ks * 64)));
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[rt][ks], pf[ct], acc[rt][ct], 0, 0, 0);
-        }
-        // accumulators -> bf16 rows [pixel][64 channels] in this wave's staging area
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                bf16x4 o;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(sbias + rt * 16 + fq * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[rt][ct][r] + bv[r];
-                    if (a.relu && !RES) v = fmaxf(v, 0.f);
-                    o[r] = (short)f32_to_bf16(v);
-                }
-                *reinterpret_cast<bf16x4*>(stg + (ct * 16 + fr) * STG_STRIDE + (rt * 16 + fq * 4) * 2) = o;
-            }
-        if (POST) {
-            // the operands of THIS sub-tile (requested one iteration ago): everything issued since may stay in flight
-            PW_WAIT(S + G + R);
-#pragma unroll
-            for (int jj = 0; jj < NP; ++jj) {       // ties the operand registers to the wait (no use may move above it)
-                if (RES) asm volatile("" : "+v"(rv[set][jj]));
-                if (BIN) asm volatile("" : "+v"(mb[set][jj]));
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < NP; ++jj) {
-            const int px = ppx + 8 * jj;
-            const long m = sub * SP + px;
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + px * STG_STRIDE + psl * 16);
-            const bool ok = m < a.M;
-            const size_t off = (size_t)(ok ? m : 0) * a.K + kcol + psl * 8;
-            float cs_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            v = finish_piece<POST>(a, v, RES ? rv[set][jj] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0},
-                                   ok ? csum : cs_, BIN ? mb[set][jj] : 0xffu, off);
-            if (ok) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.y + off), "v"(v) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.zeros + 64), "v"(v) : "memory");
-        }
-    };
-    for (int i = 0; i < n_it; i += 2) {
-        body(i, std::integral_constant<int, 0>{});
-        if (i + 1 < n_it) body(i + 1, std::integral_constant<int, 1>{});
-    }
-    if (a.colsum) {     // per-range partial column sums of what was stored: lanes l, l+8, ... share a channel slot
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = csum[e];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
-            csum[e] = t;
-        }
-        if (lane < 8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a.colsum[(size_t)range * a.K + kcol + lane * 8 + e] = csum[e];
-        }
-    }
-}
-
-template <int C, bool RES, bool BIN, bool BOUT>
-void launch_pw(const ConvArgs& a) {
-    using Geo = PwGeo<C>;
-    const int ncol = a.K / 256;
-    const int grid = 512;
-    const long ranges = grid / ncol;
-    const long n_sub = (a.M + Geo::SP - 1) / Geo::SP;
-    const int per = (int)((n_sub + ranges - 1) / ranges);
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv_pw_ws_kernel<C, RES, BIN, BOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo::LDS); attr = true; }
-    hipLaunchKernelGGL((conv_pw_ws_kernel<C, RES, BIN, BOUT>), dim3(grid), dim3(256), Geo::LDS, 0, a, ncol, per);
-}
+// (the weights-stationary persistent kernel developed here is now csrc conv_pw_stream_kernel, variant 4)
 
 template <typename F>
 float time_it(F f, int it) {
@@ -442,12 +249,8 @@ int main(int argc, char** argv) {
             t[4] = run_abl<false, 8>(a, it); t[5] = run_abl<false, 16>(a, it); t[6] = run_abl<false, 17>(a, it); t[7] = run_abl<false, 19>(a, it);
         }
         float tw = 0.f; size_t bad = 0, worse = 0;
-        if ((C == 64 || C == 128 || C == 256) && K % 256 == 0) {
-            auto lw = [&] {
-                if (C == 64) { if (sh.res) launch_pw<64, true, false, false>(a); else launch_pw<64, false, false, false>(a); }
-                else if (C == 128) { if (sh.res && sh.bits) launch_pw<128, true, true, false>(a); else if (sh.res) launch_pw<128, true, false, false>(a); else launch_pw<128, false, false, false>(a); }
-                else { if (sh.res && sh.bits) launch_pw<256, true, true, false>(a); else if (sh.res) launch_pw<256, true, false, false>(a); else launch_pw<256, false, false, false>(a); }
-            };
+        if (pw_stream_ranges((long)M, C, K, 1, 1, 1, 0) > 0) {
+            auto lw = [&] { conv_launch(x, w, nullptr, a.res, y, z, N, H, W, C, K, 1, 1, 1, 0, 1, a.relu, 4, nullptr, nullptr, nullptr, nullptr, a.bits_in, nullptr); };
             std::vector<unsigned short> y0(ny), y1(ny);
             conv_launch(x, w, nullptr, a.res, y, z, N, H, W, C, K, 1, 1, 1, 0, 1, a.relu, 3, nullptr, nullptr, nullptr, nullptr, a.bits_in, nullptr);
             hipMemcpy(y0.data(), y, ny * 2, hipMemcpyDeviceToHost);
@@ -459,7 +262,7 @@ int main(int argc, char** argv) {
                 if (y0[i] != y1[i]) { ++bad; int d = (int)y0[i] - (int)y1[i]; if (d < -1 || d > 1) ++worse; }
             }
             tw = time_it(lw, it);
-            printf("    ws kernel %6.1f us %5.2f TB/s  (%zu of %zu outputs differ from the 128-tile kernel, %zu by more than one bf16 step)\n",
+            printf("    streaming kernel (variant 4) %6.1f us %5.2f TB/s  (%zu of %zu outputs differ from the 128-tile kernel, %zu by more than one bf16 step)\n",
                    tw * 1e3, gb / tw, bad, ny, worse);
         }
         const float ts = time_it([&] { hipLaunchKernelGGL(stream_kernel, dim3(256 * 8), dim3(256), 0, 0, a); }, it);
