@@ -47,17 +47,19 @@ class FPN(nn.Module):
                 xavier_init(m, distribution='uniform')
 
     @staticmethod
-    def _lateral(conv, x):
+    def _lateral(conv, x, out_token=None):
         # a backbone stage output carries the GradToken of the next stage's first convolution, which finishes its
-        # gradient: the lateral's data gradient is deposited there instead of returned (hip_conv.GradToken)
+        # gradient: the lateral's data gradient is deposited there instead of returned (hip_conv.GradToken).
+        # out_token (finest level): the 3x3 output convolution is the only reader of lateral + top-down, so its data
+        # gradient IS this convolution's output gradient and its column sums are this convolution's bias gradient.
         tok = getattr(x, '_oadg_token', None)
-        if tok is not None and not (conv.with_norm or conv.with_activation):
+        if (tok is not None or out_token is not None) and not (conv.with_norm or conv.with_activation):
             c = conv.conv
-            return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok)
+            return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok, out_token=out_token)
         return conv(x)
 
     @staticmethod
-    def _fpn_conv(conv, x, token):
+    def _fpn_conv(conv, x, token, in_token=None):
         # an output level is read by the RPN convolution and by RoIAlign: the RPN convolution's data gradient finishes
         # the level's gradient (RoIAlign deposits its part on the token, hip_ops.roi_align_fpn) and hands this
         # convolution its bias gradient as the column sums of that launch.  Not for the level the extra levels are
@@ -67,7 +69,7 @@ class FPN(nn.Module):
                 torch.is_grad_enabled() and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
             c = conv.conv
             tok = hip_conv.GradToken(masked=False)
-            y = layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, out_token=tok)
+            y = layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, out_token=tok, in_token=in_token)
             if getattr(y.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
                 y._oadg_token = tok
             return y
@@ -75,7 +77,12 @@ class FPN(nn.Module):
 
     def forward(self, inputs):
         assert len(inputs) == len(self.in_channels)
-        laterals = [self._lateral(conv, inputs[i + self.start_level]) for i, conv in enumerate(self.lateral_convs)]
+        from . import hip_conv
+        x0 = inputs[self.start_level]
+        t_lat0 = hip_conv.GradToken(masked=False) if (hip_conv.ENABLED and x0.is_cuda and torch.is_grad_enabled() and
+                                                      (x0.dtype == torch.bfloat16 or torch.is_autocast_enabled())) else None
+        laterals = [self._lateral(conv, inputs[i + self.start_level], t_lat0 if i == 0 else None)
+                    for i, conv in enumerate(self.lateral_convs)]
         n = len(laterals)
         for i in range(n - 1, 0, -1):   # fpn.py:166-175
             if 'scale_factor' in self.upsample_cfg:
@@ -87,7 +94,8 @@ class FPN(nn.Module):
             else:
                 laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
                                                                   **self.upsample_cfg)
-        outs = [self._fpn_conv(self.fpn_convs[i], laterals[i], token=i < n - 1 or self.num_outs == n) for i in range(n)]
+        outs = [self._fpn_conv(self.fpn_convs[i], laterals[i], token=i < n - 1 or self.num_outs == n,
+                               in_token=t_lat0 if (i == 0 and n > 1) else None) for i in range(n)]
         for _ in range(self.num_outs - len(outs)):   # fpn.py:184-188
             # fpn.py:177-181 `F.max_pool2d(outs[-1], 1, stride=2)`: a kernel-1 pool is a strided subsample - the same
             # values without the pooling library (whose kernels are compiled per shape)
