@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
 // Results equal the 128-tile kernel's bit for bit (same products, same fp32 summation order per output).
 template <int C>
 struct PwGeo {
-    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = 4, NP = SP / 8, SLOTS = C / 8;
+    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = (C >= 256 ? 8 : 4), NP = SP / 8, SLOTS = C / 8;
     static constexpr int SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
     static constexpr int RT = KPW / 16, CT = SP / 16, KS = C / 32, STG_STRIDE = KPW * 2 + 16, STG_BYTES = SP * STG_STRIDE;
     static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES + 4 * KPW * 4;
