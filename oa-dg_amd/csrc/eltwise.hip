@@ -161,17 +161,36 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// linear piece index -> (n, h, w, c8) of an [N][H][W][C8] tensor.  The 64-bit div / mod chain (six ~100-instruction
+// sequences per piece) made these element-wise passes VALU-bound; below 2^32 pieces it is three 32-bit divisions.
+__device__ __forceinline__ void split_nhwc(long i, int H, int W, int C8, int& n, int& h, int& w, int& c8) {
+    if (i <= 0xffffffffL) {
+        const unsigned u = (unsigned)i;
+        const unsigned p = u / (unsigned)C8;
+        c8 = (int)(u - p * (unsigned)C8);
+        const unsigned q = p / (unsigned)W;
+        w = (int)(p - q * (unsigned)W);
+        const unsigned m = q / (unsigned)H;
+        h = (int)(q - m * (unsigned)H);
+        n = (int)m;
+    } else {
+        c8 = (int)(i % C8);
+        long p = i / C8;
+        w = (int)(p % W);
+        p /= W;
+        h = (int)(p % H);
+        n = (int)(p / H);
+    }
+}
+
 __global__ __launch_bounds__(256) void fpn_topdown_fwd_kernel(const unsigned short* __restrict__ lat,
                                                               const unsigned short* __restrict__ top,
                                                               unsigned short* __restrict__ out, int N, int H, int W,
                                                               int Ht, int Wt, int C8, float sh, float sw) {
     const long total = (long)N * H * W * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int w = (int)(p % W);
-        p /= W;
-        const int h = (int)(p % H), n = (int)(p / H);
+        int n, h, w, c8;
+        split_nhwc(i, H, W, C8, n, h, w, c8);
         const long src = (((long)n * Ht + nearest_src(h, sh, Ht)) * Wt + nearest_src(w, sw, Wt)) * C8 + c8;
         float a[8], b[8];
         unpack8(reinterpret_cast<const uint4*>(lat)[i], a);
@@ -188,11 +207,8 @@ __global__ __launch_bounds__(256) void fpn_topdown_bwd_kernel(const unsigned sho
                                                               int Ht, int Wt, int C8, float sh, float sw) {
     const long total = (long)N * Ht * Wt * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int wt = (int)(p % Wt);
-        p /= Wt;
-        const int ht = (int)(p % Ht), n = (int)(p / Ht);
+        int n, ht, wt, c8;
+        split_nhwc(i, Ht, Wt, C8, n, ht, wt, c8);
         // candidate destination range: a superset of {d : nearest_src(d) == s}, filtered exactly below
         int h0 = (int)floorf((float)ht / sh) - 1, h1 = (int)ceilf((float)(ht + 1) / sh) + 1;
         int w0 = (int)floorf((float)wt / sw) - 1, w1 = (int)ceilf((float)(wt + 1) / sw) + 1;
@@ -290,11 +306,8 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const unsigned s
                                                                 int Ho, int Wo, int C8) {
     const long total = (long)N * Ho * Wo * C8;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % C8);
-        long p = i / C8;
-        const int wo = (int)(p % Wo);
-        p /= Wo;
-        const int ho = (int)(p % Ho), n = (int)(p / Ho);
+        int n, ho, wo, c8;
+        split_nhwc(i, Ho, Wo, C8, n, ho, wo, c8);
         float m[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
