@@ -329,6 +329,8 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
     (4, 64, 128, 264, 256),       # uneven: some workgroups run 9 sub-tiles, some 8
     (2, 128, 128, 256, 512),      # layer2 conv3 / conv1 data gradient: two columns share a pixel range
     (2, 256, 64, 128, 1024),      # layer3: 16-pixel sub-tiles, four columns
+    (2, 256, 64, 64, 2048),       # eight columns on 64 pixel ranges (exactly 8 sub-tiles each)
+    (4, 64, 128, 128, 512),       # 64 input channels (128-byte pixel rows), two columns
 ])
 def test_streaming_pointwise_kernel_equals_the_tile_kernel(dev, N, C, H, W, K):
     """csrc conv_pw_stream_kernel (variant 4: weights in registers, LDS-DMA pixel ring, operands one sub-tile ahead)
