@@ -1320,8 +1320,14 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
         combo = (int)(j % combos);
         split = (int)((j / combos) * 8 + xcd);
     } else {
-        combo = (int)(bid % combos);
-        split = (int)(bid / combos);
+        // workgroup b runs on XCD b % 8: XCD x takes the CONTIGUOUS slice [x * per, (x + 1) * per) of the split-major
+        // workgroup list, so the taps / tiles of a pixel range share an XCD's L2 except where a slice boundary cuts a
+        // split (28 splits x 9 taps = 252 workgroups use 252 CUs; 24 aligned splits only 216)
+        const long total = (long)a.splits * combos, per = (total + 7) >> 3;
+        const long xcd = bid & 7, slot = bid >> 3, w = xcd * per + slot;
+        if (slot >= per || w >= total) return;
+        combo = (int)(w % combos);
+        split = (int)(w / combos);
     }
     const int ct = combo % ct_n;
     const int kt = (combo / ct_n) % kt_n;
@@ -1556,12 +1562,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, 
 //    back by the reduction) are the cost that matters there (1.15x on layer2, 1.6x on layer3 / layer4).
 // One workgroup of the 256-tile kernel per CU, ONE round of <= 256 workgroups: half the partial tiles of two rounds to
 // write and read back, and since the loader carries its addresses incrementally (round 2) one round is as fast as two
-// on every shape (P2 3x3: 1109 us with 24 splits against 1125 with 56; P3: 293 / 303; layer3 / P4: 85 / 90).  Split
-// counts >= 8 are rounded down to a multiple of 8: the taps of a pixel range then share an XCD (and its L2).
+// on every shape (P2 3x3: 1076 us with 28 splits against 1125 with 56; P3: 273 / 294; layer3 / P4: 76 / 90).  The
+// workgroup list is split-major and every XCD runs a contiguous slice of it (see the kernel), so the taps of a pixel
+// range share an XCD's L2 for any split count - 28 splits x 9 taps use 252 CUs where 24 XCD-aligned splits use 216.
 long wgrad256_splits(long P, int K, int C, int RS) {
     const long tiles = (long)(K / 256) * (C / 256) * RS;
     long s = 256 / tiles;
-    if (s >= 8) s = s / 8 * 8;
     if (s < 1) s = 1;
     return s;
 }
@@ -1621,7 +1627,8 @@ int wgrad_launch(const void* x, const void* dy, float* dw, const void* zeros16, 
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
-        const long blocks = (long)a.splits * (K / 256) * (C / 256) * R * S;
+        long blocks = (long)a.splits * (K / 256) * (C / 256) * R * S;
+        if (a.splits % 8 != 0) blocks = ((blocks + 7) / 8) * 8;          // eight equal XCD slices (the kernel drops the padding)
         hipLaunchKernelGGL(conv_wgrad256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES, st, a);
     } else {
         const long blocks = (long)a.splits * (K / 128) * (C / 128) * R * S;

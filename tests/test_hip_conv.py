@@ -138,7 +138,7 @@ def test_conv_autograd_matches_reference(dev):
     (2, 512, 40, 56, 256, 1, 1, 0, 1),
     (4, 256, 65, 67, 256, 3, 2, 1, 1),
     (2, 256, 48, 48, 512, 3, 1, 2, 2),
-    (8, 256, 64, 128, 256, 3, 1, 1, 1),     # FPN P4 / layer3 conv2 at the bench size: one round of 216 workgroups (24 splits)
+    (8, 256, 64, 128, 256, 3, 1, 1, 1),     # FPN P4 / layer3 conv2 at the bench size: one round of 252 workgroups (28 splits, contiguous XCD slices)
     (8, 512, 32, 64, 512, 3, 1, 1, 1),      # layer4 conv2: 36 tiles x 7 splits
     (2, 256, 320, 320, 256, 1, 1, 0, 1),    # 1x1 over >= 200k pixels (lateral P2 form) on the 256-tile kernel
     (4, 256, 128, 130, 512, 3, 2, 1, 1),    # stride 2, ragged, 18 tiles x 14 splits

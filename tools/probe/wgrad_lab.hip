@@ -202,7 +202,8 @@ int main(int argc, char** argv) {
                 b.chunks_per_split = (int)((nchunks + b.splits - 1) / b.splits);
                 const size_t wsb2 = (size_t)b.splits * K * R * R * C * 4;
                 float* ws2; hipMalloc(&ws2, wsb2); b.part = ws2;
-                const long blocks = (long)b.splits * tiles;
+                long blocks = (long)b.splits * tiles;
+                if (b.splits % 8 != 0) blocks = ((blocks + 7) / 8) * 8;
                 const float t2 = time_it([&] { hipLaunchKernelGGL(conv_wgrad256_kernel, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES, 0, b); }, it);
                 printf("    256-tile: splits %3d (%ld workgroups, %d chunks each, ws %5.1f MB) %6.1f us %6.1f TF/s\n", b.splits, blocks,
                        b.chunks_per_split, wsb2 / 1e6, t2 * 1e3, gf / t2);
