@@ -12,8 +12,10 @@
 //   1. nms_mask_kernel : 64x64 tiles of the upper triangle -> one 64-bit suppression word per (row, tile)
 //   2. nms_scan_kernel : one wave per image walks the rows in order, 64 at a time; the `removed` bit set lives in
 //      registers (lane l owns words l, l+64, ...), the within-chunk dependency chain runs on v_readlane of the
-//      chunk's diagonal block, the off-diagonal updates are independent loads.
+//      chunk's diagonal block, the updates of the next two chunks are OR-reductions of prefetched words and the
+//      farther ones loads consumed a chunk later: no memory round trip on the chain (round 2: 370 -> ~100 us).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -54,6 +56,33 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
     mask[((size_t)img * Mmax + r) * words + cb] = bits;
 }
 
+// OR over the 64 lanes, the same value in every lane: four DPP row rotations inside each row of 16 lanes, then one
+// v_readlane per row (ds_bpermute-based shuffles cost a ~6-deep LDS round-trip chain on the scan's critical path)
+__device__ __forceinline__ unsigned wave_or32(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);     // row_ror:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);     // row_ror:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);     // row_ror:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);     // row_ror:1
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16) |
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+    return ((unsigned long long)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+}
+
+// One wave per image.  The greedy dependency chain must not contain a global-memory round trip per 64-row chunk (149
+// chunks at 9536 proposals: the first form of this kernel waited ~2 us per chunk for the kept rows' words, 370 us per
+// launch).  Per chunk c:
+//   * lane l holds three words of row 64 c + l, prefetched one chunk ahead: the diagonal word (what the row suppresses
+//     inside its own chunk) and the words of chunks c + 1 and c + 2;
+//   * the serial walk over the chunk's 64 bits runs on v_readlane of the diagonal words;
+//   * the kept rows' contributions to the next two chunks are an OR-reduction over the kept lanes of the prefetched
+//     words - no load on the chain;
+//   * their contributions to chunks > c + 2 are plain loads whose results are OR-ed in one chunk LATER (the first 8 kept
+//     rows; further ones, rare, immediately): they are first needed at chunk c + 3.
+// SLOTS = removed-set words per lane (64 SLOTS chunks); ROUNDS = rounds of 8 kept rows per chunk whose far words are
+// consumed a chunk later (RPN proposals keep 10-30 rows per chunk until max_keep is reached).
+template <int SLOTS, int ROUNDS>
 __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
                                                       const int* __restrict__ counts, int Mmax,
                                                       int words, int max_keep, int* __restrict__ keep,
@@ -62,61 +91,121 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     const int M = min(counts[img], Mmax);
     const unsigned long long* mk = mask + (size_t)img * Mmax * words;
     int* out = keep + (size_t)img * Mmax;
-    unsigned long long removed[MAX_WORDS_PER_LANE];
+    unsigned long long removed[SLOTS];       // lane l owns words l, l + 64, ...
+    unsigned long long pend[2][ROUNDS * 8][SLOTS];   // far words of the first ROUNDS * 8 kept rows of chunks c - 2 / c - 1
 #pragma unroll
-    for (int s = 0; s < MAX_WORDS_PER_LANE; ++s) removed[s] = 0ull;
-    int nkeep = 0;
+    for (int s = 0; s < SLOTS; ++s) {
+        removed[s] = 0ull;
+#pragma unroll
+        for (int u = 0; u < ROUNDS * 8; ++u) pend[0][u][s] = pend[1][u][s] = 0ull;
+    }
+    int nkeep = 0, pend_rounds[2] = {0, 0};
     const int nchunks = (M + 63) / 64;
-    for (int cw = 0; cw < nchunks && nkeep < max_keep; ++cw) {
-        // fetch this chunk's removed word from its owner lane
+    // words (c, c + 1, c + 2) of row 64 c + lane; only words of valid rows at / right of the diagonal and of existing
+    // chunks are ever written by the mask kernel
+    auto row_words = [&](int c, unsigned long long& d, unsigned long long& n1, unsigned long long& n2) {
+        const int row = c * 64 + lane;
+        const bool ok = c < nchunks && row < M;
+        const unsigned long long* r = mk + (size_t)(ok ? row : 0) * words;
+        d = ok ? r[c] : 0ull;
+        n1 = (ok && c + 1 < nchunks) ? r[c + 1] : 0ull;
+        n2 = (ok && c + 2 < nchunks) ? r[c + 2] : 0ull;
+    };
+    auto merge = [&](int w, unsigned long long v) {       // removed word w |= v (at its owner lane)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s)
+            if (s == (w >> 6) && lane == (w & 63)) removed[s] |= v;
+    };
+    unsigned long long diag, near1, near2;
+    row_words(0, diag, near1, near2);
+    auto chunk = [&](int cw, auto set_c) {
+        constexpr int SET = decltype(set_c)::value;
+        // this chunk's removed word from its owner lane (every contribution of earlier chunks has been merged)
         unsigned long long mine = 0ull;
 #pragma unroll
-        for (int s = 0; s < MAX_WORDS_PER_LANE; ++s)
+        for (int s = 0; s < SLOTS; ++s)
             if (s == (cw >> 6)) mine = removed[s];
-        const unsigned lo = __shfl((unsigned)mine, cw & 63, 64);
-        const unsigned hi = __shfl((unsigned)(mine >> 32), cw & 63, 64);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, cw & 63);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), cw & 63);
         unsigned long long cur = ((unsigned long long)hi << 32) | lo;
+        unsigned long long ndiag, nnear1, nnear2;
+        row_words(cw + 1, ndiag, nnear1, nnear2);          // in flight during the walk
         const int nb = min(64, M - cw * 64);
-        // The serial part of the greedy scan stays inside the chunk and inside registers: lane l holds the diagonal
-        // word of row cw*64 + l (which boxes of this chunk row l suppresses); walking the 64 bits needs one
-        // v_readlane pair per kept box instead of a dependent global load.
         const int myrow = cw * 64 + lane;
-        const unsigned long long diag = lane < nb ? mk[(size_t)myrow * words + cw] : 0ull;
+        // the walk visits only the rows still alive (10-30 of 64 for RPN proposals), on the scalar unit: the removed
+        // word is uniform, the next survivor is a find-first-set, its diagonal word comes by v_readlane
+        unsigned long long avail = ~cur & (nb == 64 ? ~0ull : ((1ull << nb) - 1ull));
         unsigned long long kept = 0ull;
         int nk = nkeep;
-        for (int bit = 0; bit < nb && nk < max_keep; ++bit) {
-            if ((cur >> bit) & 1ull) continue;
+        while (avail && nk < max_keep) {
+            const int bit = __ffsll((long long)avail) - 1;
             kept |= 1ull << bit;
             ++nk;
             const unsigned dlo = __builtin_amdgcn_readlane((int)(unsigned)diag, bit);
             const unsigned dhi = __builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), bit);
-            cur |= ((unsigned long long)dhi << 32) | dlo;
+            const unsigned long long d = ((unsigned long long)dhi << 32) | dlo;
+            avail &= ~d & ~((2ull << bit) - 1ull);      // minus what this row suppresses, minus the visited bits
         }
-        if ((kept >> lane) & 1ull) out[nkeep + __popcll(kept & ((1ull << lane) - 1ull))] = myrow;
+        const bool me_kept = (kept >> lane) & 1ull;
+        if (me_kept) out[nkeep + __popcll(kept & ((1ull << lane) - 1ull))] = myrow;
         nkeep = nk;
-        // the kept rows' words right of the diagonal: independent loads, no serial dependency
-        // (8 rows per round so that the loads of a round are in flight together)
+        // near words: OR over the kept rows of what each lane prefetched
+        merge(cw + 1, wave_or64(me_kept ? near1 : 0ull));
+        merge(cw + 2, wave_or64(me_kept ? near2 : 0ull));
+        // far words of the kept rows of chunk cw - 2 (loaded two chunks ago into this set: first needed at chunk cw + 1)
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; ++rd)
+            if (rd < pend_rounds[SET]) {                       // (uniform) only the rounds that were issued
+#pragma unroll
+                for (int s = 0; s < SLOTS; ++s)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) removed[s] |= pend[SET][rd * 8 + u][s];
+            }
+        // far words (> cw + 2) of this chunk's kept rows: 8 rows per round, the first round is consumed a chunk later
         unsigned long long todo = kept;
-        while (todo) {
-            int bits[8];
+        auto far_round = [&](int* bits) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 bits[u] = todo ? __ffsll((long long)todo) - 1 : -1;
                 todo &= todo - 1ull;
             }
+        };
+        pend_rounds[SET] = 0;
 #pragma unroll
-            for (int s = 0; s < MAX_WORDS_PER_LANE; ++s) {
+        for (int rd = 0; rd < ROUNDS; ++rd) {                  // deferred rounds, as many as there are kept rows
+            if (!todo) break;
+            ++pend_rounds[SET];
+            int bits[8];
+            far_round(bits);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
                 const int w = lane + 64 * s;
-                if (w > cw && w < nchunks) {
-                    unsigned long long v[8];
+                const bool far = w > cw + 2 && w < nchunks;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        v[u] = bits[u] >= 0 ? mk[(size_t)(cw * 64 + bits[u]) * words + w] : 0ull;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) removed[s] |= v[u];
-                }
+                for (int u = 0; u < 8; ++u)
+                    pend[SET][rd * 8 + u][s] = (far && bits[u] >= 0) ? mk[(size_t)(cw * 64 + bits[u]) * words + w] : 0ull;
             }
         }
+        while (todo) {                                         // more kept rows than deferred slots: immediately
+            int bits[8];
+            far_round(bits);
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                const int w = lane + 64 * s;
+                const bool far = w > cw + 2 && w < nchunks;
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = (far && bits[u] >= 0) ? mk[(size_t)(cw * 64 + bits[u]) * words + w] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) removed[s] |= v[u];
+            }
+        }
+        diag = ndiag; near1 = nnear1; near2 = nnear2;
+    };
+    for (int cw = 0; cw < nchunks && nkeep < max_keep; cw += 2) {
+        chunk(cw, std::integral_constant<int, 0>{});
+        if (cw + 1 < nchunks && nkeep < max_keep) chunk(cw + 1, std::integral_constant<int, 1>{});
     }
     if (lane == 0) keep_cnt[img] = nkeep;
 }
@@ -147,8 +236,12 @@ int oadg_nms_batched(const float* boxes, const int* counts, int n_images, int Mm
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, n_images), dim3(64), 0, st,
                        (const float4*)boxes, counts, Mmax, words, iou_thr, (unsigned long long*)workspace);
     OADG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(n_images), dim3(64), 0, st,
-                       (const unsigned long long*)workspace, counts, Mmax, words, max_keep, keep, keep_cnt);
+    if (words <= 64 * 3)        // <= 12288 boxes per image (RPN: 9536): three words per lane, 16 deferred rows per chunk (two sets)
+        hipLaunchKernelGGL((nms_scan_kernel<3, 2>), dim3(n_images), dim3(64), 0, st,
+                           (const unsigned long long*)workspace, counts, Mmax, words, max_keep, keep, keep_cnt);
+    else
+        hipLaunchKernelGGL((nms_scan_kernel<MAX_WORDS_PER_LANE, 1>), dim3(n_images), dim3(64), 0, st,
+                           (const unsigned long long*)workspace, counts, Mmax, words, max_keep, keep, keep_cnt);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
