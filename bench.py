@@ -32,7 +32,7 @@ CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_o
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
-PROFILE_TAGS = ('r02', 'r01')
+PROFILE_TAGS = ('r03', 'r02', 'r01')
 
 
 def pmc_traffic(kernel):
@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-families', action='store_true', help='skip the per-family table (3 extra steps after the timed region)')
     ap.add_argument('--pipeline-thread', type=int, default=1,
                     help='1: the data pipeline host code runs in a worker thread (DataLoader-worker analogue)')
     ap.add_argument('--conv', default='mfma', choices=['mfma', 'miopen'],
@@ -71,15 +72,108 @@ def parse():
     return ap.parse_args()
 
 
-def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56):
+def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56, fwd=False):
     """SURVEY.md 8d RoIAlign row, backward: read 49*C grad elements + read-modify-write of the unique fp32
-    input footprint (ceil(w_l)+1)(ceil(h_l)+1)*C on the RoI's level."""
+    input footprint (ceil(w_l)+1)(ceil(h_l)+1)*C on the RoI's level; forward: read that footprint once in the map
+    dtype + write 49*C elements."""
     w = (rois[:, 3] - rois[:, 1]).clamp(min=0)
     h = (rois[:, 4] - rois[:, 2]).clamp(min=0)
     lvl = torch.floor(torch.log2(torch.sqrt(w * h) / finest_scale + 1e-6)).clamp(0, len(strides) - 1).long()
     s = torch.tensor(strides, device=rois.device, dtype=torch.float32)[lvl]
     foot = (torch.ceil(w / s) + 1) * (torch.ceil(h / s) + 1)
+    if fwd:
+        return float((49 * C * elem + elem * C * foot).sum().item())
     return float((49 * C * elem + 2 * 4 * C * foot).sum().item())
+
+
+def family_of(kernel_name):
+    """hip_conv.TIMERS_ONLY_VARIANT key of a kernel name recorded by hip_conv"""
+    if kernel_name.startswith('conv_wgrad256'):
+        return 'wgrad256'
+    if kernel_name.startswith('conv_wgrad'):
+        return 'wgrad128'
+    if kernel_name.startswith('conv_igemm256'):
+        return 2
+    if kernel_name.startswith('conv_pw_stream'):
+        return 4
+    return 3
+
+
+FAMILIES = (('conv256 forward / data gradient', ('conv_igemm256_kernel',), 'mfma'),
+            ('weight gradient 256-tile', ('conv_wgrad256_kernel',), 'mfma'),
+            ('weight gradient 128-tile', ('conv_wgrad_kernel',), 'hbm'),
+            ('pointwise streaming (1x1, C <= 256)', ('conv_pw_stream_kernel',), 'hbm'),
+            ('128-tile convolution', ('conv_igemm_kernel',), 'mfma'))
+F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (xf32-free) MFMA peak
+
+
+def families_table(conv_timers, op_timers, roi_sets, steps, elem):
+    """roofline.families: achieved rate of every hand-written kernel family the north star names, from HIP events
+    recorded on the launch stream during ``steps`` extra steps after the timed region; PMC traffic (bytes per launch)
+    from the committed rocprofv3 counter passes of this same command."""
+    out = []
+    for title, prefixes, bound in FAMILIES:
+        rows = [t for t in conv_timers if t[4].startswith(prefixes)]
+        if not rows:
+            continue
+        ms = sum(t[0].elapsed_time(t[1]) for t in rows)
+        fl, by = sum(t[2] for t in rows), sum(t[3] for t in rows)
+        names = sorted({t[4] for t in rows})
+        e = {'family': title, 'kernels': names, 'bound': bound, 'launches_per_step': round(len(rows) / steps, 1),
+             'ms_per_step': round(ms / steps, 3)}
+        if bound == 'mfma':
+            e.update(achieved=round(fl / ms / 1e9, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                     frac=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4), hbm_gbs=round(by / ms / 1e6, 1))
+        else:
+            e.update(achieved=round(by / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                     frac=round(by / ms / 1e6 / HBM_PEAK_GBS, 4), tflops=round(fl / ms / 1e9, 1))
+        tr = [pmc_traffic(n_.replace('+reduce', '')) for n_ in names]
+        tr = [t_ for t_ in tr if t_.get('traffic')]
+        if tr:
+            e['traffic'] = {n_: t_['traffic'] for n_, t_ in zip(names, tr)}
+            e['traffic_source'] = tr[0]['traffic_source']
+        out.append(e)
+
+    def ms_of(key):
+        return [(t[0].elapsed_time(t[1]), t[2]) for t in op_timers.get(key, [])]
+    # RoIAlign (SURVEY 8d row): bytes per launch from the RoIs of the step
+    rois_bytes = {'roi_align_fwd': [], 'roi_align_bwd': []}
+    for rs_ in roi_sets:
+        if rs_ is None:
+            continue
+        allr = torch.cat([r_.float() for r_ in rs_])
+        b_bwd = roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem)
+        rois_bytes['roi_align_bwd'].append(b_bwd)
+        # forward: read the unique footprint in the map dtype, write 49 C elements
+        rois_bytes['roi_align_fwd'].append(roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem, fwd=True))
+    for key, title in (('roi_align_fwd', 'RoIAlign forward'), ('roi_align_bwd', 'RoIAlign backward (atomics kernel)')):
+        rows = ms_of(key)
+        if rows and rois_bytes[key]:
+            ms = sum(r[0] for r in rows)
+            by = sum(rois_bytes[key]) / len(rois_bytes[key]) * len(rows)
+            e = {'family': title, 'kernels': [key + '_kernel'], 'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1),
+                 'ms_per_step': round(ms / steps, 3), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
+                 'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
+                 'algorithmic_bytes_per_launch': int(by / len(rows))}
+            e.update({k: v for k, v in pmc_traffic(key + '_kernel').items() if v})
+            out.append(e)
+    for key, title in (('supcon_fwd', 'OA-Loss supcon forward'), ('supcon_bwd', 'OA-Loss supcon backward')):
+        rows = ms_of(key)
+        if rows:
+            ms, fl = sum(r[0] for r in rows), sum(r[1] for r in rows)
+            out.append({'family': title, 'kernels': ['supcon_tile_kernel'], 'bound': 'mfma-f32',
+                        'launches_per_step': round(len(rows) / steps, 1), 'ms_per_step': round(ms / steps, 3),
+                        'achieved': round(fl / ms / 1e9, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4)})
+    rows = ms_of('oamix_bbox_chain')
+    if rows:
+        ms, by = sum(r[0] for r in rows), sum(r[1] for r in rows)
+        e = {'family': 'OA-Mix per-box blend chains (side stream)', 'kernels': ['bbox_blend_multi_kernel', 'rect_copy_multi_kernel'],
+             'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1), 'ms_per_step': round(ms / steps, 3),
+             'achieved': round(by / ms / 1e6, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+             'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 5), 'algorithmic_bytes_per_step': int(by / steps)}
+        out.append(e)
+    return out
 
 
 def cpu_baseline(cfg, seconds_budget=30.0):
@@ -215,14 +309,30 @@ def main():
     priming = max(0, 11 - a.warmup) if engine.ddp is not None else 0      # (torch DDP is opt-in: OADG_USE_TORCH_DDP=1)
     for i in range(priming):
         step(i)
-    for i in range(a.warmup):
+    mfma = a.conv == 'mfma' and amp is not None
+    probe = min(2, a.warmup) if mfma else 0
+    for i in range(a.warmup - probe):
         out = step(i)
-    hip_ops.TIMERS = {'roi_align_bwd': []}
-    if a.conv == 'mfma' and amp is not None:
+    # the last warm-up steps time EVERY convolution / weight-gradient launch (HIP events on the launch stream) to find the
+    # dominant hand-written kernel family of this run; the timed region then carries event pairs around that family only
+    # (all ~350 pairs per step cost ~1.5 ms per step), and the per-family table is measured on extra steps AFTER the
+    # timed region (same process, same data stream, not part of `value`)
+    dominant = None
+    if probe:
+        torch.cuda.synchronize()
+        hip_conv.TIMERS, hip_conv.TIMERS_ONLY_VARIANT = [], None
+        for i in range(a.warmup - probe, a.warmup):
+            out = step(i)
+        torch.cuda.synchronize()
+        tot = {}
+        for t in hip_conv.TIMERS:
+            tot[t[4]] = tot.get(t[4], 0.0) + t[0].elapsed_time(t[1])
+        dominant = max(tot.items(), key=lambda kv: kv[1])[0]
         hip_conv.TIMERS = []
-        # HIP events around every launch of the dominant kernel family only (the 256-tile kernels); the per-family
-        # table of all convolution launches costs ~250 event records per step: OADG_BENCH_DIAG_CONV=1 turns it on
-        hip_conv.TIMERS_ONLY_VARIANT = None if os.environ.get('OADG_BENCH_DIAG_CONV') == '1' else 2
+        hip_conv.TIMERS_ONLY_VARIANT = family_of(dominant)
+        if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':
+            hip_conv.TIMERS_ONLY_VARIANT = None
+    hip_ops.TIMERS = None
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -239,17 +349,33 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    pairs = hip_ops.TIMERS['roi_align_bwd']
-    hip_ops.TIMERS = None
     conv_timers, hip_conv.TIMERS = hip_conv.TIMERS, None
     loss = float(out['loss'])
     assert np.isfinite(loss), 'training diverged'
+    # ---- per-family table: DIAG_STEPS more steps with event pairs around every convolution / weight-gradient launch,
+    #      RoIAlign forward / backward, the OA-Loss kernels and the OA-Mix per-box chains (worker thread, side stream)
+    diag_conv, diag_ops, diag_steps = [], {}, 0
+    if rank == 0 and a.gpus == 1 and not a.no_families:
+        diag_steps = 3
+        hip_ops.TIMERS = {k: [] for k in ('roi_align_fwd', 'roi_align_bwd', 'supcon_fwd', 'supcon_bwd', 'oamix_bbox_chain')}
+        if mfma:
+            hip_conv.TIMERS, hip_conv.TIMERS_ONLY_VARIANT = [], None
+        roi_sets = []
+        for i in range(diag_steps):
+            step(a.warmup + a.steps + i)
+            roi_sets.append(getattr(det.roi_head, '_last_rois', None))
+        torch.cuda.synchronize()
+        if wseed is not None:
+            state['next'].get()          # the worker's last pipeline pass has been enqueued: its events are recorded
+            torch.cuda.synchronize()
+        diag_conv, hip_conv.TIMERS = (hip_conv.TIMERS or []), None
+        diag_ops, hip_ops.TIMERS = hip_ops.TIMERS, None
     if rank != 0:
         return
     # ---- roofline of the dominant hand-written kernel, from HIP events recorded on the kernel's stream inside
-    #      the timed region.  With the MFMA convolutions enabled that is conv_igemm_kernel (forward + stride-1
-    #      data gradient of the 3x3 / 1x1 convs): algorithmic FLOPs per launch = 2*M*K*R*S*C summed over the
-    #      launches / number of launches, divided by the mean launch duration.  Otherwise RoIAlign backward.
+    #      the timed region: forward / data-gradient (conv_igemm*) or weight-gradient (conv_wgrad*) family, whichever
+    #      takes the most time per step.  Algorithmic FLOPs per launch = 2*M*K*R*S*C summed over the launches / number of
+    #      launches, divided by the mean launch duration.
     elem = 2 if amp is not None else 4
     if conv_timers:
         per_kernel = {}
@@ -282,29 +408,21 @@ def main():
                                       'avg_launch_ms': round(e[1] / e[0], 4),
                                       'achieved': round(e[2] / e[1] / 1e9, 1),
                                       'frac': round(e[2] / e[1] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
-        roof.update(pmc_traffic(name))
+        roof.update(pmc_traffic(name.replace('+reduce', '')))
+    else:
+        roof = {'kernel': None, 'bound': 'mfma', 'achieved': None, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': None, 'traffic': None, 'note': 'library convolutions (--conv miopen / fp32): no own conv kernel timed'}
+    if diag_steps:
+        roof['families'] = families_table(diag_conv, diag_ops, roi_sets, diag_steps, elem)
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':      # per-shape table of the conv launches (stderr)
             shp = {}
-            for t in conv_timers:
+            for t in diag_conv:
                 e = shp.setdefault((t[4],) + t[5], [0, 0.0, 0.0, 0.0])
                 e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]; e[3] += t[3]
             for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1]):
-                print(f'{k_[0][5:]:26s} N{k_[1]} {k_[2]}x{k_[3]} C{k_[4]} K{k_[5]} R{k_[6]} s{k_[7]} res{int(k_[8])} mask{int(k_[9])}: '
-                      f'{e[0] / a.steps:5.1f}/step {e[1] / a.steps:6.3f} ms/step {e[2] / e[1] / 1e9:7.1f} TF/s '
+                print(f'{k_[0][5:]:30s} N{k_[1]} {k_[2]}x{k_[3]} C{k_[4]} K{k_[5]} R{k_[6]} s{k_[7]} res{int(k_[8])} mask{int(k_[9])}: '
+                      f'{e[0] / diag_steps:5.1f}/step {e[1] / diag_steps:6.3f} ms/step {e[1] / e[0] * 1e3:7.1f} us {e[2] / e[1] / 1e9:7.1f} TF/s '
                       f'{e[3] / e[1] / 1e9:6.2f} TB/s', file=sys.stderr)
-    else:
-        ms = [s_.elapsed_time(e_) for s_, e_ in pairs]
-        rois = getattr(det.roi_head, '_last_rois', None)
-        if rois is not None:
-            per_launch = sum(roi_algorithmic_bytes(r_, [4, 8, 16, 32], 256, elem) for r_ in rois) / max(len(rois), 1)
-        else:
-            per_launch = 2 * a.batch * 512 * 49 * 256 * elem
-        avg_ms = sum(ms) / max(len(ms), 1)
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        roof = {'kernel': 'roi_align_bwd_kernel', 'bound': 'hbm', 'achieved': round(achieved, 2),
-                'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
-                'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
-                'algorithmic_bytes_per_launch': int(per_launch)}
     res = {
         'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
         'n_gpus': a.gpus, 'rccl_ranks': (dist.get_world_size() if distributed and dist.get_backend() == 'nccl' else 1),

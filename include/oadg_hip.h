@@ -85,11 +85,12 @@ int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float f
  * the bf16 gradient maps dmaps[l] [N,H_l,W_l,C] is WRITTEN (no zero fill, no fp32 maps, no atomics, no cast pass) and the
  * summation order is fixed by `order` (deterministic).  order [K] = RoI indices sorted by the oadg_roi_order_keys keys,
  * range [levels * N + 1] (device int32) = first position in `order` of every (level, image) group.  PH, PW <= 8.
+ * tile_boxes: device scratch of 16 K bytes (the tile rectangle of every RoI, written by a first small launch).
  * Same arithmetic as oadg_roi_align_bwd (mmcv RoIAlign backward) up to the fp32 summation order. */
 int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* widths, const float* scales,
                              int levels, int N, int C, float finest_scale, const float* rois, int K, int PH, int PW,
                              int sampling_ratio, int aligned, const void* grad_out, const int* order, const int* range,
-                             void* stream);
+                             void* tile_boxes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Greedy NMS, batched over images
@@ -244,6 +245,9 @@ int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* st
  * range) and to the launch. */
 int oadg_conv2d_auto_variant(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil);
 size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C, int K, int R, int S);
+/* the kernel a weight-gradient problem resolves to: 256 = the 256-tile phase pipeline, 2 / 1 = the 128-tile kernel with
+ * two / one LDS stages, 0 = shape not covered */
+int oadg_conv2d_wgrad_variant(int N, int Ho, int Wo, int C, int K, int R, int S);
 int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,
                                 size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
                                 int stride, int pad, int dil, void* stream);

@@ -37,7 +37,7 @@ SIGNATURES = {
                                 vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
     'oadg_roi_align_bwd_tiles': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, cf, vp, ci, ci, ci,
-                                      ci, ci, vp, vp, vp, vp]),
+                                      ci, ci, vp, vp, vp, vp, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_resize_bilinear_u8': (ci, [vp, ci, ci, ci, vp, ci, ci, vp]),
@@ -49,6 +49,7 @@ SIGNATURES = {
     'oadg_colsum_reduce': (ci, [vp, cl, ci, vp, vp]),
     'oadg_conv2d_nhwc_bf16_variant': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 12 + [vp]),
     'oadg_conv2d_wgrad_workspace_bytes': (cs, [ci] * 7),
+    'oadg_conv2d_wgrad_variant': (ci, [ci] * 7),
     'oadg_conv2d_wgrad_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, cs] + [ci] * 10 + [vp]),
     'oadg_conv2d_wgrad_parts_nhwc_bf16': (ci, [vp, vp, vp, vp, cs] + [ci] * 10 + [POINTER(ci), vp]),
     'oadg_prep_conv_weights_bwd_parts': (ci, [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),

@@ -1599,6 +1599,14 @@ extern "C" size_t oadg_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int C
     return (size_t)sp * K * R * S * C * sizeof(float);
 }
 
+// which kernel a weight-gradient problem runs on: 256 = conv_wgrad256_kernel, 2 / 1 = conv_wgrad_kernel<2> / <1>
+// (LDS stages), 0 = shape not covered.  (bench.py names its live event pairs with this.)
+extern "C" int oadg_conv2d_wgrad_variant(int N, int Ho, int Wo, int C, int K, int R, int S) {
+    if (C % 128 || K % 128) return 0;
+    if (wgrad_use256((long)N * Ho * Wo, K, C, R * S)) return 256;
+    return wgrad_stages(R * S);
+}
+
 namespace {
 int wgrad_launch(const void* x, const void* dy, float* dw, const void* zeros16, void* workspace,
                  size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,

@@ -376,8 +376,16 @@ __global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __
             pk[bi >> 2] |= byte << ((bi & 3) * 8);
         }
     }
-    unsigned* out = reinterpret_cast<unsigned*>(scratch + st.scratch_off + (size_t)i0 * 3);   // scratch_off % 4 == 0
-    out[0] = pk[0]; out[1] = pk[1]; out[2] = pk[2];
+    uint8_t* ob = scratch + st.scratch_off + (size_t)i0 * 3;                                   // scratch_off % 4 == 0
+    const int left = rw * rh - i0;
+    if (left >= 4) {
+        unsigned* out = reinterpret_cast<unsigned*>(ob);
+        out[0] = pk[0]; out[1] = pk[1]; out[2] = pk[2];
+    } else {
+        // tail group of a rect whose area is not a multiple of 4: only the bytes of its own pixels - the next rect's
+        // scratch slice starts at the next 4-byte boundary and belongs to another workgroup of this launch
+        for (int bi = 0; bi < left * 3; ++bi) ob[bi] = (uint8_t)(pk[bi >> 2] >> ((bi & 3) * 8));
+    }
 }
 
 // one thread = one pixel (four workgroups per 1024-pixel tile of the blend kernel)

@@ -330,103 +330,240 @@ __device__ void axis_tile_weights(float start, float bin, int grid, int b, int s
     }
 }
 
-__global__ __launch_bounds__(256) void roi_align_bwd_tiles_kernel(Pyramid p, TileGrid tg, const float* __restrict__ rois,
-                                                                  int PH, int PW, int sampling_ratio, int aligned,
-                                                                  const unsigned short* __restrict__ gout,
-                                                                  const int* __restrict__ order,
-                                                                  const int* __restrict__ range) {
-    __shared__ float wy[RB_MAXP][TILE], wx[RB_MAXP][TILE];
-    __shared__ unsigned short slab[RB_MAXP * RB_MAXP * 256];
-    __shared__ int hits[256];
-    __shared__ int nhit;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Round 3.  The first tile kernel (round 2) took ~3 ms per launch at BASELINE config 2 and stayed an opt-in.  Measured with
+// ablations (tools/probe/roi_bwd_probe.py):
+//  * 0.8 ms was the per-tile scan - every one of the 21,760 tile workgroups evaluated roi_geom (log2f, sqrtf, divisions)
+//    for the ~440 RoIs of its (level, image) group;
+//  * even an EMPTY kernel over 21,760 workgroups of 512 threads took 0.66 ms (workgroup launch + argument loads + three
+//    barriers: ~10 us of lifetime each, 42 rounds over the chip);
+//  * the pair loop ran at ~8 us per (tile, RoI) pair: per pixel a chain of dependent LDS round trips (bin bounds, wy,
+//    wx, slab value) with trip counts of 1-3, the slab staged behind a workgroup barrier, the pair's tables built by one
+//    wave while seven waited.
+// Now:
+//  * roi_tile_box_kernel writes the tile rectangle of every RoI once (int4, in processing order): the scan of a tile is
+//    one coalesced 16-byte load and four compares per RoI;
+//  * a workgroup walks TPW = 8 consecutive tiles of one (level, image): 2,720 workgroups instead of 21,760;
+//  * the row / column weight tables of up to 32 pairs are built at once by all 512 threads (16 lanes per pair);
+//  * separable accumulation: T[x] = sum_pw WX[pw][x] g[ph][pw][c], then acc[y][x] += (WY[ph][y] / count) T[x], on 4 x 4
+//    blocks of the bins that reach the tile (bin rows / columns outside the tile are never touched); the weights sit
+//    lane-indexed in two VGPRs and reach the multiplies through v_readlane (no memory latency, no per-pixel control
+//    flow);
+//  * no slab in LDS and no barrier inside the pair loop: lane c of a wave reads g[ph][pw][c] of its 64-channel chunk
+//    straight from global memory (128-byte wave rows, L2 resident: a slab is used by ~12 tiles), the first block of the
+//    NEXT pair in flight while the current pair is accumulated; the 8 waves (4 channel chunks x 2 column halves, 8 rows x
+//    4 columns per lane in registers) run through the tile's pair list independently.
+// Deterministic (the RoIs of a tile are visited in `order`, fixed fp32 summation order), one bf16 rounding at the end.
+constexpr int TB_THREADS = 512;
+constexpr int TPW = 8;               // tiles per workgroup
+constexpr int HB = 32;               // pairs per table batch
+
+struct TileTables {
+    float wy[RB_MAXP][TILE], wx[RB_MAXP][TILE];         // [bin][tile row / column]; wy already divided by the sample count
+    int plo, phi, qlo, qhi;                             // bin rows / columns with a non-zero weight somewhere on the tile
+};
+
+// tile rectangle [tx0, tx1] x [ty0, ty1] (inclusive, 8-pixel tiles of the RoI's level; conservative) and (level, image) of
+// the RoI at processing position i: {tx0 | tx1 << 16, ty0 | ty1 << 16, level, image}; an empty rectangle has tx1 < tx0
+__global__ void roi_tile_box_kernel(Pyramid p, const float* __restrict__ rois, int K, int PH, int PW, int sampling_ratio,
+                                    int aligned, const int* __restrict__ order, int4* __restrict__ boxes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    const int k = order[i];
+    const RoiGeom g = roi_geom(rois + (size_t)k * 5, p, PH, PW, sampling_ratio, aligned);
+    const int H = p.H[g.lvl], W = p.W[g.lvl];
+    const float rh = g.bin_h * PH, rw = g.bin_w * PW;
+    float ylo = floorf(g.start_h) - 1.f, yhi = ceilf(g.start_h + rh) + 1.f;
+    float xlo = floorf(g.start_w) - 1.f, xhi = ceilf(g.start_w + rw) + 1.f;
+    int4 b;
+    if (g.batch < 0 || g.batch >= p.N || !(yhi >= 0.f) || !(xhi >= 0.f) || !(ylo < (float)H) || !(xlo < (float)W)) {
+        b = make_int4(1, 1, g.lvl, -1);                // tx1 (0) < tx0 (1): touches nothing (NaN coordinates land here too)
+    } else {
+        ylo = fmaxf(ylo, 0.f); xlo = fmaxf(xlo, 0.f);
+        yhi = fminf(yhi, (float)(H - 1)); xhi = fminf(xhi, (float)(W - 1));
+        const int ty0 = (int)ylo / TILE, ty1 = (int)yhi / TILE, tx0 = (int)xlo / TILE, tx1 = (int)xhi / TILE;
+        b = make_int4(tx0 | (tx1 << 16), ty0 | (ty1 << 16), g.lvl, g.batch);
+    }
+    boxes[i] = b;
+}
+
+__device__ __forceinline__ float lane_f(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyramid p, TileGrid tg, const float* __restrict__ rois,
+                                                                         int PH, int PW, int sampling_ratio, int aligned,
+                                                                         const unsigned short* __restrict__ gout,
+                                                                         const int* __restrict__ order,
+                                                                         const int* __restrict__ range,
+                                                                         const int4* __restrict__ boxes) {
+    __shared__ TileTables tab[HB];
+    __shared__ int hits[TB_THREADS];
+    __shared__ int wcnt[TB_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = wave & 3, xh = wave >> 2;         // channel chunk of 64, column half (tile columns 4 xh .. 4 xh + 3)
     int lvl = 0;
     while (lvl + 1 < p.levels && (int)blockIdx.x >= tg.first[lvl + 1]) ++lvl;
-    const int local = blockIdx.x - tg.first[lvl];
-    const int per_img = tg.tx[lvl] * tg.ty[lvl];
-    const int n = local / per_img, t = local - n * per_img;
-    const int y0 = (t / tg.tx[lvl]) * TILE, x0 = (t % tg.tx[lvl]) * TILE;
     const int H = p.H[lvl], W = p.W[lvl], C = p.C;
+    const int per_img = tg.tx[lvl] * tg.ty[lvl];
+    const int wg_per_img = (per_img + TPW - 1) / TPW;
+    const int local = blockIdx.x - tg.first[lvl];
+    const int n = local / wg_per_img, t_first = (local - n * wg_per_img) * TPW;
     const int r0 = range[lvl * p.N + n], r1 = range[lvl * p.N + n + 1];
     const int bins = PH * PW;
     unsigned short* dst = reinterpret_cast<unsigned short*>(const_cast<void*>(p.feat[lvl])) + (size_t)n * H * W * C;
 
-    for (int cb = 0; cb < C; cb += 256) {
-        const int cw = min(256, C - cb);
-        float acc[2 * TILE][4];
+    // the common case - a group of at most 512 RoIs: every thread keeps ITS RoI's tile rectangle for all tiles of the workgroup
+    const bool one_chunk = r1 - r0 <= TB_THREADS;
+    int4 mybox = make_int4(1, 0, -1, -1);
+    int myk = -1;
+    if (one_chunk && r0 + tid < r1) { mybox = boxes[r0 + tid]; myk = order[r0 + tid]; }
+    for (int t = t_first; t < t_first + TPW && t < per_img; ++t) {
+        const int tyi = t / tg.tx[lvl], txi = t - tyi * tg.tx[lvl];
+        const int y0 = tyi * TILE, x0 = txi * TILE;
+        for (int cb = 0; cb < C; cb += 256) {
+            const int cw = min(256, C - cb);
+            float acc[TILE][TILE / 2];
 #pragma unroll
-        for (int i = 0; i < 2 * TILE; ++i)
+            for (int y = 0; y < TILE; ++y)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-        for (int rb = r0; rb < r1; rb += 256) {
-            // which of the next 256 RoIs of this (level, image) can touch the tile?  (conservative pixel bounds)
-            __syncthreads();
-            if (tid == 0) nhit = 0;
-            __syncthreads();
-            bool hit = false;
-            int k = -1;
-            if (rb + tid < r1) {
-                k = order[rb + tid];
-                const RoiGeom g = roi_geom(rois + (size_t)k * 5, p, PH, PW, sampling_ratio, aligned);
-                const float rh = g.bin_h * PH, rw = g.bin_w * PW;
-                const float ylo = floorf(g.start_h) - 1.f, yhi = ceilf(g.start_h + rh) + 1.f;
-                const float xlo = floorf(g.start_w) - 1.f, xhi = ceilf(g.start_w + rw) + 1.f;
-                hit = g.lvl == lvl && g.batch == n && yhi >= (float)y0 && ylo < (float)(y0 + TILE) &&
-                      xhi >= (float)x0 && xlo < (float)(x0 + TILE);
-            }
-            // compact in position order (a fixed summation order): ballot + prefix over the four waves
-            const unsigned long long m = __ballot(hit);
-            __shared__ int wcnt[4];
-            if (lane == 0) wcnt[wave] = __popcll(m);
-            __syncthreads();
-            int base = 0;
-            for (int w2 = 0; w2 < wave; ++w2) base += wcnt[w2];
-            if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
-            if (tid == 0) nhit = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-            __syncthreads();
-            const int nh = nhit;
-            for (int hidx = 0; hidx < nh; ++hidx) {
-                const int kk = hits[hidx];
-                const RoiGeom g = roi_geom(rois + (size_t)kk * 5, p, PH, PW, sampling_ratio, aligned);
-                __syncthreads();                       // previous RoI's tables / slab are no longer read
-                if (tid < PH) axis_tile_weights(g.start_h, g.bin_h, g.grid_h, tid, H, y0, wy[tid]);
-                else if (tid >= 64 && tid < 64 + PW) axis_tile_weights(g.start_w, g.bin_w, g.grid_w, tid - 64, W, x0, wx[tid - 64]);
-                for (int q = tid; q < bins * 64; q += 256) {          // 4 channels per piece
-                    const int bin = q >> 6, c4 = (q & 63) << 2;
-                    if (c4 < cw) {
-                        const unsigned short* src = gout + ((size_t)kk * bins + bin) * C + cb + c4;
-                        *reinterpret_cast<bf16x4*>(slab + bin * 256 + c4) = *reinterpret_cast<const bf16x4*>(src);
-                    }
+                for (int x = 0; x < TILE / 2; ++x) acc[y][x] = 0.f;
+            const bool chan_ok = chunk * 64 + lane < cw;
+            const unsigned short* gcol = gout + cb + chunk * 64 + lane;        // this lane's channel of g[k][bin][.]
+            for (int rb = r0; rb < r1; rb += TB_THREADS) {
+                // which of the next 512 RoIs of this (level, image) reach the tile?
+                bool hit = false;
+                int k = -1;
+                if (rb + tid < r1) {
+                    const int4 b = one_chunk ? mybox : boxes[rb + tid];
+                    hit = b.z == lvl && b.w == n && txi >= (b.x & 0xffff) && txi <= (b.x >> 16) &&
+                          tyi >= (b.y & 0xffff) && tyi <= (b.y >> 16);
+                    if (hit) k = one_chunk ? myk : order[rb + tid];
                 }
+                // compact in position order (a fixed summation order): ballot + prefix over the waves
+                const unsigned long long m = __ballot(hit);
+                __syncthreads();                               // the previous batch's hits / tables are no longer read
+                if (lane == 0) wcnt[wave] = __popcll(m);
                 __syncthreads();
-                const float inv = 1.0f / g.count;
+                int base = 0, nh = 0;
 #pragma unroll
-                for (int i = 0; i < 2 * TILE; ++i) {
-                    const int ry = wave * 2 + (i >> 3), rx = i & 7;       // this wave: tile rows 2w, 2w+1
-                    for (int ph = 0; ph < PH; ++ph) {
-                        const float wyv = wy[ph][ry];
-                        if (wyv == 0.f) continue;
-                        for (int pw = 0; pw < PW; ++pw) {
-                            const float wv = wyv * wx[pw][rx];
-                            if (wv == 0.f) continue;
-                            const unsigned short* row = slab + (ph * PW + pw) * 256;
-                            const float ws = wv * inv;
+                for (int w2 = 0; w2 < TB_THREADS / 64; ++w2) {
+                    if (w2 < wave) base += wcnt[w2];
+                    nh += wcnt[w2];
+                }
+                if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+                for (int hb = 0; hb < nh; hb += HB) {
+                    __syncthreads();                           // hits written / the previous table batch consumed
+                    // ---- tables of pairs hb .. hb+31: 16 lanes per pair (0-7: bin rows, 8-15: bin columns)
+                    {
+                        const int hi_ = hb + (tid >> 4), sub = tid & 15;
+                        const bool rows = sub < 8;
+                        const int bin = sub & 7, nb = rows ? PH : PW;
+                        bool nz = false;
+                        if (hi_ < nh) {
+                            TileTables& tb = tab[tid >> 4];
+                            if (bin < nb) {
+                                const RoiGeom g = roi_geom(rois + (size_t)hits[hi_] * 5, p, PH, PW, sampling_ratio, aligned);
+                                float* w = rows ? tb.wy[bin] : tb.wx[bin];
+                                if (rows) axis_tile_weights(g.start_h, g.bin_h, g.grid_h, bin, H, y0, w);
+                                else axis_tile_weights(g.start_w, g.bin_w, g.grid_w, bin, W, x0, w);
+                                const float inv = rows ? 1.0f / g.count : 1.0f;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (lane + 64 * j < cw) acc[i][j] += ws * bf16_to_f32(row[lane + 64 * j]);
+                                for (int j = 0; j < TILE; ++j) {
+                                    const float v = w[j];
+                                    nz = nz || v != 0.f;
+                                    if (rows) w[j] = v * inv;
+                                }
+                            } else {
+                                float* w = rows ? tb.wy[bin] : tb.wx[bin];        // bins beyond PH / PW: zeros
+#pragma unroll
+                                for (int j = 0; j < TILE; ++j) w[j] = 0.f;
+                            }
+                        }
+                        const unsigned mm = (unsigned)(__ballot(nz) >> ((lane >> 4) * 16)) & 0xffffu;
+                        if (hi_ < nh && (sub == 0 || sub == 8)) {
+                            const unsigned f = (sub ? mm >> 8 : mm) & 0xffu;
+                            const int lo = f ? __ffs((int)f) - 1 : nb, hi2 = f ? 32 - __clz((int)f) : 0;
+                            TileTables& tb = tab[tid >> 4];
+                            if (sub == 0) { tb.plo = lo; tb.phi = hi2; } else { tb.qlo = lo; tb.qhi = hi2; }
+                        }
+                    }
+                    __syncthreads();
+                    // ---- every wave walks the batch's pairs on its own: first 4 x 4 bin block of pair i+1 in flight
+                    const int nb_ = min(HB, nh - hb);
+                    if (chan_ok) {
+                        float nxt[4][4];
+                        // 4 x 4 bins from (pb, qb); bins beyond the RoI's last row / column are CLAMPED, not skipped (no
+                        // branches in the load stream): their weights on this tile are zero by construction of the ranges
+                        auto load_block = [&](float (&v)[4][4], int kk, int pb, int phi, int qb, int qhi) {
+                            const unsigned short* gk = gcol + (size_t)kk * bins * C;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int pr = min(pb + i, PH - 1) * PW;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    v[i][j] = bf16_to_f32(gk[(size_t)(pr + min(qb + j, PW - 1)) * C]);
+                            }
+                        };
+                        {
+                            const TileTables& t0 = tab[0];
+                            load_block(nxt, hits[hb], __builtin_amdgcn_readfirstlane(t0.plo), __builtin_amdgcn_readfirstlane(t0.phi),
+                                       __builtin_amdgcn_readfirstlane(t0.qlo), __builtin_amdgcn_readfirstlane(t0.qhi));
+                        }
+                        for (int i2 = 0; i2 < nb_; ++i2) {
+                            const TileTables& tb = tab[i2];
+                            const int kk = hits[hb + i2];
+                            const int plo = __builtin_amdgcn_readfirstlane(tb.plo), phi = __builtin_amdgcn_readfirstlane(tb.phi);
+                            const int qlo = __builtin_amdgcn_readfirstlane(tb.qlo), qhi = __builtin_amdgcn_readfirstlane(tb.qhi);
+                            float cur[4][4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) cur[i][j] = nxt[i][j];
+                            if (i2 + 1 < nb_) {
+                                const TileTables& tn = tab[i2 + 1];
+                                load_block(nxt, hits[hb + i2 + 1], __builtin_amdgcn_readfirstlane(tn.plo), __builtin_amdgcn_readfirstlane(tn.phi),
+                                           __builtin_amdgcn_readfirstlane(tn.qlo), __builtin_amdgcn_readfirstlane(tn.qhi));
+                            }
+                            if (plo >= phi || qlo >= qhi) continue;
+                            // lane j of WY / WX holds table entry j ([bin][row / column], 8 x 8 floats each)
+                            const float WY = (&tb.wy[0][0])[lane], WX = (&tb.wx[0][0])[lane];
+                            for (int pb = plo; pb < phi; pb += 4)
+                                for (int qb = qlo; qb < qhi; qb += 4) {
+                                    if (pb != plo || qb != qlo) load_block(cur, kk, pb, phi, qb, qhi);    // (rare: > 4 bins on a tile)
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        if (pb + i >= phi) continue;
+                                        float T[TILE / 2] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j) {
+                                            if (qb + j >= qhi) continue;
+#pragma unroll
+                                            for (int x = 0; x < TILE / 2; ++x)
+                                                T[x] += lane_f(WX, (qb + j) * TILE + xh * 4 + x) * cur[i][j];
+                                        }
+#pragma unroll
+                                        for (int y = 0; y < TILE; ++y) {
+                                            const float wyv = lane_f(WY, (pb + i) * TILE + y);
+#pragma unroll
+                                            for (int x = 0; x < TILE / 2; ++x) acc[y][x] += wyv * T[x];
+                                        }
+                                    }
+                                }
                         }
                     }
                 }
             }
-        }
+            if (chan_ok) {
 #pragma unroll
-        for (int i = 0; i < 2 * TILE; ++i) {
-            const int py = y0 + wave * 2 + (i >> 3), px = x0 + (i & 7);
-            if (py >= H || px >= W) continue;
-            unsigned short* o = dst + ((size_t)py * W + px) * C + cb;
+                for (int y = 0; y < TILE; ++y)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (lane + 64 * j < cw) o[lane + 64 * j] = f32_to_bf16(acc[i][j]);
+                    for (int x = 0; x < TILE / 2; ++x) {
+                        const int py = y0 + y, px = x0 + xh * 4 + x;
+                        if (py >= H || px >= W) continue;
+                        dst[((size_t)py * W + px) * C + cb + chunk * 64 + lane] = f32_to_bf16(acc[y][x]);
+                    }
+            }
         }
     }
 }
@@ -532,8 +669,8 @@ int oadg_roi_align_bwd(float* const* dfeats, const int* heights, const int* widt
 int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* widths, const float* scales,
                              int levels, int N, int C, float finest_scale, const float* rois, int K, int PH, int PW,
                              int sampling_ratio, int aligned, const void* grad_out, const int* order, const int* range,
-                             void* stream) {
-    if (!dmaps || !heights || !widths || !scales || !rois || !grad_out || !order || !range) return OADG_EARG;
+                             void* tile_boxes, void* stream) {
+    if (!dmaps || !heights || !widths || !scales || !rois || !grad_out || !order || !range || !tile_boxes) return OADG_EARG;
     if (K < 0 || PH < 1 || PW < 1 || PH > RB_MAXP || PW > RB_MAXP) return OADG_EARG;
     Pyramid p;
     const int rc = fill_pyramid(p, (const void* const*)dmaps, nullptr, heights, widths, scales, levels, N, C, finest_scale);
@@ -544,11 +681,16 @@ int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* 
         tg.first[l] = total;
         tg.tx[l] = (widths[l] + TILE - 1) / TILE;
         tg.ty[l] = (heights[l] + TILE - 1) / TILE;
-        total += N * tg.tx[l] * tg.ty[l];
+        total += N * ((tg.tx[l] * tg.ty[l] + TPW - 1) / TPW);          // workgroups: TPW consecutive tiles of one image
     }
     tg.first[levels] = total;
-    hipLaunchKernelGGL(roi_align_bwd_tiles_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, p, tg, rois, PH, PW,
-                       sampling_ratio, aligned, (const unsigned short*)grad_out, order, range);
+    if (K > 0) {
+        hipLaunchKernelGGL(roi_tile_box_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, rois, K, PH, PW,
+                           sampling_ratio, aligned, order, (int4*)tile_boxes);
+        OADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(roi_align_bwd_tiles_kernel, dim3(total), dim3(TB_THREADS), 0, (hipStream_t)stream, p, tg, rois, PH,
+                       PW, sampling_ratio, aligned, (const unsigned short*)grad_out, order, range, (const int4*)tile_boxes);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

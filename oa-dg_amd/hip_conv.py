@@ -18,7 +18,38 @@ USE_HIP_WGRAD = 'auto'      # True / False / 'auto' (= where tools/bench_conv.py
 # kernel name)
 # (bytes = algorithmic HBM bytes of the launch: input + weights + output [+ residual], each touched once)
 TIMERS = None
-TIMERS_ONLY_VARIANT = None      # restrict the event pairs to one kernel variant (2 = 256-tile): ~50 events per step, not ~250
+# restrict the event pairs to some kernel families (a set of: conv variant numbers 2 / 3 / 4 = 256-tile / 128-tile /
+# streaming pointwise, 'wgrad256', 'wgrad128'): ~50 events per step instead of ~350
+TIMERS_ONLY_VARIANT = None
+
+
+def _timed(family):
+    if TIMERS is None:
+        return False
+    only = TIMERS_ONLY_VARIANT
+    return only is None or family == only or (isinstance(only, (set, frozenset, tuple, list)) and family in only)
+
+
+def _wgrad_events(x16, gy16, K, R, S):
+    """(family, kernel name) of a weight-gradient launch when it is to be timed, else None"""
+    if TIMERS is None:
+        return None
+    N, C = x16.shape[0], x16.shape[1]
+    v = _lib.lib().oadg_conv2d_wgrad_variant(N, gy16.shape[2], gy16.shape[3], C, K, R, S)
+    fam = 'wgrad256' if v == 256 else 'wgrad128'
+    if not _timed(fam):
+        return None
+    return 'conv_wgrad256_kernel' if v == 256 else 'conv_wgrad_kernel<%d>' % v
+
+
+def _wgrad_record(name, e0, x16, gy16, K, R, S, stride, part_bytes):
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    N, C, H, W = x16.shape
+    Ho, Wo = gy16.shape[2], gy16.shape[3]
+    # algorithmic bytes: x and dy read once, dW (fp32) written once; the split partials are implementation traffic
+    TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S, 2.0 * (N * H * W * C + N * Ho * Wo * K) + 4.0 * K * C * R * S,
+                   name, (N, H, W, C, K, R, stride, False, False)))
 
 
 def _zeros(device):
@@ -51,9 +82,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
     variant = int(variant) or L.oadg_conv2d_auto_variant(N, H, W, C, K, R, S, stride, pad, dil)
     if variant == 4 and (mask is not None or (mask_bits is not None and bits_out is not None)):
         variant = 3                                    # the streaming pointwise kernel takes mask BITS, or writes them
-    timed = TIMERS is not None
-    if timed and TIMERS_ONLY_VARIANT is not None:      # bench.py: only the dominant kernel family carries events
-        timed = variant == TIMERS_ONLY_VARIANT
+    timed = _timed(int(variant))                       # bench.py: only the dominant kernel family carries events
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -134,9 +163,15 @@ def conv_wgrad(x16, gy16, K, R, S, stride, pad, dil):
     nbytes = L.oadg_conv2d_wgrad_workspace_bytes(N, Ho, Wo, C, K, R, S)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x16.device)
     dw = torch.empty((K, R, S, C), dtype=torch.float32, device=x16.device)
+    name = _wgrad_events(x16, gy16, K, R, S)
+    if name:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.oadg_conv2d_wgrad_nhwc_bf16(ptr(x16), ptr(gy16), ptr(dw), ptr(_zeros(x16.device)), ptr(ws), nbytes, N,
                                         H, W, C, K, R, S, stride, pad, dil, stream_ptr()),
           'oadg_conv2d_wgrad_nhwc_bf16')
+    if name:
+        _wgrad_record(name + '+reduce', e0, x16, gy16, K, R, S, stride, nbytes)
     return dw.permute(0, 3, 1, 2)
 
 
@@ -150,9 +185,15 @@ def conv_wgrad_parts(x16, gy16, K, R, S, stride, pad, dil):
     nbytes = L.oadg_conv2d_wgrad_workspace_bytes(N, Ho, Wo, C, K, R, S)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x16.device)
     splits = ctypes.c_int(0)
+    name = _wgrad_events(x16, gy16, K, R, S)
+    if name:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(L.oadg_conv2d_wgrad_parts_nhwc_bf16(ptr(x16), ptr(gy16), ptr(_zeros(x16.device)), ptr(ws), nbytes, N, H, W,
                                               C, K, R, S, stride, pad, dil, ctypes.byref(splits), stream_ptr()),
           'oadg_conv2d_wgrad_parts_nhwc_bf16')
+    if name:
+        _wgrad_record(name, e0, x16, gy16, K, R, S, stride, nbytes)
     return ws, splits.value
 
 

@@ -18,14 +18,16 @@ from ._lib import check, ptr, require_cuda, stream_ptr
 TIMERS = None
 
 
-def _timed(name, fn, *args):
+def _timed(name, fn, *args, work=0.0):
+    """``fn(*args)`` between two events on the calling thread's current stream when bench.py asked for ``name``;
+    ``work`` = the launch's algorithmic FLOPs or bytes (0: the caller of the timers derives it)."""
     if TIMERS is None or name not in TIMERS:
         return fn(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     rc = fn(*args)
     b.record()
-    TIMERS[name].append((a, b))
+    TIMERS[name].append((a, b, work))
     return rc
 
 
@@ -46,9 +48,9 @@ class _SupCon(torch.autograd.Function):
         nbytes = L.oadg_supcon_workspace_bytes(B, D)
         ws = _ws(nbytes, feats.device)
         out = torch.empty(1, dtype=torch.float32, device=feats.device)
-        check(L.oadg_supcon_fwd(ptr(feats), ptr(labels), B, D, n_labels, ori_size, rp_size,
-                                float(temper), int(min_samples), float(loss_weight), ptr(ws), nbytes,
-                                ptr(out), stream_ptr()), 'oadg_supcon_fwd')
+        check(_timed('supcon_fwd', L.oadg_supcon_fwd, ptr(feats), ptr(labels), B, D, n_labels, ori_size, rp_size,
+                     float(temper), int(min_samples), float(loss_weight), ptr(ws), nbytes,
+                     ptr(out), stream_ptr(), work=2.0 * B * B * D), 'oadg_supcon_fwd')
         ctx.save_for_backward(labels, ws)
         ctx.args = (B, D, n_labels, ori_size, rp_size, float(temper), float(loss_weight), nbytes)
         return out[0]
@@ -60,8 +62,9 @@ class _SupCon(torch.autograd.Function):
         L = _lib.lib()
         g = gout.contiguous().float().view(1)
         dfeats = torch.empty(B, D, dtype=torch.float32, device=ws.device)
-        check(L.oadg_supcon_bwd(ptr(labels), B, D, n_labels, ori_size, rp_size, temper, loss_weight,
-                                ptr(g), ptr(ws), nbytes, ptr(dfeats), stream_ptr()), 'oadg_supcon_bwd')
+        check(_timed('supcon_bwd', L.oadg_supcon_bwd, ptr(labels), B, D, n_labels, ori_size, rp_size, temper,
+                     loss_weight, ptr(g), ptr(ws), nbytes, ptr(dfeats), stream_ptr(), work=4.0 * B * B * D),
+              'oadg_supcon_bwd')
         return dfeats, None, None, None, None, None, None, None
 
 
@@ -135,11 +138,22 @@ def _as_nhwc(x):
 
 
 ROI_LOCALITY_ORDER = os.environ.get('OADG_ROI_ORDER', '1') == '1'
-# bf16 backward by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no atomics, deterministic summation order).
-# Correct (tests/test_hip_roi_nms.py) but OFF by default: proposals cluster on objects, a hot 8 x 8 tile walks hundreds of
-# RoIs serially, and the launch takes ~3 ms at BASELINE config 2 against 1.4 ms (+ 0.6 ms of fill / cast) for the atomic
-# scatter.  Kept for runs that need bit-reproducible gradients.
-BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '0') == '1'
+# bf16 backward by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no zero fill, no atomics, no cast pass,
+# deterministic summation order).  Round 3: the default - with the pair loop pipelined (next slab in flight, bin ranges
+# per tile row / column, one barrier per pair, 8 waves) a hot coarse-level tile no longer dominates the launch; the
+# fp32 atomic scatter (OADG_ROI_BWD_TILES=0; fp32 atomics retire at ~1.2 TB/s of 4-byte adds on this chip whatever their
+# scope - tools/probe/atomic_lab.hip - so 236 M of them cannot take less than 0.8 ms) stays for fp32 maps and PH, PW > 8.
+BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '1') == '1'
+_GROUP_KEYS = {}
+
+
+def _group_keys(levels, n_img, device):
+    """first sort key of every (level, image) group of oadg_roi_order_keys (+ the end sentinel), cached"""
+    k = (levels, n_img, device)
+    g = _GROUP_KEYS.get(k)
+    if g is None:
+        g = _GROUP_KEYS[k] = torch.arange(levels * n_img + 1, device=device, dtype=torch.int64) << 20
+    return g
 
 
 class _RoIAlignFPN(torch.autograd.Function):
@@ -171,8 +185,7 @@ class _RoIAlignFPN(torch.autograd.Function):
             if tiles:       # the tile-gather backward walks the RoIs of one (level, image) group: group boundaries
                 skeys, order = keys.sort()
                 order = order.int()
-                groups = torch.arange(len(feats) * N + 1, device=rois.device, dtype=torch.int64) << 20
-                rng_ = torch.searchsorted(skeys, groups).int()
+                rng_ = torch.searchsorted(skeys, _group_keys(len(feats), N, rois.device), out_int32=True)
             else:
                 order = keys.argsort().int()
         check(_timed('roi_align_fwd', L.oadg_roi_align_fwd, P, Hs, Ws, Ss, len(feats), N, C,
@@ -198,9 +211,10 @@ class _RoIAlignFPN(torch.autograd.Function):
             grads = [torch.empty(s, dtype=dt, device=rois.device, memory_format=torch.channels_last) for s in shapes]
             N, C = shapes[0][:2]
             P, Hs, Ws, Ss = _pyramid_args(grads, scales)
+            boxes = torch.empty((max(rois.shape[0], 1), 4), dtype=torch.int32, device=rois.device)
             check(_timed('roi_align_bwd', L.oadg_roi_align_bwd_tiles, P, Hs, Ws, Ss, len(grads), N, C, finest_scale,
                          ptr(rois), rois.shape[0], PH, PW, sampling_ratio, aligned, ptr(gout), ptr(order), ptr(rng_),
-                         stream_ptr()), 'oadg_roi_align_bwd_tiles')
+                         ptr(boxes), stream_ptr()), 'oadg_roi_align_bwd_tiles')
             return (None, None, None, None, None, None, None, *_deposit(ctx.tokens, grads))
         grads = [torch.empty(s, dtype=torch.float32, device=rois.device,
                              memory_format=torch.channels_last).zero_() for s in shapes]

@@ -509,10 +509,14 @@ class OAMix:
         steps_dev = _upload(steps.view(np.uint8).reshape(-1), dev)
         tiles_dev = _upload(tiles, dev)
         keep += [steps_dev, tiles_dev]
-        check(L.oadg_oamix_bbox_chain(ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
-                                      first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
-                                      tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(st.My), ptr(st.Mx),
-                                      ptr(b['scratch']), stream_ptr()), 'oadg_oamix_bbox_chain')
+        from .. import hip_ops
+        # model bytes of the chain (SURVEY 8d's sum 3 w h term, per blend: the rect is read, its warped source is read,
+        # the result is written) + the two mask profiles of every step
+        work = float(9 * area.sum() + 4 * (steps['rect'][:, 2].sum() + steps['rect'][:, 3].sum()))
+        check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
+                             first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
+                             tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(st.My), ptr(st.Mx),
+                             ptr(b['scratch']), stream_ptr(), work=work), 'oadg_oamix_bbox_chain')
 
     # ------------------------------------------------------------------------------------------ one view
     def oamix(self, st, out_u8=None, out_norm=None, norm=None, pad_shape=None):

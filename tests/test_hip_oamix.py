@@ -203,3 +203,43 @@ def test_oamix_stress_config5_full_size_properties(dev):
         else:
             with np.errstate(all='ignore'):
                 assert abs(got[i] - cv.saliency_score(img[y1:y2, x1:x2])) <= 0.05
+
+
+@pytest.mark.parametrize('H,W', [(131, 253), (133, 250), (129, 255)])
+def test_bbox_chain_rect_areas_not_multiple_of_4(dev, H, W):
+    """Supports clipped at the right / bottom border of an image whose sides are not multiples of 4 have areas with
+    area % 4 in {1, 2, 3}: the tail thread of such a rect must not store past its own pixels (the next rect of the level
+    starts at the next 4-byte boundary of the packed scratch image).  Level-batched path == per-box path == oracle."""
+    from oadg_amd.pipelines import OAMix
+    from oadg_amd.pipelines import oa_mix as PM
+    rs = np.random.RandomState(H)
+    img = lowpass_image(rs, H, W, 4)
+    gts = np.array([[W - 23.4, 5, W - 0.5, 31], [W - 21, H - 19.2, W - 1, H - 0.7], [3, H - 26, 30, H - 1.2],
+                    [60, 40, 93, 77], [W - 41.5, 60, W - 2.2, 90.5], [120, H - 31, 150.5, H - 0.2],
+                    [10, 10, 33, 29], [W // 2, 5, W // 2 + 27, 33]], np.float32)
+    outs = []
+    prev = PM.BATCH_BOXES
+    try:
+        for batch in (True, False):
+            PM.BATCH_BOXES = batch
+            for seed in range(6):
+                np.random.seed(400 + seed)
+                mix = OAMix(version='augmix.all')
+                mix.trace = []
+                r = mix(dict(img=img.copy(), gt_bboxes=gts.copy()))
+                outs.append((batch, seed, r['img2'].copy(), list(mix.trace)))
+    finally:
+        PM.BATCH_BOXES = prev
+    n_bbox = 0
+    for (b0, s0, a, tr), (b1, s1, c, _) in zip(outs[:6], outs[6:]):
+        assert s0 == s1 and np.array_equal(a, c), (s0, int((a != c).sum()))
+        n_bbox += sum(t.startswith('bboxes_only') for t in tr)
+    assert n_bbox > 0
+    for _, seed, a, _tr in outs[:6]:
+        np.random.seed(400 + seed)
+        oracle = OO.OAMixOracle(version='augmix.all')
+        ref = oracle(dict(img=img.copy(), gt_bboxes=gts.copy()))
+        fg = [t[1] for t in oracle.trace if t[0] == 'fg_scores']
+        if fg and any(abs(s - 10) < 0.2 for s in fg[0] if s >= 0):
+            continue
+        assert np.array_equal(a, ref['img2']), seed

@@ -101,9 +101,10 @@ def test_host_logic_reproduces_reference_step(golden_dir, fold_bn, monkeypatch):
 @pytest.mark.gpu
 def test_product_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
     """fp32 on the MI355X.  Convolutions come from a different library (MIOpen vs the CPU's oneDNN), and the
-    step contains discrete decisions (top-k, NMS, IoU thresholds, sampling), so agreement is asserted at
-    5e-3 for the loss terms and 2e-2 for the gradient norms rather than at 1e-4; the 1e-4 bar is held by
-    the per-kernel tests, which feed identical inputs to both sides."""
+    step contains discrete decisions (top-k, NMS, IoU thresholds, sampling): measured (round 3) 1e-7 on the RPN
+    terms, 3.3e-4 on loss_cls, 9e-5 on loss_cont, 2e-3 on acc; asserted at 1e-3 (acc 1e-2) and 1e-3 for the
+    gradient norms - about 3x the measured deviations; the 1e-4 bar is held by the per-kernel tests, which feed
+    identical inputs to both sides."""
     g = np.load(os.path.join(golden_dir, 'model_step_256x512.npz'))
     torch.backends.cudnn.allow_tf32 = False
     # MIOpen's default fp32 solvers reduce split-K partials with atomics: ulp-level run-to-run noise that flips a
@@ -120,13 +121,14 @@ def test_product_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
     print({k: (v, float(g['lv_' + k])) for k, v in out['log_vars'].items()})
     for k, v in out['log_vars'].items():
         ref = float(g['lv_' + k])
-        tol = 5e-3 if k != 'acc' else 2e-2
+        tol = 1e-3 if k != 'acc' else 1e-2
         assert abs(v - ref) <= tol * abs(ref), (k, v, ref)
     same = (det.roi_head.bbox_targets[0].cpu().numpy() == g['roi_labels']).mean()
-    assert same >= 0.99, same
-    for k, v in grad_groups(det).items():
-        ref = float(g['gn_' + k])
-        assert abs(v - ref) <= 2e-2 * ref, (k, v, ref)
+    assert same >= 0.999, same
+    gdev = {k: abs(v - float(g['gn_' + k])) / float(g['gn_' + k]) for k, v in grad_groups(det).items()}
+    print('grad-norm dev', {k: f'{v:.2e}' for k, v in gdev.items()})
+    for k, v in gdev.items():
+        assert v <= 1e-3, (k, v)
 
 
 @pytest.mark.gpu
@@ -219,9 +221,11 @@ def test_bf16_mfma_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
     ~4e-3 relative rounding per layer, which also flips a few discrete decisions (top-k / NMS / IoU thresholds, ~1 %
     of the sampled RoIs).  Measured on MI355X (round 2): loss terms 1e-4..3e-3 (3e-2 for loss_cls / loss_bbox
     of the DC5 fixture, where 2 of 2048 sampled RoIs flip), acc <= 3.6e-2, per-module gradient norms 1e-5..1.1e-2,
-    sampled labels >= 99.9 % identical.  Asserted: 5e-2 / 5e-2 / 3e-2 / 99 %.  north_star's 1e-4 bar is held by the
-    per-kernel tests on identical operands and by the fp32 product step (1e-7..2.5e-4 against the same fixtures)."""
-    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_256x512.npz', CFG, True, 5e-2, 5e-2, 3e-2, 0.99, monkeypatch)
+    sampled labels >= 99.9 % identical.  Round 3 (measured again, RoIAlign backward by tiles): loss terms <= 5.3e-3,
+    acc 3.2e-2, gradient norms <= 8.9e-3, labels identical.  Asserted at ~3x that: 1.5e-2 / 1e-1 (acc) / 2.5e-2 /
+    99.9 %.  north_star's 1e-4 bar is held by the per-kernel tests on identical operands and by the fp32 product
+    step (1e-7..3.3e-4 against the same fixtures)."""
+    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_256x512.npz', CFG, True, 1.5e-2, 1e-1, 2.5e-2, 0.999, monkeypatch)
 
 
 @pytest.mark.gpu
@@ -231,8 +235,10 @@ def test_full_size_config1_step_matches_reference_on_gpu(dev, golden_dir, bf16, 
     step on the build container's 8 cores)."""
     # bf16 `acc`: an argmax over 9 near-tied random-init logits per RoI (reference 35.7 % of 2048 RoIs).  The losses agree
     # to 2e-3 and the sampled labels are identical, yet 25-55 argmaxes flip with the bf16 rounding pattern of the
-    # convolutions (3.6e-2 relative with tap-major K order, 7.5e-2 with the chunk-major order of round 2): 1e-1 asserted
-    tol = (5e-2, 1e-1, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
+    # convolutions (3.6e-2 relative with tap-major K order, 7.5e-2 with the chunk-major order of round 2): 1.5e-1 asserted.
+    # Measured (round 3): fp32 loss terms <= 2.5e-4, acc 4.1e-3, gradient norms <= 2e-4, labels identical; bf16 loss
+    # terms <= 2e-3, gradient norms <= 7.1e-3, labels identical.  Asserted at ~3x the measured deviations.
+    tol = (6e-3, 1.5e-1, 2e-2, 0.999) if bf16 else (1e-3, 1.5e-2, 1e-3, 0.999)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_1024x2048.npz', CFG, bf16, *tol, monkeypatch)
 
 
@@ -274,8 +280,10 @@ def test_r101_dc5_host_logic_reproduces_reference_step(golden_dir):
 @pytest.mark.parametrize('bf16', [False, True])
 def test_r101_dc5_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypatch):
     """R101-DC5 OA-DG product path on the device against the reference-generated fixture: fp32 (library convolutions +
-    HIP RoIAlign / NMS / losses) and the bf16 MFMA path incl. the dilated 3x3 and the 2048->2048 RPN convolution."""
-    tol = (5e-2, 5e-2, 3e-2, 0.99) if bf16 else (5e-3, 2e-2, 2e-2, 0.99)
+    HIP RoIAlign / NMS / losses) and the bf16 MFMA path incl. the dilated 3x3 and the 2048->2048 RPN convolution.
+    Measured (round 3): fp32 loss terms <= 1.1e-6, gradient norms <= 5.8e-5, labels identical; bf16 loss terms <= 1.6e-2
+    (loss_cls: 2 of 2048 sampled RoIs flip), acc 5.7e-4, gradient norms <= 2.1e-2, labels 99.9 %."""
+    tol = (5e-2, 1e-2, 6e-2, 0.998) if bf16 else (1e-4, 1e-3, 3e-4, 0.999)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_dc5_384x768.npz', DC5_CFG, bf16, *tol, monkeypatch)
 
 
@@ -309,5 +317,62 @@ def test_bf16_training_overfits_a_fixed_batch(dev):
         assert all(np.isfinite(h['loss']) for h in hist)
         assert last < 0.6 * first, (first, last)
         assert np.mean([h['loss_rpn_cls'] for h in hist[-5:]]) < 0.5 * np.mean([h['loss_rpn_cls'] for h in hist[:5]])
+    finally:
+        hip_conv.enable(False)
+
+
+@pytest.mark.gpu
+def test_config2_whole_step_bs4_1024x2048_bf16(dev):
+    """BASELINE configs[1] - the benchmarked workload - as ONE whole step through the product path (bench.py runs the same
+    step but only asserts a finite loss): bs 4 x 2 views at 1024 x 2048, 20 boxes per image, bf16 autocast, every
+    convolution on the csrc MFMA kernels, OA-Mix on the device, HIP losses / RoIAlign / NMS / assigner
+    (mmdet/models/detectors/base.py:413-455 is the reference step).  Size-independent properties: the 7 log vars are
+    finite, 8 x 512 = 4096 sampled RoIs, the contrastive batch is 4096 + the random proposals, EVERY trainable parameter
+    receives a finite, non-zero gradient, and two runs from the same seeds are bit-identical (deterministic kernels:
+    fixed-order weight-gradient / column-sum reductions, RoIAlign backward by output tiles)."""
+    from oadg_amd import Config, build_detector, hip_conv
+    from oadg_amd.apis import TrainEngine, build_optimizer, set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    cfg = Config.fromfile(CFG)
+    set_random_seed(0)
+    det = build_detector(cfg.model)
+    det.init_weights(allow_missing_pretrained=True)
+    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    try:
+        eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
+        ds = SyntheticCityscapes(img_shape=(1024, 2048), num_boxes=20, num_classes=8, seed=0, device=dev)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
+        set_random_seed(5)
+        data = pipe(*ds.batch(range(4)))
+        assert tuple(data['img'].shape) == (4, 3, 1024, 2048) and tuple(data['img2'].shape) == (4, 3, 1024, 2048)
+        runs = []
+        for rep in range(2):
+            set_random_seed(11)                      # RandomSampler (torch CPU generator) + random proposals (numpy)
+            det.zero_grad(set_to_none=True)
+            (loss, log_vars), n = eng.forward_losses(data)
+            loss.backward()
+            torch.cuda.synchronize()
+            lv = {k: float(v) for k, v in log_vars.items()}
+            assert n == 4
+            assert set(lv) == {'loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'acc', 'loss_bbox', 'loss_cont', 'loss'}
+            assert all(np.isfinite(v) for v in lv.values()), lv
+            assert lv['loss_cont'] > 0 and lv['loss_cls'] > 0 and lv['loss_rpn_cls'] > 0
+            labels = det.roi_head.bbox_targets[0]
+            assert labels.shape[0] == 8 * 512
+            rois = det.roi_head._last_rois
+            assert rois[0].shape[0] == 4096 and len(rois) == 2 and 8 * 11 <= rois[1].shape[0] <= 8 * 18
+            grads = {}
+            for name, p in det.named_parameters():
+                if p.requires_grad:
+                    assert p.grad is not None, name
+                    g = p.grad.float()
+                    assert torch.isfinite(g).all(), name
+                    assert float(g.abs().sum()) > 0, name
+                    grads[name] = p.grad.detach().clone()
+            runs.append((lv, grads))
+        assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+        bad = [k for k in runs[0][1] if not torch.equal(runs[0][1][k], runs[1][1][k])]
+        assert not bad, bad[:5]
+        print('config 2 whole step:', {k: round(v, 4) for k, v in runs[0][0].items()}, 'trainable tensors', len(runs[0][1]))
     finally:
         hip_conv.enable(False)

@@ -28,7 +28,7 @@ for r in csv.DictReader(open(f)):
         k = k.split('<')[0]
     k = k[-70:]
     agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
-rows = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda t: -t[1])[:25]
+rows = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda t: -t[1])[:60]
 json.dump([dict(kernel=k, counter=c, total=t, dispatches=n, per_dispatch=t / max(n, 1)) for k, t, n in rows],
           open(f'{out}/pmc_{c}.json', 'w'), indent=1)
 PY
