@@ -244,6 +244,52 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def timed_region(step, a, distributed, dev, sync):
+    """EXACTLY a.steps steps bracketed by barrier + device synchronisation on both sides; returns (seconds - the MAX
+    over the ranks, last step's output)"""
+    sync()
+    if distributed:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(a.steps):
+        out = step(a.warmup + i)
+    sync()
+    if distributed:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+def plumbing_run(a, factory, rank, world, distributed):
+    """see OADG_BENCH_STEP_FACTORY in main(): same control flow as the GPU run, CPU tensors, gloo"""
+    import importlib
+    mod, fn = factory.split(':')
+    wl = getattr(importlib.import_module(mod), fn)(a, rank, world, distributed)
+    for i in range(a.warmup):
+        wl['step'](i)
+    dt, out = timed_region(wl['step'], a, distributed, torch.device('cpu'), lambda: None)
+    extras = wl['finish']() if 'finish' in wl else {}
+    if rank != 0:
+        return
+    print(json.dumps({
+        'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s', 'n_gpus': a.gpus,
+        'rccl_ranks': 0, 'world_size': dist.get_world_size() if distributed else 1,
+        'dist_backend': dist.get_backend() if distributed else None, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'fp32', 'data': 'synthetic',
+        'config': dict({'workload': 'PLUMBING RUN on CPU ranks (OADG_BENCH_STEP_FACTORY): NOT a measurement',
+                        'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}',
+                        'final_loss': round(float(out['loss']), 4)}, **extras),
+        'roofline': None, 'cpu_baseline': None}))
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -255,13 +301,19 @@ def main():
     from oadg_amd import Config, build_detector, hip_ops
     from oadg_amd.apis import TrainEngine, build_optimizer, init_dist, set_random_seed
     from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    # OADG_BENCH_STEP_FACTORY='module:function' (tests only, tests/test_cli.py): the launch / rendezvous / barrier / max-
+    # over-ranks / JSON plumbing of THIS script run on CPU ranks over gloo, with the step supplied by the named factory -
+    # there is no multi-GPU node to run the RCCL path on.  Its line is marked as a plumbing run, never a measurement.
+    plumbing = os.environ.get('OADG_BENCH_STEP_FACTORY')
     if distributed:
-        init_dist('pytorch', backend='nccl')
+        init_dist('pytorch', backend='gloo' if plumbing else 'nccl')
     rank = dist.get_rank() if distributed else 0
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    if plumbing:
+        return plumbing_run(a, plumbing, rank, world, distributed)
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dev = torch.device('cuda', torch.cuda.current_device())
-    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     cfg = Config.fromfile(CFG)
     amp = torch.bfloat16 if a.dtype == 'bf16' else None
     from oadg_amd import hip_conv
@@ -333,22 +385,7 @@ def main():
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':
             hip_conv.TIMERS_ONLY_VARIANT = None
     hip_ops.TIMERS = None
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = step(a.warmup + i)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, out = timed_region(step, a, distributed, dev, torch.cuda.synchronize)
     conv_timers, hip_conv.TIMERS = hip_conv.TIMERS, None
     loss = float(out['loss'])
     assert np.isfinite(loss), 'training diverged'
@@ -426,6 +463,7 @@ def main():
     res = {
         'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
         'n_gpus': a.gpus, 'rccl_ranks': (dist.get_world_size() if distributed and dist.get_backend() == 'nccl' else 1),
+        'world_size': dist.get_world_size() if distributed else 1, 'dist_backend': dist.get_backend() if distributed else None,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '

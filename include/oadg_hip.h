@@ -283,6 +283,17 @@ int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bia
 int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta, const float* mean,
                            const float* var, float eps, const float* bias_in, int K, int C, int R, int S, void* wf,
                            void* wt, float* bias, float* scale, int w_krsc, int wt_mode, void* stream);
+/* the same for many layers in ONE launch: a device table of descriptors (the arguments of oadg_prep_conv_weights per
+ * layer; first_block = sum of K of the layers before it, ascending), total_blocks = sum of K.  Weights change only in
+ * optimizer.step(), so a trainer re-prepares every layer once after it instead of per layer inside the forward pass. */
+typedef struct oadg_prep_desc {
+    const float *w, *gamma, *beta, *mean, *var, *bias_in;
+    void *wf, *wt;
+    float *bias, *scale;
+    float eps;
+    int K, C, R, S, w_krsc, wt_mode, first_block;
+} oadg_prep_desc;
+int oadg_prep_conv_weights_multi(const oadg_prep_desc* descs, int n_layers, int total_blocks, void* stream);
 int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
                                float* dgamma, int w_krsc, void* stream);

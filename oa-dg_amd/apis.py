@@ -281,6 +281,11 @@ class TrainEngine:
                 self.reducer.finish()
         with _rf('sec:optimizer'):
             self.optimizer.step()
+            if self.amp_dtype is torch.bfloat16:
+                # the parameters just changed: re-prepare every convolution's weights (BN fold, bf16 layouts) in one launch,
+                # so that the next forward pass prepares nothing (hip_conv.refresh_prepared)
+                from . import hip_conv
+                hip_conv.refresh_prepared()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
 
 

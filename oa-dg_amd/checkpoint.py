@@ -31,7 +31,9 @@ def resolve_checkpoint(name):
     stem = os.path.splitext(os.path.basename(m.group(2).rstrip('/')))[0]
     d = checkpoint_dir()
     if os.path.isdir(d):
-        hits = sorted(f for f in os.listdir(d) if f.startswith(stem) and f.endswith(('.pth', '.pt')))
+        # the stem followed by '-', '_' + hash, '.' or the extension: 'resnet50' must not pick up 'resnet50_caffe-*.pth'
+        pat = re.compile(r'^' + re.escape(stem) + r'([-.][^/]*)?\.(pth|pt)$')
+        hits = sorted(f for f in os.listdir(d) if pat.match(f))
         if hits:
             return os.path.join(d, hits[0])
     raise FileNotFoundError(

@@ -1685,15 +1685,13 @@ extern "C" int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, 
 // d gamma = (sum d wf * w - d bias * mean) / sqrt(var + eps), d beta = d bias.
 namespace {
 
-__global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta,
-                                                           const float* __restrict__ mean,
-                                                           const float* __restrict__ var, float eps,
-                                                           const float* __restrict__ bias_in, int K, int C, int R,
-                                                           int S, unsigned short* __restrict__ wf,
-                                                           unsigned short* __restrict__ wt, float* __restrict__ bias,
-                                                           float* __restrict__ scale_out, int w_krsc, int wt_mode) {
-    const int k = blockIdx.x;
+__device__ __forceinline__ void prep_weights_channel(int k, const float* __restrict__ w, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, float eps,
+                                                     const float* __restrict__ bias_in, int K, int C, int R, int S,
+                                                     unsigned short* __restrict__ wf, unsigned short* __restrict__ wt,
+                                                     float* __restrict__ bias, float* __restrict__ scale_out, int w_krsc,
+                                                     int wt_mode) {
     float scale = 1.f, b = bias_in ? bias_in[k] : 0.f;
     if (gamma) {
         scale = gamma[k] * rsqrtf(var[k] + eps);
@@ -1727,6 +1725,32 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, float eps,
+                                                           const float* __restrict__ bias_in, int K, int C, int R, int S,
+                                                           unsigned short* __restrict__ wf, unsigned short* __restrict__ wt,
+                                                           float* __restrict__ bias, float* __restrict__ scale_out,
+                                                           int w_krsc, int wt_mode) {
+    prep_weights_channel(blockIdx.x, w, gamma, beta, mean, var, eps, bias_in, K, C, R, S, wf, wt, bias, scale_out, w_krsc,
+                         wt_mode);
+}
+
+// every prepared layer of a model in ONE launch (weights change only in optimizer.step(): hip_conv.refresh_prepared
+// re-prepares all of them right after it instead of one launch per layer inside the next forward pass): workgroup b
+// belongs to the layer with first_block <= b < first_block + K (binary search over the descriptor table)
+__global__ __launch_bounds__(256) void prep_weights_multi_kernel(const oadg_prep_desc* __restrict__ descs, int n_layers) {
+    int lo = 0, hi = n_layers - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const oadg_prep_desc d = descs[lo];
+    prep_weights_channel(b - d.first_block, d.w, d.gamma, d.beta, d.mean, d.var, d.eps, d.bias_in, d.K, d.C, d.R, d.S,
+                         (unsigned short*)d.wf, (unsigned short*)d.wt, d.bias, d.scale, d.w_krsc, d.wt_mode);
 }
 
 __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned short* __restrict__ gwf,
@@ -1766,6 +1790,15 @@ extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const 
     if (gamma && (!beta || !mean || !var)) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, w, gamma, beta, mean, var, eps,
                        bias_in, K, C, R, S, (unsigned short*)wf, (unsigned short*)wt, bias, scale, w_krsc, wt_mode);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+// descs (device memory): n_layers descriptors sorted by first_block, first_block = sum of K over the layers before;
+// total_blocks = sum of K.  Same arithmetic per layer as oadg_prep_conv_weights.
+extern "C" int oadg_prep_conv_weights_multi(const oadg_prep_desc* descs, int n_layers, int total_blocks, void* stream) {
+    if (!descs || n_layers < 1 || total_blocks < 1) return OADG_EARG;
+    hipLaunchKernelGGL(prep_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_layers);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -351,7 +351,7 @@ class RPNHead(AnchorHead):
             tok = hip_conv.GradToken()
             # (in_token: an FPN level whose gradient this convolution finishes - necks.FPN._fpn_conv)
             x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok,
-                       in_token=getattr(x, '_oadg_token', None))
+                       in_token=getattr(x, '_oadg_token', None), owner=c)
             if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
                 w, b = self._fused_head_params()
                 y = conv2d(x, w, b, 1, 0, 1, in_token=tok)

@@ -12,9 +12,13 @@ import numpy as np
 
 IOU_THRS = np.linspace(.5, 0.95, int(np.round((0.95 - .5) / .05)) + 1, endpoint=True)
 REC_THRS = np.linspace(.0, 1.00, int(np.round((1.00 - .0) / .01)) + 1, endpoint=True)
-MAX_DETS = [1, 10, 100]
 AREA_RNG = [[0 ** 2, 1e5 ** 2], [0 ** 2, 32 ** 2], [32 ** 2, 96 ** 2], [96 ** 2, 1e5 ** 2]]
 METRICS = ['AP', 'AP50', 'AP75', 'APs', 'APm', 'APl', 'AR1', 'AR10', 'AR100', 'ARs', 'ARm', 'ARl']
+# CocoDataset.evaluate (mmdet/datasets/coco.py:362-575, CityscapesDataset delegates 'bbox' to it): proposal_nums =
+# (100, 300, 1000) become cocoEval.params.maxDets, mAP is taken at maxDets[-1] = 1000 and the names are mmdet's
+MMDET_MAX_DETS = (100, 300, 1000)
+MMDET_METRICS = ['mAP', 'mAP_50', 'mAP_75', 'mAP_s', 'mAP_m', 'mAP_l', 'AR@100', 'AR@300', 'AR@1000', 'AR_s@1000',
+                 'AR_m@1000', 'AR_l@1000']
 
 
 def _iou_xywh(d, g, iscrowd):
@@ -69,10 +73,16 @@ def _evaluate_img(gts, dts, a_rng, max_det):
     return dict(dtm=dtm, dt_ig=dt_ig, g_ig=g_ig, scores=np.array([d['score'] for d in dts], np.float64))
 
 
-def coco_eval_bbox(gt_anns, results, num_classes):
+def coco_eval_bbox(gt_anns, results, num_classes, max_dets=None, names=None):
     """gt_anns: per image, list of dict(bbox=[x, y, w, h], category=label index, area, iscrowd);
     results: per image, list over classes of arrays [k, 5] = x1, y1, x2, y2, score (``bbox2result`` format).
-    Returns dict(metric name -> value) with the twelve COCO numbers (-1 where undefined)."""
+    Returns dict(metric name -> value) with the twelve COCO numbers (-1 where undefined).
+    ``max_dets`` / ``names``: COCOeval's defaults (1, 10, 100) with its own names - what test_robustness.py's
+    coco_eval_with_return reports - or MMDET_MAX_DETS / MMDET_METRICS for the numbers of ``CocoDataset.evaluate``
+    (tools/test.py --eval bbox)."""
+    MAX_DETS = list(max_dets) if max_dets is not None else [1, 10, 100]
+    names = list(names) if names is not None else METRICS
+    assert len(MAX_DETS) == 3 and len(names) == 12
     n_img = len(gt_anns)
     assert len(results) == n_img
     T, R, K, A, M = len(IOU_THRS), len(REC_THRS), num_classes, len(AREA_RNG), len(MAX_DETS)
@@ -132,7 +142,7 @@ def coco_eval_bbox(gt_anns, results, num_classes):
     stats = [summarize(1), summarize(1, .5), summarize(1, .75), summarize(1, None, 1), summarize(1, None, 2),
              summarize(1, None, 3), summarize(0, None, 0, 0), summarize(0, None, 0, 1), summarize(0, None, 0, 2),
              summarize(0, None, 1), summarize(0, None, 2), summarize(0, None, 3)]
-    return dict(zip(METRICS, stats))
+    return dict(zip(names, stats))
 
 
 def dataset_gt_anns(dataset, indices=None):

@@ -254,7 +254,7 @@ class _PrepWeights(torch.autograd.Function):
     and casts; the backward is one launch as well."""
 
     @staticmethod
-    def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt, wtoken=None):
+    def forward(ctx, w, gamma, beta, mean, var, eps, bias_in, want_wt, wtoken=None, entry=None):
         L = _lib.lib()
         K, C, R, S = w.shape
         leaf = all(t is None or t.grad_fn is None for t in (w, gamma, beta, bias_in))
@@ -264,20 +264,27 @@ class _PrepWeights(torch.autograd.Function):
         krsc = int(R * S > 1 and not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last))
         if not krsc:
             w = w.contiguous()
-        dev = w.device
-        wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         want_wt = int(want_wt)         # 0 none, 1 flipped / transposed copy (stride-1 dgrad), 2 stride-2 parity classes
-        wt = torch.empty((C, K, R, S), dtype=torch.bfloat16, device=dev,
-                         memory_format=torch.channels_last) if want_wt else None
-        has_bias = gamma is not None or bias_in is not None
-        bias = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
-        scale = torch.empty((K,), dtype=torch.float32, device=dev) if gamma is not None else None
         f = lambda t: None if t is None else (t.detach() if (t.dtype == torch.float32 and t.is_contiguous())  # noqa: E731
                                               else t.detach().float().contiguous())
-        g_, b_, m_, v_, bi_ = f(gamma), f(beta), f(mean), f(var), f(bias_in)
-        check(L.oadg_prep_conv_weights(ptr(w), ptr(g_), ptr(b_), ptr(m_), ptr(v_), float(eps), ptr(bi_), K, C, R, S,
-                                       ptr(wf), ptr(wt), ptr(bias), ptr(scale), krsc, want_wt, stream_ptr()),
-              'oadg_prep_conv_weights')
+        if entry is not None and entry.valid:
+            # prepared by refresh_prepared() right after the last optimizer step (or by the previous forward pass with the
+            # parameters unchanged since): nothing to launch
+            wf, wt, bias, scale, m_, v_ = entry.wf, entry.wt, entry.bias, entry.scale, entry.mean, entry.var
+        else:
+            dev = w.device
+            wf = torch.empty((K, C, R, S), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            wt = torch.empty((C, K, R, S), dtype=torch.bfloat16, device=dev,
+                             memory_format=torch.channels_last) if want_wt else None
+            has_bias = gamma is not None or bias_in is not None
+            bias = torch.empty((K,), dtype=torch.float32, device=dev) if has_bias else None
+            scale = torch.empty((K,), dtype=torch.float32, device=dev) if gamma is not None else None
+            g_, b_, m_, v_, bi_ = f(gamma), f(beta), f(mean), f(var), f(bias_in)
+            check(L.oadg_prep_conv_weights(ptr(w), ptr(g_), ptr(b_), ptr(m_), ptr(v_), float(eps), ptr(bi_), K, C, R, S,
+                                           ptr(wf), ptr(wt), ptr(bias), ptr(scale), krsc, want_wt, stream_ptr()),
+                  'oadg_prep_conv_weights')
+            if entry is not None:
+                entry.fill(w, g_, b_, m_, v_, float(eps), bi_, K, C, R, S, wf, wt, bias, scale, krsc, want_wt)
         ctx.save_for_backward(w, scale, m_, v_)
         # no zero tensors for the outputs nobody differentiates (autograd would otherwise fill a weight-sized zero
         # gradient for the transposed copy and a [K] one for an unused bias on every step); backward handles None
@@ -285,6 +292,8 @@ class _PrepWeights(torch.autograd.Function):
         ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S, krsc)
         ctx.leaf_inputs = leaf      # False: autograd ops (not AccumulateGrad) consume the gradients next
         ctx.wtoken = wtoken
+        if entry is not None:       # the bank's tensors live across steps: hand out fresh aliases (autograd stamps outputs)
+            wf, bias, wt = wf.detach(), (bias.detach() if bias is not None else None), (wt.detach() if wt is not None else None)
         outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
         ctx.mark_non_differentiable(outs[2])
         return outs
@@ -318,7 +327,7 @@ class _PrepWeights(torch.autograd.Function):
             dbeta = gb
         elif has_bias_in:
             dbias_in = gb
-        return dw, dgamma, dbeta, None, None, None, dbias_in, None, None
+        return dw, dgamma, dbeta, None, None, None, dbias_in, None, None, None
 
 
 S2_DGRAD = os.environ.get('OADG_S2_DGRAD', '1') == '1'      # stride-2 data gradients on the csrc kernels (else MIOpen)
@@ -337,9 +346,102 @@ def _wt_useful(x, K, C, stride, pad, dil, R):
     return 0
 
 
+class _BankEntry:
+    """The prepared tensors of one trainable convolution, kept across steps (weights change only in optimizer.step()):
+    ``valid`` while the version counters of the source parameters are the ones the tensors were prepared from."""
+    __slots__ = ('src', 'versions', 'args', 'wf', 'wt', 'bias', 'scale', 'mean', 'var', 'want_wt', '__weakref__')
+
+    def __init__(self, src, want_wt):
+        self.src, self.want_wt = src, int(want_wt)           # src: the tensors whose versions define validity
+        self.versions = None
+        self.wf = self.wt = self.bias = self.scale = self.mean = self.var = self.args = None
+
+    def current_versions(self):
+        return tuple((t._version, t.data_ptr()) for t in self.src)
+
+    @property
+    def valid(self):
+        return self.versions is not None and self.versions == self.current_versions()
+
+    def fill(self, w, g_, b_, m_, v_, eps, bi_, K, C, R, S, wf, wt, bias, scale, krsc, want_wt):
+        # the bank re-reads the SOURCE tensors later: only layers whose kernel operands alias their parameters / buffers
+        # (fp32, dense - no dtype or layout copy was made for the launch) can be refreshed in place
+        ops = [w] + ([g_, b_, m_, v_] if g_ is not None else []) + ([bi_] if bi_ is not None else [])
+        if len(ops) != len(self.src) or any(a.data_ptr() != s_.data_ptr() for a, s_ in zip(ops, self.src)):
+            self.args = self.versions = None
+            return
+        self.args = (w, g_, b_, m_, v_, eps, bi_, K, C, R, S, krsc, want_wt)
+        self.wf, self.wt, self.bias, self.scale, self.mean, self.var = wf, wt, bias, scale, m_, v_
+        self.versions = self.current_versions()
+        _BANK.register(self)
+
+
+class _Bank:
+    """All bank entries of the process + the device descriptor table of oadg_prep_conv_weights_multi."""
+
+    def __init__(self):
+        import weakref
+        self.entries = weakref.WeakSet()
+        self.table = None            # (device tensor, [entries in table order], total blocks)
+        self.dirty = True
+
+    def register(self, e):
+        if e not in self.entries:
+            self.entries.add(e)
+        self.dirty = True            # (tensors of an entry may have been re-allocated)
+
+    def refresh(self):
+        """re-prepare every registered layer whose parameters changed, in ONE launch; returns the number of layers"""
+        import numpy as np
+        import weakref
+        ents = [e for e in self.entries if e.args is not None and e.args[0].is_cuda]
+        if not ents:
+            self.table = None
+            return 0
+        if self.dirty or self.table is None or len(self.table[1]) != len(ents) or any(r() is None for r in self.table[1]):
+            ents.sort(key=lambda e: e.wf.data_ptr())
+            dt = np.dtype([('w', 'u8'), ('gamma', 'u8'), ('beta', 'u8'), ('mean', 'u8'), ('var', 'u8'), ('bias_in', 'u8'),
+                           ('wf', 'u8'), ('wt', 'u8'), ('bias', 'u8'), ('scale', 'u8'), ('eps', 'f4'), ('K', 'i4'),
+                           ('C', 'i4'), ('R', 'i4'), ('S', 'i4'), ('w_krsc', 'i4'), ('wt_mode', 'i4'),
+                           ('first_block', 'i4')], align=True)
+            tab = np.zeros((len(ents),), dt)
+            p_ = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+            first = 0
+            for i, e in enumerate(ents):
+                w, g_, b_, m_, v_, eps, bi_, K, C, R, S, krsc, want_wt = e.args
+                tab[i] = (p_(w), p_(g_), p_(b_), p_(m_), p_(v_), p_(bi_), p_(e.wf), p_(e.wt), p_(e.bias), p_(e.scale),
+                          eps, K, C, R, S, krsc, want_wt, first)
+                first += K
+            dev = ents[0].wf.device
+            t = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
+            # (weak references: the table must not keep the layers of a model that was dropped alive)
+            self.table, self.dirty = (t, [weakref.ref(e) for e in ents], first), False
+        t, refs, total = self.table
+        check(_lib.lib().oadg_prep_conv_weights_multi(ptr(t), len(refs), total, stream_ptr()),
+              'oadg_prep_conv_weights_multi')
+        for e in ents:
+            e.versions = e.current_versions()
+        return len(refs)
+
+
+_BANK = _Bank()
+PREP_BANK = os.environ.get('OADG_PREP_BANK', '1') == '1'
+
+
+def refresh_prepared():
+    """Call right after optimizer.step(): one multi-layer launch re-prepares (BN fold, bf16 KRSC, data-gradient layouts)
+    every trainable convolution, so that the next forward pass launches no weight preparation at all.  Layers whose
+    parameters are changed by anything else afterwards (load_state_dict, manual edits - anything that bumps the tensors'
+    version counters) are simply prepared again by their next forward call."""
+    if not (ENABLED and PREP_BANK):
+        return 0
+    return _BANK.refresh()
+
+
 def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
     """(wf, bias, wt) for a convolution, BN-folded when ``bn`` is given.  Layers without trainable parameters are
-    prepared once (``cache_on`` = the module that owns the weight)."""
+    prepared once (``cache_on`` = the module that owns the weight); trainable ones keep their prepared tensors in a bank
+    entry that ``refresh_prepared()`` updates after every optimizer step."""
     frozen = not (conv_weight.requires_grad or (bn is not None and (bn.weight.requires_grad or bn.bias.requires_grad))
                   or (bias_in is not None and bias_in.requires_grad))
     key = None
@@ -351,11 +453,20 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
         if c is not None and c[0] == key:
             return c[1]
     tok = None if frozen else WeightGradToken()
+    entry = None
+    if not frozen and cache_on is not None and PREP_BANK and conv_weight.dtype == torch.float32 and \
+            all(t.grad_fn is None for t in (conv_weight, bias_in) if t is not None):
+        entry = getattr(cache_on, '_oadg_prep_entry', None)
+        if entry is None or entry.want_wt != int(want_wt) or entry.src[0] is not conv_weight:
+            src = [conv_weight] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else []) + \
+                ([bias_in] if bias_in is not None else [])
+            entry = _BankEntry(src, want_wt)
+            cache_on._oadg_prep_entry = entry
     if bn is not None:
         out = _PrepWeights.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None,
-                                 want_wt, tok)
+                                 want_wt, tok, entry)
     else:
-        out = _PrepWeights.apply(conv_weight, None, None, None, None, 0.0, bias_in, want_wt, tok)
+        out = _PrepWeights.apply(conv_weight, None, None, None, None, 0.0, bias_in, want_wt, tok, entry)
     wf, bias, wt = out
     if tok is not None:
         wf._oadg_wtoken = tok
@@ -454,6 +565,12 @@ class _Conv2dMFMA(torch.autograd.Function):
             extra, in_token.extra = in_token.extra, None
             in_token.closed = True
         deposit = need_x and dep_token is not None and dep_token.armed and not dep_token.closed and DEPOSIT
+        if need_x and dep_token is not None and dep_token.closed:
+            # a depositor running AFTER the finisher: its gradient is returned and autograd adds it to the finisher's -
+            # possibly IN PLACE into the very tensor ``grad_ptr`` names (InputBuffer accumulates in place when it holds the
+            # last reference), which the pointer check of the producer could not see.  Taint the token: the producer then
+            # masks and reduces the summed gradient itself.
+            dep_token.grad_ptr = dep_token.colsum = None
         if deposit:
             # this tensor's gradient is finished by another convolution: add what was deposited so far in THIS launch's
             # epilogue, leave the sum on the token, return nothing

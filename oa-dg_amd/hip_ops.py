@@ -249,6 +249,8 @@ def _deposit(tokens, grads):
             tok.extra = g if tok.extra is None else tok.extra + g
             out.append(None)
         else:
+            if tok is not None and tok.closed:
+                tok.grad_ptr = tok.colsum = None        # late depositor: the producer must not trust the finisher's result
             out.append(g)
     return out
 

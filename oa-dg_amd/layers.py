@@ -35,7 +35,7 @@ class Conv2d(nn.Conv2d):
 
     def forward(self, x):
         assert self.groups == 1 and self.padding_mode == 'zeros'
-        return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        return conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, owner=self)
 
 
 # Frozen-statistics BatchNorm (norm_eval=True: every BN of the detector, resnet.py:648-657) is a per-channel

@@ -55,7 +55,8 @@ class FPN(nn.Module):
         tok = getattr(x, '_oadg_token', None)
         if (tok is not None or out_token is not None) and not (conv.with_norm or conv.with_activation):
             c = conv.conv
-            return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok, out_token=out_token)
+            return layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, dep_token=tok, out_token=out_token,
+                                 owner=c)
         return conv(x)
 
     @staticmethod
@@ -69,7 +70,8 @@ class FPN(nn.Module):
                 torch.is_grad_enabled() and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()):
             c = conv.conv
             tok = hip_conv.GradToken(masked=False)
-            y = layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, out_token=tok, in_token=in_token)
+            y = layers.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, out_token=tok, in_token=in_token,
+                              owner=c)
             if getattr(y.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
                 y._oadg_token = tok
             return y

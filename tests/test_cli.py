@@ -4,6 +4,7 @@ import importlib.util
 import os
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -122,6 +123,22 @@ def test_train_cli_shuffles_checkpoints_and_resumes_epoch_and_iter(tmp_path):
     ck2 = torch.load(str(w2 / 'epoch_3.pth'), map_location='cpu', weights_only=False)
     assert ck2['meta']['epoch'] == 3 and ck2['meta']['iter'] == 12
     assert not (w2 / 'epoch_1.pth').exists()                                          # earlier epochs are not redone
+    # a run cut short INSIDE an epoch (--max-iters 6 = 2 batches into epoch 2): latest.pth records the unfinished epoch and
+    # the batches done, --auto-resume finishes that epoch's (seeded) order from batch 3 instead of skipping it
+    w3 = tmp_path / 'w3'
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train.py'), str(cfg), '--work-dir', str(w3), '--seed', '0',
+                         '--max-iters', '6'], capture_output=True, text=True, env=env, timeout=900)
+    assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-2000:]
+    ck3 = torch.load(str(w3 / 'latest.pth'), map_location='cpu', weights_only=False)
+    assert ck3['meta']['epoch'] == 1 and ck3['meta']['iter'] == 6 and ck3['meta']['inner_iter'] == 2
+    assert (w3 / 'epoch_1.pth').exists() and not (w3 / 'epoch_2.pth').exists()
+    r4 = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train.py'), str(cfg), '--work-dir', str(w3), '--seed', '0',
+                         '--auto-resume'], capture_output=True, text=True, env=env, timeout=900)
+    assert r4.returncode == 0, r4.stdout[-2000:] + r4.stderr[-2000:]
+    lines4 = [l for l in r4.stdout.splitlines() if l.startswith('Epoch [')]
+    assert len(lines4) == 6 and lines4[0].startswith('Epoch [2][3/4]') and lines4[-1].startswith('Epoch [3][4/4]')
+    ck4 = torch.load(str(w3 / 'epoch_3.pth'), map_location='cpu', weights_only=False)
+    assert ck4['meta']['epoch'] == 3 and ck4['meta']['iter'] == 12
 
 
 @pytest.mark.gpu
@@ -139,8 +156,10 @@ def test_test_cli_coco_style_eval_and_robustness_loop(tmp_path):
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     ev = json.load(open(wd / 'eval.json'))
-    assert list(ev['bbox']) == ['AP', 'AP50', 'AP75', 'APs', 'APm', 'APl', 'AR1', 'AR10', 'AR100', 'ARs', 'ARm', 'ARl']
-    assert -1.0 <= ev['bbox']['AP'] <= 1.0 and 'mAP' in ev['mAP']
+    # CocoDataset.evaluate's numbers and names: maxDets (100, 300, 1000), mAP at 1000 detections (coco.py:468-480)
+    assert list(ev['bbox']) == ['mAP', 'mAP_50', 'mAP_75', 'mAP_s', 'mAP_m', 'mAP_l', 'AR@100', 'AR@300', 'AR@1000', 'AR_s@1000',
+                                'AR_m@1000', 'AR_l@1000']
+    assert -1.0 <= ev['bbox']['mAP'] <= 1.0 and 'mAP' in ev['mAP']
     assert len(pickle.load(open(tmp_path / 'r.pkl', 'rb'))) == 2
     out = tmp_path / 'rob.pkl'
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'analysis_tools', 'test_robustness.py'), cfg, 'none',
@@ -154,3 +173,31 @@ def test_test_cli_coco_style_eval_and_robustness_loop(tmp_path):
         agg['snow'][0] == agg['fog'][0]
     summ = json.load(open(tmp_path / 'rob_summary.json'))
     assert set(summ) == {'P', 'mPC', 'rPC'} and 'Mean Performance under Corruption [mPC] (bbox)' in r.stdout
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_through_its_own_launch_path_on_gloo():
+    """``python bench.py --gpus 2`` end to end - self-launch under torch.distributed.run on 127.0.0.1, env:// rendezvous,
+    warm-up, barrier-bracketed timed region, MAX over ranks, ONE JSON line from rank 0 - with the whole detector step of
+    tests/ddp_bench_factory.py on CPU ranks over gloo (no multi-GPU node exists for the RCCL path):
+    world plumbing as reported, parameters identical on both ranks after 2 steps of different data per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env['OADG_BENCH_STEP_FACTORY'] = 'ddp_bench_factory:make'
+    env['PYTHONPATH'] = os.path.join(ROOT, 'tests') + os.pathsep + env.get('PYTHONPATH', '')
+    env.pop('WORLD_SIZE', None)
+    env['OMP_NUM_THREADS'] = '3'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0',
+                        '--batch', '1', '--height', '128', '--width', '192', '--no-cpu-baseline'],
+                       env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['world_size'] == 2 and d['dist_backend'] == 'gloo' and d['steps'] == 2
+    assert d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
+    assert d['rccl_ranks'] == 0 and 'PLUMBING' in d['config']['workload']
+    assert d['config']['params_equal_across_ranks'] is True
+    assert d['config']['param_tensors_changed'] == d['config']['param_tensors'] > 100
+    assert np.isfinite(d['config']['final_loss']) and d['value'] > 0

@@ -84,3 +84,17 @@ def test_robustness_bookkeeping():
     assert agg['P']['AP'] == pytest.approx(0.4)
     exp = np.mean([[0.4 - 0.05 * s - 0.1 * ci for s in range(1, 6)] for ci in range(2)])
     assert agg['mPC']['AP'] == pytest.approx(exp, abs=1e-6) and agg['rPC']['AP'] == pytest.approx(exp / 0.4, abs=1e-6)
+
+
+def test_mmdet_style_max_dets_and_names():
+    """CocoDataset.evaluate (coco.py:468-480) sets maxDets = (100, 300, 1000): 150 equally good detections of 150 objects
+    give AR@100 = 100 / 150 under COCOeval's default cut (AR100) but the full recall at 300 / 1000, and mAP is taken at
+    1000 detections."""
+    gts = [[_gt(10 * i, 0, 10 * i + 8, 8) for i in range(150)]]
+    dets = [[10 * i, 0, 10 * i + 8, 8, 0.9 - 1e-4 * i] for i in range(150)]
+    d = E.coco_eval_bbox(gts, [_res(dets)], 1)
+    assert d['AR100'] == pytest.approx(100 / 150) and d['AP'] < 0.7
+    m = E.coco_eval_bbox(gts, [_res(dets)], 1, max_dets=E.MMDET_MAX_DETS, names=E.MMDET_METRICS)
+    assert list(m) == E.MMDET_METRICS
+    assert m['AR@100'] == pytest.approx(100 / 150) and m['AR@300'] == pytest.approx(1.0) and m['AR@1000'] == pytest.approx(1.0)
+    assert m['mAP'] == pytest.approx(1.0) and m['mAP_50'] == pytest.approx(1.0)

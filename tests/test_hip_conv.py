@@ -708,3 +708,83 @@ def test_stem_conv_kernel_matches_fp32_reference(dev, N, H, W):
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     d = (y.float() - ref).abs()
     assert d.max().item() <= 8e-3 * ref.abs().max().item() + 1e-6, (d.max().item(), ref.abs().max().item())
+
+
+def test_weight_bank_refresh_equals_per_layer_preparation(dev):
+    """hip_conv.refresh_prepared() (ONE multi-layer launch after optimizer.step()) must leave exactly the tensors the
+    per-layer preparation of the next forward pass would have produced - BN-folded bf16 weights, bias, scale and both
+    data-gradient layouts (flipped / transposed for stride 1, parity classes for stride 2) - for plain and channels_last
+    parameters, with and without BatchNorm; afterwards a forward pass launches no preparation (entries valid), and any
+    other in-place change of a parameter invalidates its entry."""
+    import torch.nn as nn
+    from oadg_amd import hip_conv, layers
+    torch.manual_seed(3)
+    hip_conv.enable()
+    try:
+        specs = [(64, 128, 3, 1, 1, True, True), (128, 64, 1, 1, 0, True, False), (64, 64, 3, 2, 1, True, True),
+                 (128, 256, 1, 2, 0, True, False), (64, 128, 3, 1, 1, False, True)]
+        mods, params = [], []
+        for C, K, R, st, pd, has_bn, cl in specs:
+            conv = nn.Conv2d(C, K, R, st, pd, bias=not has_bn).to(dev)
+            if cl:
+                conv = conv.to(memory_format=torch.channels_last)
+            bn = None
+            if has_bn:
+                bn = nn.BatchNorm2d(K).to(dev).eval()
+                with torch.no_grad():
+                    bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+            mods.append((conv, bn))
+            params += list(conv.parameters()) + (list(bn.parameters()) if bn is not None else [])
+        opt = torch.optim.SGD(params, lr=0.1, momentum=0.9)
+
+        def forward():
+            outs = []
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                for conv, bn in mods:
+                    x = torch.randn(2, conv.in_channels, 16, 20, device=dev).bfloat16() \
+                        .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                    y = layers.conv_bn(x, conv, bn) if bn is not None else layers.conv2d(
+                        x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation, owner=conv)
+                    outs.append(y)
+            return outs
+
+        def snapshot():
+            out = []
+            for conv, _ in mods:
+                e = conv._oadg_prep_entry
+                assert e.args is not None and e.valid
+                out.append([t.clone() if t is not None else None for t in (e.wf, e.wt, e.bias, e.scale)])
+            return out
+        torch.manual_seed(1)
+        sum(o.float().sum() for o in forward()).backward()         # fills the entries, produces gradients
+        opt.step()
+        assert not any(conv._oadg_prep_entry.valid for conv, _ in mods)        # versions moved
+        n = hip_conv.refresh_prepared()
+        assert n >= len(mods)            # (the bank is per process: layers of other live models are refreshed too)
+        banked = snapshot()
+        # reference: the per-layer preparation from the same (updated) parameters
+        for (conv, bn), got in zip(mods, banked):
+            e = conv._oadg_prep_entry
+            if bn is not None:
+                ref = hip_conv._PrepWeights.apply(conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                                                  None, e.want_wt, None, None)
+            else:
+                ref = hip_conv._PrepWeights.apply(conv.weight, None, None, None, None, 0.0, conv.bias, e.want_wt, None, None)
+            assert torch.equal(ref[0], got[0])
+            assert torch.equal(ref[1], got[2])
+            if e.want_wt:
+                assert torch.equal(ref[2], got[1])
+        # a forward pass on valid entries hands out the banked tensors (same storage)
+        torch.manual_seed(1)
+        forward()
+        for conv, _ in mods:
+            assert conv._oadg_prep_entry.valid
+        with torch.no_grad():
+            mods[0][0].weight.mul_(0.5)
+        assert not mods[0][0]._oadg_prep_entry.valid and mods[1][0]._oadg_prep_entry.valid
+        torch.manual_seed(1)
+        y = forward()[0]
+        assert mods[0][0]._oadg_prep_entry.valid            # re-prepared by its forward call
+        assert torch.isfinite(y.float()).all()
+    finally:
+        hip_conv.enable(False)

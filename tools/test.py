@@ -125,13 +125,17 @@ def run_test(model, data_cfg, dev, amp, samples_per_gpu=1, max_samples=None):
     return results, ds, time.time() - t0
 
 
-def evaluate(results, ds, metrics, num_classes):
-    """{'bbox': {AP, AP50, ...}} (COCO style) and / or {'mAP': ...} (VOC style AP@0.5)"""
+def evaluate(results, ds, metrics, num_classes, mmdet_style=False):
+    """{'bbox': {AP, AP50, ...}} (COCO style) and / or {'mAP': ...} (VOC style AP@0.5).  ``mmdet_style``: the numbers and
+    names of CocoDataset.evaluate (maxDets 100 / 300 / 1000, mAP at 1000 detections: mAP, mAP_50, ..., AR@100, ...) -
+    what tools/test.py prints, comparable with the reference's logs; False: COCOeval's defaults (1 / 10 / 100), which is
+    what the robustness benchmark aggregates (test_robustness.py coco_eval_with_return)."""
     from oadg_amd import evaluation as E
     out = {}
     idx = range(len(results))
     if 'bbox' in metrics:
-        out['bbox'] = E.coco_eval_bbox(E.dataset_gt_anns(ds, idx), results, num_classes)
+        kw = dict(max_dets=E.MMDET_MAX_DETS, names=E.MMDET_METRICS) if mmdet_style else {}
+        out['bbox'] = E.coco_eval_bbox(E.dataset_gt_anns(ds, idx), results, num_classes, **kw)
     if 'mAP' in metrics:
         anns = []
         for i in idx:
@@ -167,7 +171,7 @@ def main():
     if a.eval:
         assert set(a.eval) <= {'bbox', 'mAP'}, "--eval bbox (COCO style) and / or mAP (VOC style AP@0.5)"
         nc = len(getattr(ds, 'CLASSES', None) or range(dcfg.get('num_classes', 8)))
-        ev = evaluate(results, ds, a.eval, nc)
+        ev = evaluate(results, ds, a.eval, nc, mmdet_style=True)
         if 'bbox' in ev:
             print('bbox (COCO style): ' + '  '.join(f'{k} {v:.3f}' for k, v in ev['bbox'].items()))
         if 'mAP' in ev:

@@ -102,10 +102,11 @@ def main():
     model = build_detector(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
     from oadg_amd.checkpoint import load_checkpoint
     log0 = print if rank == 0 else None
-    model.init_weights(allow_missing_pretrained=a.allow_missing_pretrained)
+    # (None when the flag is absent: ResNet.init_weights then honours OADG_ALLOW_RANDOM_INIT=1)
+    model.init_weights(allow_missing_pretrained=True if a.allow_missing_pretrained else None)
     model = model.to(dev).to(memory_format=torch.channels_last).train()
     resume = a.resume_from or (latest_checkpoint(work_dir) if a.auto_resume else None) or cfg.get('resume_from')
-    start_iter = start_epoch = 0
+    start_iter = start_epoch = skip_batches = 0
     optimizer = build_optimizer(model, cfg.optimizer)
     load_from = cfg.get('load_from')
     if resume:
@@ -116,8 +117,12 @@ def main():
             optimizer.load_state_dict(ck['optimizer'])
         start_iter = int(ck.get('meta', {}).get('iter', 0))
         start_epoch = int(ck.get('meta', {}).get('epoch', 0))
+        # a run stopped INSIDE an epoch (--max-iters) saved meta.epoch = the unfinished epoch and meta.inner_iter = the
+        # batches of it already trained: that epoch is re-entered and those batches of its (seeded) order are skipped
+        skip_batches = int(ck.get('meta', {}).get('inner_iter', 0))
         if rank == 0:
-            print(f'resumed epoch {start_epoch}, iter {start_iter} from {resume}', flush=True)
+            print(f'resumed epoch {start_epoch}, iter {start_iter}' + (f' (+{skip_batches} batches into the epoch)'
+                                                                        if skip_batches else '') + f' from {resume}', flush=True)
     elif load_from:
         # mmdet checkpoints ({'state_dict': ...}, same key names); a head trained for another class count is dropped
         # key by key and reported, as mmcv.load_checkpoint does (apis/train.py:196-197)
@@ -149,12 +154,24 @@ def main():
     iters_per_epoch = len(sampler) // bs
     interval = cfg.get('log_config', {}).get('interval', 50)
 
-    def save_checkpoint(epoch, it):
-        if rank == 0 and cfg.get('checkpoint_config', {}).get('interval', 0):
+    ck_interval = int(cfg.get('checkpoint_config', {}).get('interval', 0) or 0)
+
+    def save_checkpoint(epoch, it, inner=None):
+        """CheckpointHook (by_epoch): epoch_{n}.pth after every ``interval``-th COMPLETED epoch (+ latest.pth).  ``inner``
+        (a run cut short by --max-iters inside an epoch): only latest.pth, with meta.epoch = the unfinished epoch and
+        meta.inner_iter = its batches already trained, so that a resumed run finishes that epoch instead of skipping it."""
+        if rank != 0 or not ck_interval:
+            return
+        if inner is None:
+            if (epoch + 1) % ck_interval != 0 and epoch + 1 != epochs:
+                return
             state = dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
                          meta=dict(iter=it, epoch=epoch + 1, mmdet_version='2.20.0-compatible keys'))
             torch.save(state, os.path.join(work_dir, f'epoch_{epoch + 1}.pth'))
-            torch.save(state, os.path.join(work_dir, 'latest.pth'))
+        else:
+            state = dict(state_dict=model.state_dict(), optimizer=optimizer.state_dict(),
+                         meta=dict(iter=it, epoch=epoch, inner_iter=inner, mmdet_version='2.20.0-compatible keys'))
+        torch.save(state, os.path.join(work_dir, 'latest.pth'))
 
     it, t0 = start_iter, time.time()
     # software pipeline, the analogue of the reference's DataLoader workers: a loader thread produces batch i+2 (decode +
@@ -166,6 +183,8 @@ def main():
         for epoch in range(start_epoch, epochs):          # a resumed run continues with the epoch after the saved one
             sampler.set_epoch(epoch)
             for k, idx in enumerate(batches(sampler.indices(), bs)):
+                if epoch == start_epoch and k < skip_batches:
+                    continue                              # trained before the run was interrupted inside this epoch
                 yield epoch, k, idx
 
     def load(item):
@@ -188,10 +207,11 @@ def main():
                 pending_load.append(loader.submit(load, nxt))
             staged.append((item[0], item[1], pipe.prefetch(*batch, worker_seed=wseed, ready=ready)))
     advance()
-    last_epoch = None
+    last_epoch, done_in_epoch, cut_short = None, 0, False
     while staged:
         epoch, k, handle = staged.pop(0)
         if a.max_iters is not None and it >= a.max_iters:
+            cut_short = done_in_epoch < iters_per_epoch
             break
         if last_epoch is not None and epoch != last_epoch:
             save_checkpoint(last_epoch, it)
@@ -201,13 +221,14 @@ def main():
         advance()                        # batch i+1 is augmented while this step runs
         out = engine.step(data)
         it += 1
+        done_in_epoch = k + 1
         if rank == 0 and it % interval == 0:
             lv = {n: float(v) for n, v in out['log_vars'].items()}
             print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
                   f'time: {(time.time() - t0) / (it - start_iter):.3f} ' +
                   ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
     if last_epoch is not None:
-        save_checkpoint(last_epoch, it)
+        save_checkpoint(last_epoch, it, inner=done_in_epoch if cut_short else None)
     loader.shutdown(wait=False, cancel_futures=True)
 
 
