@@ -1,5 +1,6 @@
-"""Inference post-processing: ``multiclass_nms`` (mmdet/core/post_processing/bbox_nms.py:8-98) and
-``bbox2result`` (mmdet/core/bbox/transforms.py:118-139).
+"""Inference post-processing: ``multiclass_nms`` (mmdet/core/post_processing/bbox_nms.py:8-98),
+``bbox2result`` (mmdet/core/bbox/transforms.py:118-139) and the test-time-augmentation merges
+(mmdet/core/post_processing/merge_augs.py:13-112, mmdet/core/bbox/transforms.py:22-72).
 
 ``mmcv.ops.batched_nms`` (class-offset trick + greedy NMS in descending-score order) runs through the same device
 kernel as the RPN proposals (csrc/nms.hip via ``hip_ops.nms_sorted_batched``): boxes under the score threshold are
@@ -58,3 +59,73 @@ def bbox2result(bboxes, labels, num_classes):
         bboxes = bboxes.detach().cpu().numpy()
         labels = labels.detach().cpu().numpy()
     return [bboxes[labels == i, :] for i in range(num_classes)]
+
+
+# ------------------------------------------------------------------------------------ test-time augmentation merges
+def bbox_flip(bboxes, img_shape, direction='horizontal'):
+    """transforms.py:22-49: boxes [..., 4k] flipped inside an image of ``img_shape`` (h, w, ...)"""
+    assert bboxes.shape[-1] % 4 == 0 and direction in ('horizontal', 'vertical', 'diagonal')
+    flipped = bboxes.clone()
+    if direction in ('horizontal', 'diagonal'):
+        flipped[..., 0::4] = img_shape[1] - bboxes[..., 2::4]
+        flipped[..., 2::4] = img_shape[1] - bboxes[..., 0::4]
+    if direction in ('vertical', 'diagonal'):
+        flipped[..., 1::4] = img_shape[0] - bboxes[..., 3::4]
+        flipped[..., 3::4] = img_shape[0] - bboxes[..., 1::4]
+    return flipped
+
+
+def bbox_mapping(bboxes, img_shape, scale_factor, flip, flip_direction='horizontal'):
+    """original image scale -> testing scale (transforms.py:51-60)"""
+    new = bboxes * bboxes.new_tensor(scale_factor)
+    return bbox_flip(new, img_shape, flip_direction) if flip else new
+
+
+def bbox_mapping_back(bboxes, img_shape, scale_factor, flip, flip_direction='horizontal'):
+    """testing scale -> original image scale (transforms.py:63-72)"""
+    new = bbox_flip(bboxes, img_shape, flip_direction) if flip else bboxes
+    new = new.view(-1, 4) / new.new_tensor(scale_factor)
+    return new.view(bboxes.shape)
+
+
+def nms_plain(dets, iou_thr):
+    """mmcv.ops.nms on dets [n, 5]: the kept rows in descending-score order (greedy, IoU > thr suppressed)"""
+    if dets.shape[0] == 0:
+        return dets
+    order = dets[:, 4].sort(descending=True, stable=True)[1]
+    boxes = dets[order, :4].float().contiguous()
+    keep, cnt = hip_ops.nms_sorted_batched(boxes[None], torch.tensor([boxes.shape[0]], dtype=torch.int32, device=dets.device),
+                                           iou_thr, -1)
+    k = int(cnt.item())
+    return dets[order[keep[0, :k].long()]]
+
+
+def merge_aug_proposals(aug_proposals, img_metas, cfg):
+    """merge_augs.py:13-81: the proposals of every augmentation mapped back to the original image, one NMS over all of
+    them, the best ``max_per_img``"""
+    recovered = []
+    for proposals, info in zip(aug_proposals, img_metas):
+        p = proposals.clone()
+        p[:, :4] = bbox_mapping_back(p[:, :4], info['img_shape'], info['scale_factor'], info['flip'],
+                                     info.get('flip_direction') or 'horizontal')
+        recovered.append(p)
+    allp = torch.cat(recovered, dim=0)
+    nms_cfg = dict(cfg.get('nms', {}))
+    thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr', cfg.get('nms_thr')))
+    merged = nms_plain(allp, thr)
+    order = merged[:, 4].sort(0, descending=True)[1]
+    num = min(cfg.get('max_per_img', cfg.get('max_num')), merged.shape[0])
+    return merged[order[:num], :]
+
+
+def merge_aug_bboxes(aug_bboxes, aug_scores, img_metas, rcnn_test_cfg):
+    """merge_augs.py:84-112: boxes [n, 4 * classes] of every augmentation mapped back and averaged, scores averaged"""
+    recovered = []
+    for bboxes, info in zip(aug_bboxes, img_metas):
+        i0 = info[0]
+        recovered.append(bbox_mapping_back(bboxes, i0['img_shape'], i0['scale_factor'], i0['flip'],
+                                           i0.get('flip_direction') or 'horizontal'))
+    bboxes = torch.stack(recovered).mean(dim=0)
+    if aug_scores is None:
+        return bboxes
+    return bboxes, torch.stack(aug_scores).mean(dim=0)

@@ -393,6 +393,19 @@ class RPNHead(AnchorHead):
         return self.get_bboxes(*self(x), img_metas=img_metas)
 
     @torch.no_grad()
+    def aug_test_rpn(self, feats, img_metas):
+        """dense_test_mixins.py:135-167: proposals of every test-time augmentation, merged per image in the ORIGINAL image
+        frame (merge_aug_proposals)"""
+        from .core import merge_aug_proposals
+        n = len(img_metas[0])
+        aug_proposals = [[] for _ in range(n)]
+        for x, metas in zip(feats, img_metas):
+            for i, proposals in enumerate(self.simple_test_rpn(x, metas)):
+                aug_proposals[i].append(proposals)
+        aug_metas = [[img_metas[j][i] for j in range(len(img_metas))] for i in range(n)]
+        return [merge_aug_proposals(p, m, self.test_cfg) for p, m in zip(aug_proposals, aug_metas)]
+
+    @torch.no_grad()
     def get_bboxes(self, cls_scores, bbox_preds, img_metas=None, cfg=None, num_imgs=None, padded=False,
                    **kwargs):
         """base_dense_head.py:31-106 + rpn_head.py:103-235, batched over images.

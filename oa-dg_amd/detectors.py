@@ -86,7 +86,10 @@ class BaseDetector(nn.Module):
             if 'proposals' in kwargs:
                 kwargs['proposals'] = kwargs['proposals'][0]
             return self.simple_test(imgs[0], img_metas[0], **kwargs)
-        raise NotImplementedError('aug_test (multi-scale / flip test-time augmentation) is not built')
+        # aug test: one image per batch only (base.py:203-212)
+        assert imgs[0].size(0) == 1, f'aug test does not support inference with batch size {imgs[0].size(0)}'
+        assert 'proposals' not in kwargs
+        return self.aug_test(imgs, img_metas, **kwargs)
 
     def _parse_losses(self, losses):
         """base.py:234-277.  Same keys and values; the per-variable all-reduces + .item() of the reference
@@ -237,6 +240,14 @@ class TwoStageDetector(BaseDetector):
         self.fpn_features = x
         proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
         return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+
+    @torch.no_grad()
+    def aug_test(self, imgs, img_metas, rescale=False):
+        """two_stage.py:268-277: test-time augmentation (MultiScaleFlipAug with several scales and / or flips).  If
+        ``rescale`` is False the returned boxes fit the scale of imgs[0]."""
+        x = [self.extract_feat(img) for img in imgs]                 # base.py extract_feats
+        proposal_list = self.rpn_head.aug_test_rpn(x, img_metas)
+        return self.roi_head.aug_test(x, proposal_list, img_metas, rescale=rescale)
 
     def get_random_proposal_list(self, img, gt_bboxes, kwargs):
         """two_stage.py:162-204, quirks kept: OA-Mix boxes are filtered against image 0's gts (:178,186);

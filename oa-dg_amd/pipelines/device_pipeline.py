@@ -16,6 +16,7 @@ import torch
 from .. import _lib
 from .._lib import check, ptr, stream_ptr
 from ..registry import DATASETS, PIPELINES, build_from_cfg
+from .corrupt import Corrupt
 from .geometric import RandomFlip, Resize
 from .oa_mix import OAMix, _ImageState
 
@@ -67,8 +68,8 @@ class ImageToTensor:
 
 @PIPELINES.register_module()
 class MultiScaleFlipAug:
-    """test_time_aug.py:12-121, the single-scale no-flip case the reference's test configs use
-    (``img_scale=(2048, 1024), flip=False``); it carries the scale and its inner transform list."""
+    """test_time_aug.py:12-121: carries the scales / flips and the inner transform list; DevicePipeline.test_batch expands
+    them into one batch per augmentation (the reference's test configs use ``img_scale=(2048, 1024), flip=False``)."""
 
     def __init__(self, transforms, img_scale=None, scale_factor=None, flip=False, flip_direction='horizontal'):
         assert (img_scale is None) ^ (scale_factor is None), 'Must have but only one variable can be set'
@@ -101,6 +102,8 @@ class DevicePipeline:
         (transforms.py:177-243), differently sized samples padded into one batch tensor like mmcv's collate does."""
         self.one_scale_per_batch = one_scale_per_batch
         ts = Compose(pipeline_cfg).transforms
+        # test_robustness.py:269-277 inserts Corrupt right after the image loading step, before MultiScaleFlipAug
+        self.corrupt = next((t for t in ts if isinstance(t, Corrupt)), None)
         self.test_aug = next((t for t in ts if isinstance(t, MultiScaleFlipAug)), None)
         if self.test_aug is not None:        # test pipeline: the transforms live inside MultiScaleFlipAug
             ts = self.test_aug.transforms.transforms
@@ -116,35 +119,56 @@ class DevicePipeline:
 
     @torch.no_grad()
     def test_batch(self, imgs_u8):
-        """The reference's test pipeline (MultiScaleFlipAug(img_scale, flip=False)[Resize(keep_ratio), RandomFlip,
-        Normalize, Pad, ImageToTensor, Collect]) for a resident uint8 batch: returns ``dict(img=[tensor],
-        img_metas=[[meta, ...]])`` as ``forward_test`` expects (one augmentation)."""
-        assert self.test_aug is not None and not self.test_aug.flip and len(self.test_aug.img_scale) == 1, \
-            'single-scale, no-flip testing (multi-scale / flip test-time augmentation is not built)'
+        """The reference's test pipeline ([Corrupt,] MultiScaleFlipAug(img_scale, flip)[Resize(keep_ratio), RandomFlip,
+        Normalize, Pad, ImageToTensor, Collect]) for a resident uint8 batch: returns ``dict(img=[tensor, ...],
+        img_metas=[[meta, ...], ...])`` as ``forward_test`` expects - one entry per test-time augmentation, scales outer,
+        (no flip, then one flip per direction) inner (test_time_aug.py:99-121).  A ``Corrupt`` step in front of it
+        (tools/analysis_tools/test_robustness.py --load-dataset original) corrupts the uint8 images first."""
+        assert self.test_aug is not None, 'test_batch needs a test pipeline (MultiScaleFlipAug)'
         L = _lib.lib()
+        if self.corrupt is not None:
+            imgs_u8 = self.corrupt.batch(imgs_u8)
         N, H0, W0 = imgs_u8.shape[:3]
-        scale = self.test_aug.img_scale[0]
-        imgs, metas = [], []
-        for i in range(N):
-            im, meta = imgs_u8[i], dict(ori_shape=(H0, W0, 3), flip=False, flip_direction=None,
-                                        scale_factor=np.ones(4, dtype=np.float32))
-            if self.resize is not None and scale is not None:
-                im, _, m = self.resize(im, np.zeros((0, 4), np.float32), scale=scale)
-                meta.update(m)
-            imgs.append(im)
-            metas.append(meta)
-        H, W = imgs[0].shape[:2]
-        Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
+        aug = self.test_aug
+        flips = [(False, None)]
+        if aug.flip:
+            dirs = aug.flip_direction if isinstance(aug.flip_direction, list) else [aug.flip_direction]
+            flips += [(True, d) for d in dirs]
+        if aug.scale_factor is not None:
+            sfs = aug.scale_factor if isinstance(aug.scale_factor, list) else [aug.scale_factor]
+            scales = [(int(W0 * f), int(H0 * f)) for f in sfs]           # test_time_aug.py:101-103
+        else:
+            scales = aug.img_scale
         na = self.norm.as_args()
         mean, stdinv = (ctypes.c_float * 3)(*na['mean']), (ctypes.c_float * 3)(*na['stdinv'])
-        img = torch.empty((N, 3, Hp, Wp), dtype=self.dtype, device=imgs_u8.device, memory_format=torch.channels_last)
-        for i in range(N):
-            check(L.oadg_oamix_normalize(ptr(imgs[i].contiguous()), H, W, mean, stdinv, int(na['to_rgb']),
-                                         ctypes.c_void_p(img.data_ptr() + i * img.stride(0) * img.element_size()),
-                                         1 if self.dtype == torch.bfloat16 else 0, Hp, Wp, stream_ptr()),
-                  'oadg_oamix_normalize')
-            metas[i].update(img_shape=(H, W, 3), pad_shape=(Hp, Wp, 3))
-        return dict(img=[img], img_metas=[metas])
+        out_imgs, out_metas = [], []
+        for scale in scales:
+            for flip, direction in flips:
+                imgs, metas = [], []
+                for i in range(N):
+                    im, meta = imgs_u8[i], dict(ori_shape=(H0, W0, 3), flip=False, flip_direction=None,
+                                                scale_factor=np.ones(4, dtype=np.float32))
+                    if self.resize is not None and scale is not None:
+                        im, _, m = self.resize(im, np.zeros((0, 4), np.float32), scale=scale)
+                        meta.update(m)
+                    if flip:
+                        assert self.flip is not None, 'MultiScaleFlipAug(flip=True) needs a RandomFlip step'
+                        im, _, m = self.flip(im, np.zeros((0, 4), np.float32), preset=(True, direction))
+                        meta.update(m)
+                    imgs.append(im)
+                    metas.append(meta)
+                H, W = imgs[0].shape[:2]
+                Hp, Wp = self.pad.padded(H, W) if self.pad is not None else (H, W)
+                img = torch.empty((N, 3, Hp, Wp), dtype=self.dtype, device=imgs_u8.device, memory_format=torch.channels_last)
+                for i in range(N):
+                    check(L.oadg_oamix_normalize(ptr(imgs[i].contiguous()), H, W, mean, stdinv, int(na['to_rgb']),
+                                                 ctypes.c_void_p(img.data_ptr() + i * img.stride(0) * img.element_size()),
+                                                 1 if self.dtype == torch.bfloat16 else 0, Hp, Wp, stream_ptr()),
+                          'oadg_oamix_normalize')
+                    metas[i].update(img_shape=(H, W, 3), pad_shape=(Hp, Wp, 3))
+                out_imgs.append(img)
+                out_metas.append(metas)
+        return dict(img=out_imgs, img_metas=out_metas)
 
     def prefetch(self, imgs_u8, gt_bboxes, gt_labels, worker_seed=None, ready=None):
         """Enqueue the whole pipeline for one batch on a side stream and return a handle (``.get()``).

@@ -136,8 +136,10 @@ class RandomFlip:
             flipped[..., 3::4] = h - bboxes[..., 1::4]
         return flipped
 
-    def __call__(self, img, bboxes):
-        cur = self.draw()
+    def __call__(self, img, bboxes, preset=None):
+        """``preset`` (test-time augmentation: MultiScaleFlipAug sets results['flip'] / ['flip_direction'] itself,
+        transforms.py:446-450): (flip, direction) instead of a draw"""
+        cur = self.draw() if preset is None else (preset[1] if preset[0] else None)
         if cur is None:
             return img, bboxes, dict(flip=False, flip_direction=None)
         H, W = img.shape[:2]

@@ -466,6 +466,37 @@ class StandardRoIHead(BaseRoIHead):
             det_labels.append(det_label)
         return det_bboxes, det_labels
 
+    @torch.no_grad()
+    def aug_test_bboxes(self, feats, img_metas, proposal_list, rcnn_test_cfg):
+        """test_mixins.py:139-177: the merged proposals (original frame) mapped into every augmentation, boxes / scores of
+        the augmentations mapped back and averaged, one multiclass NMS"""
+        from .core import bbox_mapping, merge_aug_bboxes, multiclass_nms
+        aug_bboxes, aug_scores = [], []
+        for x, meta in zip(feats, img_metas):
+            m0 = meta[0]                                            # only one image in the batch
+            proposals = bbox_mapping(proposal_list[0][:, :4], m0['img_shape'], m0['scale_factor'], m0['flip'],
+                                     m0.get('flip_direction') or 'horizontal')
+            rois = bbox2roi([proposals])
+            res = self._bbox_forward(x, rois)
+            bboxes, scores = self.bbox_head.get_bboxes(rois, res['cls_score'], res['bbox_pred'], m0['img_shape'],
+                                                       m0['scale_factor'], rescale=False, cfg=None)
+            aug_bboxes.append(bboxes)
+            aug_scores.append(scores)
+        merged_bboxes, merged_scores = merge_aug_bboxes(aug_bboxes, aug_scores, img_metas, rcnn_test_cfg)
+        if merged_bboxes.shape[0] == 0:
+            return merged_bboxes.new_zeros(0, 5), merged_bboxes.new_zeros((0,), dtype=torch.long)
+        return multiclass_nms(merged_bboxes, merged_scores, rcnn_test_cfg.score_thr, rcnn_test_cfg.nms,
+                              rcnn_test_cfg.max_per_img)
+
+    def aug_test(self, x, proposal_list, img_metas, rescale=False):
+        """standard_roi_head.py:438-462 (no mask branch): if ``rescale`` is False the boxes fit the scale of imgs[0]"""
+        from .core import bbox2result
+        det_bboxes, det_labels = self.aug_test_bboxes(x, img_metas, proposal_list, self.test_cfg)
+        if not rescale:
+            det_bboxes = det_bboxes.clone()
+            det_bboxes[:, :4] *= det_bboxes.new_tensor(img_metas[0][0]['scale_factor'])
+        return [bbox2result(det_bboxes, det_labels, self.bbox_head.num_classes)]
+
     def simple_test(self, x, proposal_list, img_metas, proposals=None, rescale=False):
         """standard_roi_head.py:392-436 (no mask branch): per image a list over classes of [k, 5] numpy arrays."""
         from .core import bbox2result

@@ -788,3 +788,50 @@ def test_weight_bank_refresh_equals_per_layer_preparation(dev):
         assert torch.isfinite(y.float()).all()
     finally:
         hip_conv.enable(False)
+
+
+def test_grad_token_late_depositor_taints_the_token(dev):
+    """The out-of-order case of the multi-consumer GradToken: t = relu(P(x)) feeds a FINISHER convolution and
+    a DEPOSITOR convolution; the depositor is issued first in the forward pass, so autograd runs its backward AFTER the
+    finisher's (higher sequence numbers first).  The depositor then finds the token closed, must return its gradient AND
+    taint the token (grad_ptr = None): the producer masks / reduces the SUM itself instead of trusting the finisher's
+    pointer - autograd may have added the late gradient in place into that very tensor.  Checked against the same
+    network without any token."""
+    import torch.nn as nn
+    from oadg_amd import hip_conv, layers
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(2)
+        P = nn.Conv2d(64, 128, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+        Pbn = nn.BatchNorm2d(128).to(dev).eval()
+        F_ = nn.Conv2d(128, 64, 3, padding=1, bias=False).to(dev).to(memory_format=torch.channels_last)
+        Fbn = nn.BatchNorm2d(64).to(dev).eval()
+        D = nn.Conv2d(128, 128, 1, bias=False).to(dev)
+        Dbn = nn.BatchNorm2d(128).to(dev).eval()
+        with torch.no_grad():
+            for bn in (Pbn, Fbn, Dbn):
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_var.uniform_(0.5, 1.5); bn.running_mean.normal_(0, 0.3)
+        params = [p for m in (P, Pbn, F_, Fbn, D, Dbn) for p in m.parameters()]
+        x = torch.randn(2, 64, 24, 40, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        g1 = torch.randn(2, 64, 24, 40, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        g2 = torch.randn(2, 128, 24, 40, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        res = {}
+        for mode in ('tokens', 'plain'):
+            for p in params:
+                p.grad = None
+            xin = x.clone().requires_grad_(True)
+            tok = hip_conv.GradToken() if mode == 'tokens' else None
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                t = layers.conv_bn(xin, P, Pbn, relu=True, **(dict(out_token=tok) if tok else {}))
+                yd = layers.conv_bn(t, D, Dbn, **(dict(dep_token=tok) if tok else {}))        # depositor FIRST
+                yf = layers.conv_bn(t, F_, Fbn, **(dict(in_token=tok) if tok else {}))         # finisher second
+            torch.autograd.backward([yf, yd], [g1, g2])
+            if tok is not None:
+                assert tok.closed and tok.grad_ptr is None and tok.extra is None     # tainted by the late depositor
+            res[mode] = {i: p.grad.float().clone() for i, p in enumerate(params)}
+            res[mode]['x'] = xin.grad.float().clone()
+        for k in res['plain']:
+            a, b = res['tokens'][k], res['plain'][k]
+            assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() + 1e-6, k
+    finally:
+        hip_conv.enable(False)

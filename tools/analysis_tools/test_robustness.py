@@ -11,9 +11,10 @@ corruption) and rPC (relative) are printed as robustness_eval.py:37-118 does, an
 
 ``--load-dataset corrupted`` (the reference's default workflow for Cityscapes-C: pre-generated image trees,
 test_robustness.py:283-299) swaps ``img_prefix`` to ``.../cityscapes-c/.../<corruption>/<severity>/``.
-``--load-dataset original`` would corrupt on the fly through the ``imagecorruptions`` package (``Corrupt`` transform),
-which is not installed in this image: it stops with that message.  On a box without the dataset the synthetic source is
-used and every severity evaluates the same images - the loop and the bookkeeping are what this run exercises then.
+``--load-dataset original`` corrupts on the fly with the ``Corrupt`` transform inserted after the loading step
+(test_robustness.py:269-277); the reference's transform calls the ``imagecorruptions`` package, which is not installed
+in this image: oadg_amd/pipelines/corrupt.py restates 13 of its 19 corruptions (the ones that need only numpy / scipy /
+Pillow) and stops with a message for the other six.  On a box without the dataset the synthetic source is used.
 """
 import argparse
 import copy
@@ -79,10 +80,9 @@ def main():
             dcfg = copy.deepcopy(cfg.data.test.to_dict() if hasattr(cfg.data.test, 'to_dict') else dict(cfg.data.test))
             if severity > 0:
                 if a.load_dataset == 'original':
-                    raise NotImplementedError("--load-dataset original corrupts images on the fly with the "
-                                              "'imagecorruptions' package (Corrupt transform), which is not installed "
-                                              "here; generate the -c tree once and use --load-dataset corrupted")
-                if dcfg.get('img_prefix') and dcfg.get('type') != 'SyntheticCityscapes':
+                    # test_robustness.py:269-277: the Corrupt transform right after the loading step (index 1)
+                    dcfg['pipeline'].insert(1, dict(type='Corrupt', corruption=corruption, severity=severity))
+                elif dcfg.get('img_prefix') and dcfg.get('type') != 'SyntheticCityscapes':
                     dcfg['img_prefix'] = E.corrupted_img_prefix(dcfg['img_prefix'], corruption, severity)
             print(f'\nTesting {corruption} at severity {severity}', flush=True)
             results, ds, dt = run_test(model, dcfg, dev, amp, 1, a.max_samples)
