@@ -173,6 +173,20 @@ def test_test_cli_coco_style_eval_and_robustness_loop(tmp_path):
         agg['snow'][0] == agg['fog'][0]
     summ = json.load(open(tmp_path / 'rob_summary.json'))
     assert set(summ) == {'P', 'mPC', 'rPC'} and 'Mean Performance under Corruption [mPC] (bbox)' in r.stdout
+    # --load-dataset original: the Corrupt transform is inserted after the loading step and corrupts on the fly
+    # (test_robustness.py:269-277); a corruption that needs the absent third-party pieces stops with its name
+    out2 = tmp_path / 'rob2.pkl'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'analysis_tools', 'test_robustness.py'), cfg, 'none',
+                        '--corruptions', 'contrast', 'gaussian_noise', '--severities', '0', '3', '--max-samples', '2',
+                        '--load-dataset', 'original', '--out', str(out2), '--seed', '0'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    agg2 = pickle.load(open(tmp_path / 'rob2_results.pkl', 'rb'))
+    assert set(agg2) == {'contrast', 'gaussian_noise'} and set(agg2['contrast']) == {0, 3}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'analysis_tools', 'test_robustness.py'), cfg, 'none',
+                        '--corruptions', 'frost', '--severities', '1', '--max-samples', '1', '--load-dataset', 'original'],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode != 0 and "corruption 'frost'" in r.stderr
 
 
 @pytest.mark.timeout(900)

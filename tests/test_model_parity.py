@@ -335,9 +335,9 @@ def test_config2_whole_step_bs4_1024x2048_bf16(dev):
     from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
     cfg = Config.fromfile(CFG)
     set_random_seed(0)
-    det = build_detector(cfg.model)
-    det.init_weights(allow_missing_pretrained=True)
-    det = det.to(dev).to(memory_format=torch.channels_last).train()
+    # name-seeded weights as in the fixtures (inputs.named_weights): mmdet's random initialisation zeroes the last BatchNorm
+    # scale of every bottleneck (zero_init_residual), which makes 91 backbone gradients EXACTLY zero by construction
+    det = build_and_load(dev).to(memory_format=torch.channels_last).train()
     try:
         eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16)
         ds = SyntheticCityscapes(img_shape=(1024, 2048), num_boxes=20, num_classes=8, seed=0, device=dev)
@@ -349,11 +349,13 @@ def test_config2_whole_step_bs4_1024x2048_bf16(dev):
         for rep in range(2):
             set_random_seed(11)                      # RandomSampler (torch CPU generator) + random proposals (numpy)
             det.zero_grad(set_to_none=True)
-            (loss, log_vars), n = eng.forward_losses(data)
+            # (integrate_data merges the views INTO the dict it is given, like base.py:22-48: every run gets its own copy)
+            fresh = {k: (list(v) if isinstance(v, list) else v) for k, v in data.items()}
+            (loss, log_vars), n = eng.forward_losses(fresh)
             loss.backward()
             torch.cuda.synchronize()
             lv = {k: float(v) for k, v in log_vars.items()}
-            assert n == 4
+            assert n == 8                     # num_samples = len(img_metas) after integrate_data: 4 images x 2 views
             assert set(lv) == {'loss_rpn_cls', 'loss_rpn_bbox', 'loss_cls', 'acc', 'loss_bbox', 'loss_cont', 'loss'}
             assert all(np.isfinite(v) for v in lv.values()), lv
             assert lv['loss_cont'] > 0 and lv['loss_cls'] > 0 and lv['loss_rpn_cls'] > 0
