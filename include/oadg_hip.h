@@ -93,6 +93,49 @@ int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* 
                              void* tile_boxes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * RPN proposals after the per-level top-k (mmdet/models/dense_heads/rpn_head.py:103-235, batched over the images;
+ * delta2bbox of mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:184-..., mmcv batched_nms's class offset): csrc/proposals.hip.
+ * A level descriptor: the level's bbox_pred (fp32 = dtype 0 / bf16 = 1, logical [N, 4A, H, W] with element strides
+ * sN, sC, sH, sW - the fused RPN head writes one 128-channel NHWC tensor), its anchors [H*W*A, 4] fp32, and for every
+ * image the k kept scores [I, k] in stable descending order with their positions index [I, k] (int64, position
+ * i = (h*W + w)*A + a; NULL: position = rank).  first = sum of k over the levels before it.
+ *   oadg_rpn_decode: props [I, M, 4] (decoded, clipped to lim [I][2] = (W_i, H_i) when clip), scores [I, M], valid [I, M]
+ *                    (w > min_size and h > min_size; min_size < 0: all valid), M = sum of k.
+ *   oadg_rpn_order:  the stable descending order of key = valid ? score : -1 as a merge of the sorted levels: order [I, M]
+ *                    (int32, candidate index per position), boxes_sorted [I, M, 4] = props + level * (max coordinate of the
+ *                    valid boxes + 1) in that order (the input of oadg_nms_batched), counts [I] = valid candidates,
+ *                    max_coord [I].
+ *   oadg_rpn_gather: dets [I, P, 5]: row j < keep_cnt[i] = (props, score) of candidate order[keep[i][j]], other rows
+ *                    (0, 0, 0, 0, -1). */
+#define OADG_RPN_MAX_LEVELS 8
+typedef struct oadg_rpn_level {
+    const void* deltas;
+    long sN, sC, sH, sW;
+    const float* anchors;
+    const float* scores;
+    const long long* index;
+    int H, W, A, k, dtype, first;
+} oadg_rpn_level;
+int oadg_rpn_decode(const oadg_rpn_level* levels, int n_levels, int n_img, const float* means4, const float* stds4,
+                    float max_ratio, const float* lim, int clip, float min_size, float* props, float* scores,
+                    unsigned char* valid, void* stream);
+int oadg_rpn_order(const oadg_rpn_level* levels, int n_levels, int n_img, const float* props, const float* scores,
+                   const unsigned char* valid, float* boxes_sorted, int* order, int* counts, float* max_coord,
+                   void* stream);
+int oadg_rpn_gather(int n_img, int M, int P, const float* props, const float* scores, const int* order, const int* keep,
+                    const int* keep_cnt, float* dets, void* stream);
+/* The per-level top-k in front of it (rpn_head.py:146-155: scores.sort(descending, stable)[:nms_pre] per image and level)
+ * for all (image, level) rows in six launches: sigmoid scores of cls[l] (dtype 0 fp32 / 1 bf16, logical [N, A, H, W] with
+ * element strides strides[4 l ..] = sN, sC, sH, sW, dims[3 l ..] = H, W, A) in (h, w, a) order, a three-pass radix SELECT of
+ * the k-th largest score (ties resolved in index order, as the stable sort does), ordered compaction, one LDS sort of the k
+ * candidates per row.  out_scores[l] [n_img, k_l] fp32 and out_index[l] [n_img, k_l] int64, k_l = min(nms_pre, A H W).
+ * n_img * n_levels <= 48 rows, k_l <= 16384. */
+size_t oadg_rpn_topk_workspace_bytes(const int* level_n, int n_levels, int n_img, int nms_pre);
+int oadg_rpn_topk(const void* const* cls, const long* strides, const int* dims, int dtype, int n_levels, int n_img,
+                  int nms_pre, float* const* out_scores, long long* const* out_index, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Greedy NMS, batched over images
  *   replaces mmcv.ops.batched_nms -> nms as called at mmdet/models/dense_heads/rpn_head.py:231
  * boxes [n_images, Mmax, 4] fp32 sorted by descending score per image, class offsets already added;

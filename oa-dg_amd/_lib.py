@@ -14,6 +14,13 @@ _lib = None
 vp, ci, cf, cl, cs, cd = c_void_p, c_int, c_float, c_long, c_size_t, c_double
 
 
+class RpnLevel(Structure):
+    """oadg_rpn_level (include/oadg_hip.h)"""
+    _fields_ = [('deltas', c_void_p), ('sN', c_long), ('sC', c_long), ('sH', c_long), ('sW', c_long), ('anchors', c_void_p),
+                ('scores', c_void_p), ('index', c_void_p), ('H', c_int), ('W', c_int), ('A', c_int), ('k', c_int),
+                ('dtype', c_int), ('first', c_int)]
+
+
 class RegionOp(Structure):
     """oadg_region_op (include/oadg_hip.h)"""
     _fields_ = [('kind', c_int), ('param', c_int), ('image', c_void_p), ('minv', c_double * 6)]
@@ -38,6 +45,11 @@ SIGNATURES = {
     'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
     'oadg_roi_align_bwd_tiles': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, cf, vp, ci, ci, ci,
                                       ci, ci, vp, vp, vp, vp, vp]),
+    'oadg_rpn_decode': (ci, [vp, ci, ci, vp, vp, cf, vp, ci, cf, vp, vp, vp, vp]),
+    'oadg_rpn_order': (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'oadg_rpn_gather': (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),
+    'oadg_rpn_topk_workspace_bytes': (cs, [POINTER(ci), ci, ci, ci]),
+    'oadg_rpn_topk': (ci, [POINTER(vp), POINTER(cl), POINTER(ci), ci, ci, ci, ci, POINTER(vp), POINTER(vp), vp, cs, vp]),
     'oadg_nms_workspace_bytes': (cs, [ci, ci]),
     'oadg_nms_batched': (ci, [vp, vp, ci, ci, cf, ci, vp, cs, vp, vp, vp]),
     'oadg_resize_bilinear_u8': (ci, [vp, ci, ci, ci, vp, ci, ci, vp]),

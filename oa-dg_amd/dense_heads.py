@@ -5,6 +5,8 @@ proposal NMS is the batched HIP NMS (one launch for all images instead of one mm
 import copy
 import os
 
+import numpy as np
+
 import torch
 from torch.profiler import record_function as _rf
 import torch.nn as nn
@@ -392,6 +394,107 @@ class RPNHead(AnchorHead):
         """dense_test_mixins.py:118-133"""
         return self.get_bboxes(*self(x), img_metas=img_metas)
 
+    FUSED_PROPOSALS = os.environ.get('OADG_FUSED_PROPOSALS', '1') == '1'
+    FUSED_TOPK = os.environ.get('OADG_FUSED_TOPK', '1') == '1'
+
+    def _fused_proposals(self, cls_scores, bbox_preds, mlvl_anchors, img_metas, cfg, n_img, nms_pre, padded):
+        """The part of get_bboxes after the per-level top-k on csrc/proposals.hip (decode + clip + size test, merge of
+        the sorted levels into the global descending order, class-offset boxes, final gather): 3 launches + the NMS pair
+        instead of ~120 element-wise / gather / sort launches.  Bit-identical to the tensor path below
+        (tests/test_hip_proposals.py).  None: a configuration the kernels do not cover (softmax scores, centre clamp,
+        CPU tensors) - the tensor path runs."""
+        import ctypes
+        from . import _lib
+        from .core.bbox import DeltaXYWHBBoxCoder, _pinned_to
+        coder = self.bbox_coder
+        dev = cls_scores[0].device
+        if not (self.FUSED_PROPOSALS and dev.type == 'cuda' and self.use_sigmoid_cls and type(coder) is DeltaXYWHBBoxCoder
+                and not coder.add_ctr_clamp and len(cls_scores) <= 8 and n_img >= 1):
+            return None
+        nms_cfg = dict(cfg.nms)
+        if nms_cfg.pop('type', 'nms') != 'nms':
+            return None
+        thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+        L = _lib.lib()
+        nl = len(cls_scores)
+        levels = (_lib.RpnLevel * nl)()
+        keep_alive, first = [], 0
+        if any(bp.dtype not in (torch.float32, torch.bfloat16) for bp in bbox_preds):
+            return None
+        dims = [(int(c.shape[2]), int(c.shape[3]), int(c.shape[1])) for c in cls_scores]
+        ks = [min(nms_pre, h * w * a) if nms_pre > 0 else h * w * a for h, w, a in dims]
+        topk = None
+        if self.FUSED_TOPK and nms_pre > 0 and n_img * nl <= 48 and max(ks) <= 16384 and \
+                len({c.dtype for c in cls_scores}) == 1 and cls_scores[0].dtype in (torch.float32, torch.bfloat16):
+            # radix select + ordered compaction + one LDS sort per (image, level) row: six launches for all rows
+            csd = [c.detach() for c in cls_scores]
+            sc = [torch.empty((n_img, k), dtype=torch.float32, device=dev) for k in ks]
+            ix = [torch.empty((n_img, k), dtype=torch.int64, device=dev) for k in ks]
+            level_n = (ctypes.c_int * nl)(*[h * w * a for h, w, a in dims])
+            nbytes = L.oadg_rpn_topk_workspace_bytes(level_n, nl, n_img, int(nms_pre))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            strides = (ctypes.c_long * (4 * nl))(*[int(v) for c in csd for v in c.stride()])
+            dims_c = (ctypes.c_int * (3 * nl))(*[v for d in dims for v in d])
+            _lib.check(L.oadg_rpn_topk((ctypes.c_void_p * nl)(*[c.data_ptr() for c in csd]), strides, dims_c,
+                                       0 if csd[0].dtype == torch.float32 else 1, nl, n_img, int(nms_pre),
+                                       (ctypes.c_void_p * nl)(*[t.data_ptr() for t in sc]),
+                                       (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ix]), _lib.ptr(ws), nbytes,
+                                       _lib.stream_ptr()), 'oadg_rpn_topk')
+            topk = (sc, ix)
+            keep_alive += [csd, ws]
+        for lvl, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
+            H, W, A = dims[lvl]
+            k = ks[lvl]
+            if topk is not None:
+                sc_k, idx_k = topk[0][lvl], topk[1][lvl]
+            else:
+                scores = cs[:n_img].detach().float().permute(0, 2, 3, 1).reshape(n_img, -1).sigmoid()
+                # every level arrives in stable descending order (the merge of the kernel relies on it; the reference leaves
+                # a level shorter than nms_pre unsorted, which only matters for the order of exactly tied invalid boxes)
+                ranked, rank_inds = scores.sort(dim=1, descending=True, stable=True)
+                sc_k, idx_k = ranked[:, :k].contiguous(), rank_inds[:, :k].contiguous()
+            bpd = bp.detach()
+            an = mlvl_anchors[lvl].contiguous()
+            keep_alive += [sc_k, idx_k, bpd, an]
+            lv = levels[lvl]
+            lv.deltas, lv.anchors, lv.scores, lv.index = bpd.data_ptr(), an.data_ptr(), sc_k.data_ptr(), idx_k.data_ptr()
+            lv.sN, lv.sC, lv.sH, lv.sW = (int(v) for v in bpd.stride())
+            lv.H, lv.W, lv.A, lv.k, lv.dtype, lv.first = H, W, int(A), int(k), 0 if bp.dtype == torch.float32 else 1, first
+            first += int(k)
+        M = first
+        if M == 0 or (2 * M + 1) * 4 > 150 * 1024:
+            return None
+        clip = bool(getattr(coder, 'clip_border', True))
+        lim_host = torch.tensor([[m['img_shape'][1], m['img_shape'][0]] for m in img_metas[:n_img]], dtype=torch.float32)
+        lim = _pinned_to(lim_host, dev)
+        means = (ctypes.c_float * 4)(*[float(v) for v in coder.means])
+        stds = (ctypes.c_float * 4)(*[float(v) for v in coder.stds])
+        max_ratio = float(np.float32(np.abs(np.log(16 / 1000))))
+        props = torch.empty((n_img, M, 4), dtype=torch.float32, device=dev)
+        scores_cat = torch.empty((n_img, M), dtype=torch.float32, device=dev)
+        valid = torch.empty((n_img, M), dtype=torch.uint8, device=dev)
+        st = _lib.stream_ptr()
+        _lib.check(L.oadg_rpn_decode(levels, len(cls_scores), n_img, means, stds, max_ratio, _lib.ptr(lim), int(clip),
+                                     float(cfg.min_bbox_size), _lib.ptr(props), _lib.ptr(scores_cat), _lib.ptr(valid), st),
+                   'oadg_rpn_decode')
+        boxes_sorted = torch.empty((n_img, M, 4), dtype=torch.float32, device=dev)
+        order = torch.empty((n_img, M), dtype=torch.int32, device=dev)
+        counts = torch.empty((n_img,), dtype=torch.int32, device=dev)
+        mx = torch.empty((n_img,), dtype=torch.float32, device=dev)
+        _lib.check(L.oadg_rpn_order(levels, len(cls_scores), n_img, _lib.ptr(props), _lib.ptr(scores_cat), _lib.ptr(valid),
+                                    _lib.ptr(boxes_sorted), _lib.ptr(order), _lib.ptr(counts), _lib.ptr(mx), st),
+                   'oadg_rpn_order')
+        keep, keep_cnt = hip_ops.nms_sorted_batched(boxes_sorted, counts, thr, cfg.max_per_img)
+        P = min(cfg.max_per_img, M) if cfg.max_per_img > 0 else M
+        dets = torch.empty((n_img, P, 5), dtype=torch.float32, device=dev)
+        _lib.check(L.oadg_rpn_gather(n_img, M, P, _lib.ptr(props), _lib.ptr(scores_cat), _lib.ptr(order), _lib.ptr(keep),
+                                     _lib.ptr(keep_cnt), _lib.ptr(dets), st), 'oadg_rpn_gather')
+        del keep_alive
+        if padded:
+            return list(dets.unbind(0))
+        cnt = keep_cnt.tolist()                      # one host read for the whole batch
+        return [dets[i, :min(cnt[i], P)] for i in range(n_img)]
+
     @torch.no_grad()
     def aug_test_rpn(self, feats, img_metas):
         """dense_test_mixins.py:135-167: proposals of every test-time augmentation, merged per image in the ORIGINAL image
@@ -419,6 +522,9 @@ class RPNHead(AnchorHead):
         featmap_sizes = [c.shape[-2:] for c in cls_scores]
         mlvl_anchors = self.prior_generator.grid_priors(featmap_sizes, device=device)
         nms_pre = cfg.get('nms_pre', -1)
+        fused = self._fused_proposals(cls_scores, bbox_preds, mlvl_anchors, img_metas, cfg, n_img, nms_pre, padded)
+        if fused is not None:
+            return fused
         sc_l, dl_l, an_l, id_l = [], [], [], []
         for lvl, (cs, bp) in enumerate(zip(cls_scores, bbox_preds)):
             cs = cs[:n_img].detach().float().permute(0, 2, 3, 1)
