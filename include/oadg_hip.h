@@ -221,6 +221,18 @@ typedef struct {
 /* HOST function (no device work): dependency level of each of the n steps in list order - rects [n][4] = x0, y0, w, h
  * (pixels written), minvs [n][6]; level[j] > level[i] whenever i < j and one writes what the other reads or writes. */
 int oadg_oamix_bbox_levels(const int* rects, const double* minvs, int n, int H, int W, int* level);
+/* HOST function: the whole host side of one bboxes_only_* op for all gt boxes (bbox_augmentation.py:31-88 with the leaf
+ * matrices of augmix.py:83-188): kind 0 rotate / 1 shear_x / 2 shear_y / 3 translate_x / 4 translate_y; ib [n][4] int64
+ * box corners; support [n][4] = x0, y0, w, h of every box's mask support (w or h <= 0: empty); draws [2 m] = the (level,
+ * sign) uniforms of the m boxes that draw (integer width and height >= 1), in box order.  Writes the level-major step
+ * table + the (n_live + 1)-entry tile prefix into `staging` (>= oadg_oamix_bbox_plan_bytes(n), the layout
+ * oadg_oamix_bbox_chain consumes after one copy to the device), level_first [n_levels + 1] (host, >= n + 2 entries),
+ * out = {n_live, n_levels, tiles}, *area_sum = sum of rect areas.  Same numpy operation order as the reference's
+ * expressions: bit-identical matrices. */
+size_t oadg_oamix_bbox_plan_bytes(int n);
+int oadg_oamix_bbox_plan(int kind, double severity, const long long* ib, const int* support, int n, const double* draws,
+                         int n_draws, int H, int W, void* staging, size_t staging_bytes, int* level_first, int* out,
+                         long long* area_sum);
 int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* steps_dev, const int* tile_prefix_dev,
                           const int* level_first_host, int n_levels, const int* tile_prefix_host, const float* My,
                           const float* Mx, uint8_t* scratch, void* stream);

@@ -82,3 +82,111 @@ extern "C" int oadg_oamix_bbox_levels(const int* rects, const double* minvs, int
     }
     return OADG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The host side of one bboxes_only_* op (bbox_augmentation.py:31-88 with the augmix.py:83-188 leaf matrices) for ALL gt
+// boxes in one call: what oadg_amd/pipelines/oa_mix.py did with ~25 numpy expressions per op (2 ms of Python per view,
+// under the interpreter lock that the training thread needs) - draws -> level / sign -> affine matrix in the dtype cv2
+// receives it -> inverse -> live steps -> dependency levels -> level-major step table + tile prefix, written straight
+// into the caller's (pinned) staging buffer.  Every expression keeps numpy's operation order (IEEE doubles, float32
+// round trips where the reference builds np.float32 matrices, libm cos / sin of the integer angle like math.cos):
+// bit-identical matrices (tests/test_hip_oamix.py compares the images with the oracle byte for byte).
+//   kind: 0 rotate, 1 shear_x, 2 shear_y, 3 translate_x, 4 translate_y
+//   ib [n][4]: int64 box corners (truncated gt boxes); support [n][4]: x0, y0, w, h of the box's mask support (w <= 0 or
+//   h <= 0: the mask is empty - the step draws but changes nothing); draws [2 m]: the m drawing boxes' (level, sign)
+//   uniforms in box order (boxes with integer width or height < 1 return before drawing, :45-47).
+// staging: [n_live] oadg_bbox_step followed by [n_live + 1] int32 tile prefix; level_first [n_levels + 1] (host).
+// out[0] = n_live, out[1] = n_levels, out[2] = total tiles; *area_sum = sum of the rect areas.
+extern "C" size_t oadg_oamix_bbox_plan_bytes(int n) {
+    return (size_t)(n > 0 ? n : 0) * sizeof(oadg_bbox_step) + ((size_t)(n > 0 ? n : 0) + 1) * sizeof(int) + 8;
+}
+
+extern "C" int oadg_oamix_bbox_plan(int kind, double severity, const long long* ib, const int* support, int n,
+                                    const double* draws, int n_draws, int H, int W, void* staging, size_t staging_bytes,
+                                    int* level_first, int* out, long long* area_sum) {
+    if (kind < 0 || kind > 4 || n < 0 || H < 1 || W < 1 || !out || !area_sum || (n > 0 && (!ib || !support || !staging || !level_first)))
+        return OADG_EARG;
+    if (staging_bytes < oadg_oamix_bbox_plan_bytes(n)) return OADG_ESIZE;
+    out[0] = out[1] = out[2] = 0;
+    *area_sum = 0;
+    auto f32 = [](double v) { return (double)(float)v; };
+    std::vector<int> rects, rows;
+    std::vector<double> minvs;
+    rects.reserve((size_t)n * 4); rows.reserve(n); minvs.reserve((size_t)n * 6);
+    int d = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long x1i = ib[4 * i], y1i = ib[4 * i + 1], x2i = ib[4 * i + 2], y2i = ib[4 * i + 3];
+        if ((x2i - x1i) < 1 || (y2i - y1i) < 1) continue;                 // returns before any draw
+        if (2 * d + 1 >= n_draws) return OADG_EARG;
+        const double level = 0.1 + (severity - 0.1) * draws[2 * d];
+        const bool flip = draws[2 * d + 1] > 0.5;
+        ++d;
+        const double x1 = (double)x1i, y1 = (double)y1i, x2 = (double)x2i, y2 = (double)y2i;
+        const double cx = (x1 + x2) / 2., cy = (y1 + y2) / 2.;
+        double M[6] = {0, 0, 0, 0, 0, 0};
+        if (kind == 0) {
+            long long deg = (long long)trunc(level * 30 / 10);
+            if (flip) deg = -deg;
+            const double cxf = f32(cx), cyf = f32(cy);                     // cv2.getRotationMatrix2D takes a Point2f
+            const double ang = (double)deg * M_PI / 180.0;
+            const double alpha = cos(ang) * 1.0, beta = sin(ang) * 1.0;
+            M[0] = alpha; M[1] = beta; M[2] = (1 - alpha) * cxf - beta * cyf;
+            M[3] = -beta; M[4] = alpha; M[5] = beta * cxf + (1 - alpha) * cyf;
+        } else if (kind == 1 || kind == 2) {
+            double lvl = level * 0.3 / 10.;
+            if (flip) lvl = -lvl;
+            if (kind == 1) { M[0] = 1.0; M[1] = f32(-lvl); M[2] = f32(-(-lvl * cy)); M[4] = 1.0; }
+            else { M[0] = 1.0; M[3] = f32(-lvl); M[4] = 1.0; M[5] = f32(-(-lvl * cx)); }
+        } else {
+            const double size = kind == 3 ? (x2 - x1 + 1) : (y2 - y1 + 1);
+            double lvl = trunc(level * (size / 3) / 10);
+            if (flip) lvl = -lvl;
+            M[0] = 1.0; M[4] = 1.0;
+            M[kind == 3 ? 2 : 5] = f32(-lvl);
+        }
+        const int* sp = support + 4 * i;
+        if (sp[2] <= 0 || sp[3] <= 0) continue;                            // mask identically zero: image unchanged
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1.0 / D : 0.0;
+        const double A11 = M[4] * D, A22 = M[0] * D, m1 = M[1] * -D, m3 = M[3] * -D;
+        const double b1 = -A11 * M[2] - m1 * M[5], b2 = -m3 * M[2] - A22 * M[5];
+        const double mi[6] = {A11, m1, b1, m3, A22, b2};
+        minvs.insert(minvs.end(), mi, mi + 6);
+        rects.insert(rects.end(), sp, sp + 4);
+        rows.push_back(i);
+    }
+    if (2 * d != n_draws) return OADG_EARG;
+    const int nl = (int)rows.size();
+    out[0] = nl;
+    if (nl == 0) return OADG_OK;
+    std::vector<int> level(nl);
+    const int rc = oadg_oamix_bbox_levels(rects.data(), minvs.data(), nl, H, W, level.data());
+    if (rc) return rc;
+    std::vector<int> order(nl);
+    for (int j = 0; j < nl; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return level[a] < level[b]; });
+    oadg_bbox_step* steps = (oadg_bbox_step*)staging;
+    int* tiles = (int*)((unsigned char*)staging + (size_t)nl * sizeof(oadg_bbox_step));
+    const int n_levels = level[order[nl - 1]] + 1;
+    long long area_tot = 0, cum = 0, level_base = 0;
+    int cur = -1, t = 0;
+    tiles[0] = 0;
+    for (int p = 0; p < nl; ++p) {
+        const int j = order[p];
+        while (cur < level[j]) { level_first[++cur] = p; level_base = cum; }
+        oadg_bbox_step& s = steps[p];
+        for (int q = 0; q < 6; ++q) s.minv[q] = minvs[6 * j + q];
+        for (int q = 0; q < 4; ++q) s.rect[q] = rects[4 * j + q];
+        s.row = rows[j];
+        const long long area = (long long)rects[4 * j + 2] * rects[4 * j + 3];
+        s.scratch_off = cum - level_base;      // the rects of one level are disjoint: their packed images fit the H*W*3 scratch
+        cum += (3 * area + 3) / 4 * 4;         // every rect starts on a 4-byte boundary of the scratch image
+        area_tot += area;
+        t += (int)((area + 1023) / 1024);      // one workgroup = 256 threads x 4 pixels
+        tiles[p + 1] = t;
+    }
+    level_first[n_levels] = nl;
+    out[1] = n_levels; out[2] = t;
+    *area_sum = area_tot;
+    return OADG_OK;
+}

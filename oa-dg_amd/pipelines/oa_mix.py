@@ -11,6 +11,7 @@ full-resolution float masks of the reference (25 MB each) are replaced by two 1-
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 
@@ -53,6 +54,7 @@ MIX_TARGET_DTYPE = np.dtype([('fg_index', '<i4'), ('rect', '<i4', (4,)), ('m_oa'
 BBOX_STEP_DTYPE = np.dtype([('minv', '<f8', (6,)), ('rect', '<i4', (4,)), ('row', '<i4'), ('pad_', '<i4'),
                             ('scratch_off', '<i8')])                                          # oadg_bbox_step
 BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
+PLAN_IN_C = os.environ.get('OADG_OAMIX_PLAN_C', '1') == '1'     # the op's host arithmetic in one C call (else numpy)
 
 
 def dependency_levels(rects, minvs, H, W):
@@ -157,6 +159,18 @@ class _PinnedRing:
     def __init__(self):
         self.bufs, self.events, self.k = [None] * self.SLOTS, [None] * self.SLOTS, 0
 
+    def slot(self, nbytes):
+        """(slot number, pinned uint8 buffer of >= nbytes) - the caller fills it, enqueues the copy and records the slot's
+        event behind it"""
+        k, self.k = self.k, (self.k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        buf = self.bufs[k]
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[k] = torch.empty((max(4096, 1 << int(max(nbytes, 2) - 1).bit_length()),), dtype=torch.uint8,
+                                             pin_memory=True)
+        return k, buf
+
     def stage(self, raw):
         k, self.k = self.k, (self.k + 1) % self.SLOTS
         if self.events[k] is not None:
@@ -246,6 +260,20 @@ class _ImageState:
         empty = (x2 <= x1) | (y2 <= y1)                      # empty at reduced resolution: mask is all zero
         rows = np.stack([xa, ya, xb - xa, yb - ya], 1).tolist()
         return [None if e else tuple(r) for e, r in zip(empty.tolist(), rows)]
+
+    def plan_arrays(self):
+        """(ib int64 [n, 4], support int32 [n, 4] with zeros for empty masks, number of boxes that draw) - the per-image
+        constants of oadg_oamix_bbox_plan, built once"""
+        c = getattr(self, '_plan_arrays', None)
+        if c is None:
+            ib = np.ascontiguousarray(self.gt.astype(np.int64))            # int() truncation of non-negative float32
+            sup = np.zeros((self.n, 4), np.int32)
+            for i, s_ in enumerate(self.support):
+                if s_ is not None and s_[2] > 0 and s_[3] > 0:
+                    sup[i] = s_
+            draws = int((~(((ib[:, 2] - ib[:, 0]) < 1) | ((ib[:, 3] - ib[:, 1]) < 1))).sum()) if self.n else 0
+            c = self._plan_arrays = (ib, sup, draws)
+        return c
 
     def scores(self):
         """fg_score_list of get_fg_regions: -1 for boxes thinner than spatial_ratio, else the saliency mean."""
@@ -389,7 +417,9 @@ class OAMix:
         step['n_tmp'] += 1
         T.copy_(src)
         H, W = st.H, st.W
-        if BATCH_BOXES:
+        if BATCH_BOXES and PLAN_IN_C:
+            self._bbox_chain_c(st, T, kind, step)
+        elif BATCH_BOXES:
             rows, rects, minvs = self._box_matrices(st, kind)
             if len(rows):
                 self._bbox_chain(st, T, rows, rects, minvs, step)
@@ -413,6 +443,55 @@ class OAMix:
             self.stats['bbox_px'] = self.stats.get('bbox_px', 0) + sum(
                 s_[2] * s_[3] for s_ in st.support if s_ is not None and s_[2] > 0 and s_[3] > 0)
         return T
+
+    _KIND_ID = dict(rotate=0, shear_x=1, shear_y=2, translate_x=3, translate_y=4)
+
+    def _bbox_chain_c(self, st, T, kind, step):
+        """_box_matrices + _bbox_chain with the host arithmetic in ONE C call (csrc/oamix_host.hip oadg_oamix_bbox_plan:
+        draws -> matrices -> inverses -> dependency levels -> level-major step table, written into the pinned staging
+        slot; ctypes releases the interpreter lock for its duration), one copy to the device, the level launches."""
+        L = _lib.lib()
+        b = self._buffers(st)
+        H, W = st.H, st.W
+        ib, sup, m = st.plan_arrays()
+        n = st.n
+        r = rng.random_sample(2 * m) if m else np.zeros((0,))            # the boxes' (level, sign) draws, in box order
+        if n == 0:
+            return
+        nbytes = L.oadg_oamix_bbox_plan_bytes(n)
+        ring = getattr(_TLS, 'ring', None)
+        if ring is None:
+            ring = _TLS.ring = _PinnedRing()
+        k, buf = ring.slot(nbytes)
+        lf = getattr(_TLS, 'level_first', None)
+        if lf is None or lf.size < n + 2:
+            lf = _TLS.level_first = np.empty((max(n + 2, 64),), np.int32)
+        out = (ctypes.c_int * 3)()
+        area = ctypes.c_longlong(0)
+        r = np.ascontiguousarray(r, np.float64)
+        check(L.oadg_oamix_bbox_plan(self._KIND_ID[kind], float(self.severity), ib.ctypes.data, sup.ctypes.data, n,
+                                     r.ctypes.data, int(r.size), H, W, buf.data_ptr(), nbytes, lf.ctypes.data, out,
+                                     ctypes.byref(area)), 'oadg_oamix_bbox_plan')
+        n_live, n_levels = int(out[0]), int(out[1])
+        if self.stats is not None:
+            self.stats['bbox_levels'] = self.stats.get('bbox_levels', 0) + n_levels
+            self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n_live
+        if n_live == 0:
+            return
+        used = n_live * BBOX_STEP_DTYPE.itemsize + (n_live + 1) * 4
+        dev = st.img.device
+        dst = torch.empty((used,), dtype=torch.uint8, device=dev)
+        dst.copy_(buf[:used], non_blocking=True)
+        ev = ring.events[k] = ring.events[k] or torch.cuda.Event()
+        ev.record()
+        step.setdefault('keepalive', []).append(dst)              # descriptor tensor lives until the step's launches ran
+        tiles_off = n_live * BBOX_STEP_DTYPE.itemsize
+        from .. import hip_ops
+        work = float(9 * area.value)
+        check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, dst.data_ptr(),
+                             dst.data_ptr() + tiles_off, lf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
+                             ctypes.cast(buf.data_ptr() + tiles_off, ctypes.POINTER(ctypes.c_int)), ptr(st.My),
+                             ptr(st.Mx), ptr(b['scratch']), stream_ptr(), work=work), 'oadg_oamix_bbox_chain')
 
     def _box_matrices(self, st, kind):
         """The per-box loop above for ALL boxes at once: (rows, rects [m,4], inverted matrices [m,6]) of the boxes that
