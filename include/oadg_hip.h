@@ -339,7 +339,8 @@ int oadg_prep_conv_weights(const float* w, const float* gamma, const float* beta
                            const float* var, float eps, const float* bias_in, int K, int C, int R, int S, void* wf,
                            void* wt, float* bias, float* scale, int w_krsc, int wt_mode, void* stream);
 /* the same for many layers in ONE launch: a device table of descriptors (the arguments of oadg_prep_conv_weights per
- * layer; first_block = sum of K of the layers before it, ascending), total_blocks = sum of K.  Weights change only in
+ * layer; first_block = sum of oadg_prep_conv_weights_multi_blocks of the layers before it, ascending), total_blocks =
+ * their sum.  Weights change only in
  * optimizer.step(), so a trainer re-prepares every layer once after it instead of per layer inside the forward pass. */
 typedef struct oadg_prep_desc {
     const float *w, *gamma, *beta, *mean, *var, *bias_in;
@@ -348,6 +349,7 @@ typedef struct oadg_prep_desc {
     float eps;
     int K, C, R, S, w_krsc, wt_mode, first_block;
 } oadg_prep_desc;
+int oadg_prep_conv_weights_multi_blocks(int K, int C, int R, int S);   /* workgroups of one layer (its first_block step) */
 int oadg_prep_conv_weights_multi(const oadg_prep_desc* descs, int n_layers, int total_blocks, void* stream);
 int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float* w, const float* scale,
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,

@@ -67,6 +67,7 @@ SIGNATURES = {
     'oadg_prep_conv_weights_bwd_parts': (ci, [vp, ci, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_prep_conv_weights': (ci, [vp, vp, vp, vp, vp, cf, vp, ci, ci, ci, ci, vp, vp, vp, vp, ci, ci, vp]),
     'oadg_prep_conv_weights_multi': (ci, [vp, ci, ci, vp]),
+    'oadg_prep_conv_weights_multi_blocks': (ci, [ci, ci, ci, ci]),
     'oadg_conv2d_nhwc_bf16_scatter': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 18 + [vp, vp, vp, vp]),
     'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_relu_bias_bwd_workspace_bytes': (ctypes.c_size_t, [cl, ci]),

@@ -1741,6 +1741,76 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const float* __restri
 // every prepared layer of a model in ONE launch (weights change only in optimizer.step(): hip_conv.refresh_prepared
 // re-prepares all of them right after it instead of one launch per layer inside the next forward pass): workgroup b
 // belongs to the layer with first_block <= b < first_block + K (binary search over the descriptor table)
+// Tiled form for layers with K % 32 == 0: a workgroup prepares 32 output channels x 256 consecutive (r, s, c) positions.
+// The per-channel form writes the data-gradient copy wt [C][taps][K] with ONE 2-byte store per element, K * 2 bytes apart
+// (24 M scattered stores per step: the multi-layer launch ran at 0.6 TB/s); here the tile goes through LDS and leaves as
+// 16-byte pieces of 8 consecutive k.  Same values (same fp32 product, same rounding).
+constexpr int PT_K = 32, PT_I = 256, PT_LD = PT_I + 8;
+__device__ __forceinline__ void prep_weights_tile(int tile, const oadg_prep_desc& d) {
+    __shared__ unsigned short T[PT_K][PT_LD];
+    __shared__ float sc[PT_K];
+    const int K = d.K, C = d.C, RS = d.R * d.S, S = d.S, n = C * RS;
+    const int itiles = (n + PT_I - 1) / PT_I;
+    const int k0 = (tile / itiles) * PT_K, i0 = (tile % itiles) * PT_I;
+    const int tid = threadIdx.x;
+    if (tid < PT_K) {
+        const int k = k0 + tid;
+        float scale = 1.f, b = d.bias_in ? d.bias_in[k] : 0.f;
+        if (d.gamma) {
+            scale = d.gamma[k] * rsqrtf(d.var[k] + d.eps);
+            b = d.beta[k] - d.mean[k] * scale;
+        }
+        sc[tid] = scale;
+        if (i0 == 0) {
+            if (d.bias) d.bias[k] = b;
+            if (d.scale) d.scale[k] = scale;
+        }
+    }
+    __syncthreads();
+    const int i = i0 + tid;
+    unsigned short* wf = (unsigned short*)d.wf;
+    if (i < n) {
+        const int c = i % C, rs = i / C;
+        const size_t src = d.w_krsc ? (size_t)i : (size_t)c * RS + rs;
+#pragma unroll 4
+        for (int kk = 0; kk < PT_K; ++kk) {
+            const unsigned short v = f32_to_bf16(d.w[(size_t)(k0 + kk) * n + src] * sc[kk]);
+            T[kk][tid] = v;
+            wf[(size_t)(k0 + kk) * n + i] = v;
+        }
+    }
+    if (!d.wt) return;
+    __syncthreads();
+    unsigned short* wt = (unsigned short*)d.wt;
+    for (int j = tid; j < PT_I * (PT_K / 8); j += 256) {
+        const int il = j >> 2, kq = (j & 3) * 8;
+        const int ii = i0 + il;
+        if (ii >= n) continue;
+        const int c = ii % C, rs = ii / C;
+        size_t dst;
+        if (d.wt_mode != 2) {
+            dst = ((size_t)c * RS + (RS - 1 - rs)) * K;
+        } else if (RS == 1) {
+            dst = (size_t)c * K;
+        } else {
+            const int r = rs / S, q = rs - r * S;
+            const int ph = r == 1 ? 0 : 1, pw = q == 1 ? 0 : 1;
+            const int tr = r == 0 ? 1 : 0, tq = q == 0 ? 1 : 0;
+            const int Sc = pw ? 2 : 1, Tt = (ph ? 2 : 1) * Sc;
+            const int cls_off = ph == 0 ? (pw == 0 ? 0 : 1) : (pw == 0 ? 3 : 5);
+            dst = (size_t)cls_off * C * K + ((size_t)c * Tt + tr * Sc + tq) * K;
+        }
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (short)T[kq + e][il];
+        *reinterpret_cast<bf16x8*>(wt + dst + k0 + kq) = v;
+    }
+}
+
+// every prepared layer of a model in ONE launch (weights change only in optimizer.step(): hip_conv.refresh_prepared
+// re-prepares all of them right after it instead of one launch per layer inside the next forward pass): workgroup b
+// belongs to the layer with first_block <= b < first_block + blocks (binary search over the descriptor table); a layer
+// has (K / 32) * ceil(C R S / 256) tile workgroups when K % 32 == 0, else one workgroup per output channel
 __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const oadg_prep_desc* __restrict__ descs, int n_layers) {
     int lo = 0, hi = n_layers - 1;
     const int b = blockIdx.x;
@@ -1749,6 +1819,10 @@ __global__ __launch_bounds__(256) void prep_weights_multi_kernel(const oadg_prep
         if (descs[mid].first_block <= b) lo = mid; else hi = mid - 1;
     }
     const oadg_prep_desc d = descs[lo];
+    if (d.K % PT_K == 0) {
+        prep_weights_tile(b - d.first_block, d);
+        return;
+    }
     prep_weights_channel(b - d.first_block, d.w, d.gamma, d.beta, d.mean, d.var, d.eps, d.bias_in, d.K, d.C, d.R, d.S,
                          (unsigned short*)d.wf, (unsigned short*)d.wt, d.bias, d.scale, d.w_krsc, d.wt_mode);
 }
@@ -1795,7 +1869,12 @@ extern "C" int oadg_prep_conv_weights(const float* w, const float* gamma, const 
 }
 
 // descs (device memory): n_layers descriptors sorted by first_block, first_block = sum of K over the layers before;
-// total_blocks = sum of K.  Same arithmetic per layer as oadg_prep_conv_weights.
+// total_blocks = sum of oadg_prep_conv_weights_multi_blocks over the layers.  Same arithmetic per layer as
+// oadg_prep_conv_weights.
+extern "C" int oadg_prep_conv_weights_multi_blocks(int K, int C, int R, int S) {
+    if (K % PT_K == 0) return (K / PT_K) * ((C * R * S + PT_I - 1) / PT_I);
+    return K;
+}
 extern "C" int oadg_prep_conv_weights_multi(const oadg_prep_desc* descs, int n_layers, int total_blocks, void* stream) {
     if (!descs || n_layers < 1 || total_blocks < 1) return OADG_EARG;
     hipLaunchKernelGGL(prep_weights_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_layers);

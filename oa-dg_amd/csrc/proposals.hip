@@ -285,15 +285,18 @@ constexpr int SEL_C = 4096;      // elements per chunk (256 threads x 16 consecu
 
 __device__ __forceinline__ float rpn_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// wave-aggregated histogram increment (saturated sigmoids put thousands of equal keys into one bin)
-__device__ __forceinline__ void hist_add(int* hist, int bin, bool active) {
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader, 64);
-        const unsigned long long same = __ballot(active && bin == b) & todo;
-        if ((threadIdx.x & 63) == leader) atomicAdd(hist + b, __popcll(same));
-        todo &= ~same;
+// Histograms are accumulated per workgroup in LDS and flushed bin by bin (non-zero bins only): sigmoid outputs of one level
+// crowd into a handful of top-bit bins (8 bins per octave), and saturated scores are EQUAL - per-element global atomics on
+// ten addresses serialise (measured: 2.7 ms for the 2.1 M scores of a step against ~20 us through LDS).
+__device__ __forceinline__ void hist_zero(int* lh, int nbins) {
+    for (int b = threadIdx.x; b < nbins; b += 256) lh[b] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void hist_flush(const int* lh, int* gh, int nbins) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256) {
+        const int c = lh[b];
+        if (c) atomicAdd(gh + b, c);
     }
 }
 
@@ -309,10 +312,13 @@ __device__ __forceinline__ int row_of_chunk(const SelArgs& a, int chunk) {
 // pass 0: scores (sigmoid of the head output, in (h, w, a) order) to scratch + histogram of key bits [31:20]
 __global__ __launch_bounds__(256) void sel_score_kernel(SelArgs a, float* __restrict__ scores,
                                                         int* __restrict__ hist) {
+    __shared__ int lh[4096];
     const int r = row_of_chunk(a, blockIdx.x);
     const SelRow row = a.rows[r];
     const SelLevel L = a.lv[row.level];
     const int base = (blockIdx.x - row.chunk0) * SEL_C;
+    const bool select = row.n > row.k;
+    if (select) hist_zero(lh, 4096);
     for (int t = 0; t < SEL_C / 256; ++t) {
         const int i = base + t * 256 + threadIdx.x;
         const bool in = i < row.n;
@@ -324,8 +330,9 @@ __global__ __launch_bounds__(256) void sel_score_kernel(SelArgs a, float* __rest
             s = rpn_sigmoid(load_delta(L.cls, off, L.dtype));
             scores[row.score_off + i] = s;
         }
-        if (row.n > row.k) hist_add(hist + (size_t)r * 4096, (int)(__builtin_bit_cast(unsigned, s) >> 20), in);
+        if (select && in) atomicAdd(&lh[__builtin_bit_cast(unsigned, s) >> 20], 1);
     }
+    if (select) hist_flush(lh, hist + (size_t)r * 4096, 4096);
 }
 
 // the bin (from the top) in which the cumulative count crosses `want`; returns the bin, `above` = elements in higher bins
@@ -380,14 +387,18 @@ __global__ __launch_bounds__(256) void sel_refine_kernel(SelArgs a,
     if (blockIdx.x == row.chunk0 && threadIdx.x == 0) state[(size_t)(LEVEL - 1) * a.n_rows + r] = SelState{prefix, tot_above};
     const int base = (blockIdx.x - row.chunk0) * SEL_C;
     const unsigned mask = LEVEL == 1 ? 0xFFF00000u : 0xFFFFFF00u;
+    constexpr int NB = LEVEL == 1 ? 4096 : 256;
+    __shared__ int lh[NB];
+    hist_zero(lh, NB);
     for (int t = 0; t < SEL_C / 256; ++t) {
         const int i = base + t * 256 + threadIdx.x;
         const bool in = i < row.n;
         const unsigned key = in ? __builtin_bit_cast(unsigned, scores[row.score_off + i]) : 0u;
         const bool hit = in && (key & mask) == prefix;
         const int b = LEVEL == 1 ? (int)((key >> 8) & 0xFFFu) : (int)(key & 0xFFu);
-        hist_add(hist_out + (size_t)r * (LEVEL == 1 ? 4096 : 256), b, hit);
+        if (hit) atomicAdd(&lh[b], 1);
     }
+    hist_flush(lh, hist_out + (size_t)r * NB, NB);
 }
 
 // pass 3: the exact threshold key T and how many keys == T are kept; per chunk the counts of keys > T and == T

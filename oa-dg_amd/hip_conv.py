@@ -411,7 +411,7 @@ class _Bank:
                 w, g_, b_, m_, v_, eps, bi_, K, C, R, S, krsc, want_wt = e.args
                 tab[i] = (p_(w), p_(g_), p_(b_), p_(m_), p_(v_), p_(bi_), p_(e.wf), p_(e.wt), p_(e.bias), p_(e.scale),
                           eps, K, C, R, S, krsc, want_wt, first)
-                first += K
+                first += _lib.lib().oadg_prep_conv_weights_multi_blocks(K, C, R, S)
             dev = ents[0].wf.device
             t = torch.from_numpy(tab.view(np.uint8).reshape(-1).copy()).to(dev)
             # (weak references: the table must not keep the layers of a model that was dropped alive)
