@@ -21,6 +21,7 @@
 // never materialised as H x W x 3 float images (25 MB each in the reference): a blurred box mask is the
 // outer product My[y] * Mx[x] of two 1-D profiles.
 #include "common.h"
+#include <stdlib.h>
 #include "oadg_hip.h"
 
 namespace {
@@ -335,14 +336,10 @@ __device__ __forceinline__ void warp_pixel(const uint8_t* __restrict__ img, int 
 }
 
 // one thread = 4 consecutive pixels of a rect (row-major inside the rect): 12 result bytes as three aligned dwords
-__global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __restrict__ img, int H, int W,
-                                                               const oadg_bbox_step* __restrict__ steps,
-                                                               const int* __restrict__ tile_prefix, int first,
-                                                               int count, int tile_base,
-                                                               const float* __restrict__ My,
-                                                               const float* __restrict__ Mx,
-                                                               uint8_t* __restrict__ scratch) {
-    const int tile = tile_base + blockIdx.x;
+__device__ __forceinline__ void blend_tile(const uint8_t* __restrict__ img, int H, int W,
+                                           const oadg_bbox_step* __restrict__ steps, const int* __restrict__ tile_prefix,
+                                           int first, int count, int tile, const float* __restrict__ My,
+                                           const float* __restrict__ Mx, uint8_t* __restrict__ scratch) {
     const int s = find_step(tile_prefix, first, count, tile);
     const oadg_bbox_step st = steps[s];
     const int rw = st.rect[2], rh = st.rect[3];
@@ -388,17 +385,24 @@ __global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __
     }
 }
 
-// one thread = one pixel (four workgroups per 1024-pixel tile of the blend kernel)
-__global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restrict__ img, int W,
-                                                              const oadg_bbox_step* __restrict__ steps,
-                                                              const int* __restrict__ tile_prefix, int first,
-                                                              int count, int tile_base,
-                                                              const uint8_t* __restrict__ scratch) {
-    const int tile = tile_base + (blockIdx.x >> 2);
+__global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                               const oadg_bbox_step* __restrict__ steps,
+                                                               const int* __restrict__ tile_prefix, int first,
+                                                               int count, int tile_base,
+                                                               const float* __restrict__ My,
+                                                               const float* __restrict__ Mx,
+                                                               uint8_t* __restrict__ scratch) {
+    blend_tile(img, H, W, steps, tile_prefix, first, count, tile_base + blockIdx.x, My, Mx, scratch);
+}
+
+// one thread = one pixel; `quarter` = which 256 pixels of the 1024-pixel blend tile
+__device__ __forceinline__ void copy_tile(uint8_t* __restrict__ img, int W, const oadg_bbox_step* __restrict__ steps,
+                                          const int* __restrict__ tile_prefix, int first, int count, int tile, int quarter,
+                                          const uint8_t* __restrict__ scratch) {
     const int s = find_step(tile_prefix, first, count, tile);
     const oadg_bbox_step st = steps[s];
     const int rw = st.rect[2], rh = st.rect[3];
-    const int i = (tile - tile_prefix[s]) * 1024 + (blockIdx.x & 3) * 256 + threadIdx.x;
+    const int i = (tile - tile_prefix[s]) * 1024 + quarter * 256 + threadIdx.x;
     if (i >= rw * rh) return;
     const int yy = i / rw, xx = i - yy * rw;
     const size_t p = ((size_t)(st.rect[1] + yy) * W + st.rect[0] + xx) * 3;
@@ -407,6 +411,21 @@ __global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restric
     img[p + 1] = in[1];
     img[p + 2] = in[2];
 }
+
+// (four workgroups per 1024-pixel tile of the blend kernel)
+__global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restrict__ img, int W,
+                                                              const oadg_bbox_step* __restrict__ steps,
+                                                              const int* __restrict__ tile_prefix, int first,
+                                                              int count, int tile_base,
+                                                              const uint8_t* __restrict__ scratch) {
+    copy_tile(img, W, steps, tile_prefix, first, count, tile_base + (blockIdx.x >> 2), blockIdx.x & 3, scratch);
+}
+
+// (Round 3 experiment, removed: the whole level chain of an op as ONE persistent launch - a fixed set of workgroups on one
+// XCD walking the levels with grid barriers in between.  It is bit-exact, but slower than the launch pair per level:
+// `buffer_inv sc0` does not drop a compute unit's L1 lines outside threadgroup-split mode (14 of 16 bit-exactness cases
+// failed), `buffer_inv sc1` does and no L2 write-back is needed inside one XCD, but that invalidate costs ~35 us per
+// barrier and disturbs the training stream's L2: config 2 5.9 ms per view against 1.55, whole step 48 ms against 35.)
 
 // ------------------------------------------------------------------------------------------------ compose
 struct ComposeArgs {

@@ -95,10 +95,11 @@ extern "C" int oadg_oamix_bbox_levels(const int* rects, const double* minvs, int
 //   ib [n][4]: int64 box corners (truncated gt boxes); support [n][4]: x0, y0, w, h of the box's mask support (w <= 0 or
 //   h <= 0: the mask is empty - the step draws but changes nothing); draws [2 m]: the m drawing boxes' (level, sign)
 //   uniforms in box order (boxes with integer width or height < 1 return before drawing, :45-47).
-// staging: [n_live] oadg_bbox_step followed by [n_live + 1] int32 tile prefix; level_first [n_levels + 1] (host).
+// staging: [n_live] oadg_bbox_step, [n_live + 1] int32 tile prefix, [n_levels + 1] int32 level table (a copy of the host
+// array level_first).
 // out[0] = n_live, out[1] = n_levels, out[2] = total tiles; *area_sum = sum of the rect areas.
 extern "C" size_t oadg_oamix_bbox_plan_bytes(int n) {
-    return (size_t)(n > 0 ? n : 0) * sizeof(oadg_bbox_step) + ((size_t)(n > 0 ? n : 0) + 1) * sizeof(int) + 8;
+    return (size_t)(n > 0 ? n : 0) * sizeof(oadg_bbox_step) + (2 * (size_t)(n > 0 ? n : 0) + 3) * sizeof(int) + 8;
 }
 
 extern "C" int oadg_oamix_bbox_plan(int kind, double severity, const long long* ib, const int* support, int n,
@@ -186,6 +187,7 @@ extern "C" int oadg_oamix_bbox_plan(int kind, double severity, const long long* 
         tiles[p + 1] = t;
     }
     level_first[n_levels] = nl;
+    for (int l = 0; l <= n_levels; ++l) tiles[nl + 1 + l] = level_first[l];      // device copy of the level table
     out[1] = n_levels; out[2] = t;
     *area_sum = area_tot;
     return OADG_OK;

@@ -37,7 +37,7 @@ def bench_pipeline(name, H, W, n_boxes, box_size, batch, iters, version='augmix'
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
     imgs, boxes, labels = ds.batch(range(batch))
     res = {}
-    for mode in ('batched', 'per_box'):
+    for mode in ('batched', 'per_box'):     # two launches per dependency level (host side in one C call) / per box
         oa_mix.BATCH_BOXES = mode == 'batched'
         np.random.seed(0)
         pipe(imgs, boxes, labels)                       # warm-up (buffers, first-touch)
