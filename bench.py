@@ -146,16 +146,21 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem):
         rois_bytes['roi_align_bwd'].append(b_bwd)
         # forward: read the unique footprint in the map dtype, write 49 C elements
         rois_bytes['roi_align_fwd'].append(roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem, fwd=True))
-    for key, title in (('roi_align_fwd', 'RoIAlign forward'), ('roi_align_bwd', 'RoIAlign backward (atomics kernel)')):
+    from oadg_amd import hip_ops as _ho
+    bwd_kernel = 'roi_align_bwd_tiles_kernel' if (_ho.BWD_TILES and elem == 2) else 'roi_align_bwd_kernel'
+    for key, title in (('roi_align_fwd', 'RoIAlign forward'),
+                       ('roi_align_bwd', 'RoIAlign backward (%s; model bytes = SURVEY 8d: 49 C read + fp32 read-modify-write of '
+                                         'the footprint, which the tile kernel does not do)' % bwd_kernel)):
         rows = ms_of(key)
         if rows and rois_bytes[key]:
             ms = sum(r[0] for r in rows)
             by = sum(rois_bytes[key]) / len(rois_bytes[key]) * len(rows)
-            e = {'family': title, 'kernels': [key + '_kernel'], 'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1),
+            kname = bwd_kernel if key == 'roi_align_bwd' else key + '_kernel'
+            e = {'family': title, 'kernels': [kname], 'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1),
                  'ms_per_step': round(ms / steps, 3), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
                  'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
                  'algorithmic_bytes_per_launch': int(by / len(rows))}
-            e.update({k: v for k, v in pmc_traffic(key + '_kernel').items() if v})
+            e.update({k: v for k, v in pmc_traffic(kname).items() if v})
             out.append(e)
     for key, title in (('supcon_fwd', 'OA-Loss supcon forward'), ('supcon_bwd', 'OA-Loss supcon backward')):
         rows = ms_of(key)

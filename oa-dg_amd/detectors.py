@@ -200,6 +200,18 @@ class TwoStageDetector(BaseDetector):
         if self.with_rpn and gt_bboxes_ignore is None and hasattr(self.rpn_head, 'begin_targets'):
             with _rf('sec:rpn_begin_targets'):
                 self.rpn_head.begin_targets(img.shape[2:], gt_bboxes, img_metas, img.device)
+        # The random proposals (two_stage.py:162-204) depend on the gt / OA-Mix boxes only and draw from the numpy stream,
+        # which nothing else in the step touches (the samplers use torch's CPU generator): they are generated HERE, while
+        # the device still works on the previous step, instead of between the RPN and the RoI head where the stream has
+        # drained to the sampler's host read (~2 ms of host-only numpy work in the most latency-sensitive window).
+        random_proposals = None
+        if 'random_proposal_cfg' in self.train_cfg.keys():
+            host_gts = [m.get('gt_bboxes_np') for m in img_metas]
+            if all(g is not None for g in host_gts):
+                kwargs['img_metas_host'] = host_gts
+            with _rf('sec:random_proposals'):
+                random_proposals = self.get_random_proposal_list(img, gt_bboxes, kwargs)
+            kwargs.pop('img_metas_host', None)
         with _rf('sec:backbone_fpn'):
             x = self.extract_feat(img)
         losses = dict()
@@ -221,13 +233,8 @@ class TwoStageDetector(BaseDetector):
             losses.update(rpn_losses)
         else:
             proposal_list = proposals
-        if 'random_proposal_cfg' in self.train_cfg.keys():
-            host_gts = [m.get('gt_bboxes_np') for m in img_metas]
-            if all(g is not None for g in host_gts):
-                kwargs['img_metas_host'] = host_gts
-            with _rf('sec:random_proposals'):
-                kwargs['random_proposal_list'] = self.get_random_proposal_list(img, gt_bboxes, kwargs)
-            kwargs.pop('img_metas_host', None)
+        if random_proposals is not None:
+            kwargs['random_proposal_list'] = random_proposals
         losses.update(self.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels,
                                                   gt_bboxes_ignore, gt_masks,
                                                   pending_sampling=pending.get('roi'), **kwargs))
