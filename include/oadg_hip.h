@@ -93,6 +93,33 @@ int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* 
                              void* tile_boxes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused RPN loss: AnchorHead.loss (mmdet/models/dense_heads/anchor_head.py:402-544) with CrossEntropyLossPlus (sigmoid
+ * BCE on the view-1 rows + lambda * jsdv1_3_2aug between the views, cross_entropy_loss_plus.py:82-130,264-319) and
+ * L1LossPlus (view-1 rows, smooth_l1_loss_plus.py) for ALL pyramid levels in one forward and one backward launch, reading the
+ * RPN head's output in place.  A level: y (dtype 0 fp32 / 1 bf16, logical [B, Cy, H, W], element strides sN, sC, sH, sW;
+ * channels [0, A) objectness logits, [A, 5A) box deltas), gy = its gradient map (dense NHWC [B, H, W, Cy], written in full
+ * by the backward), first = anchors of the levels before, pix0 = pixels of the levels before.  Images [0, B/2) are view 1,
+ * image i pairs with i + B/2.  labels / label_weights [B, At], bbox_targets / bbox_weights [B, At, 4] as produced by
+ * oadg_anchor_targets.  out4 = {loss_cls, its BCE part, its JSD part, loss_bbox}: sums over all levels (what
+ * BaseDetector._parse_losses makes of the per-level lists, base.py:234-277). */
+typedef struct oadg_rpn_loss_level {
+    const void* y;
+    void* gy;
+    long sN, sC, sH, sW;
+    int H, W, Cy;
+    long first, pix0;
+} oadg_rpn_loss_level;
+size_t oadg_rpn_loss_workspace_bytes(void);
+int oadg_rpn_loss_fwd(const oadg_rpn_loss_level* levels, int n_levels, int B, int A, long At, int dtype,
+                      const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                      const float* bbox_weights, float avg_factor, float w_cls, float lambda_jsd, float w_box,
+                      void* workspace, size_t workspace_bytes, float* out4, void* stream);
+int oadg_rpn_loss_bwd(const oadg_rpn_loss_level* levels, int n_levels, int B, int A, long At, int dtype,
+                      const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                      const float* bbox_weights, float avg_factor, float w_cls, float lambda_jsd, float w_box,
+                      const float* grad_cls, const float* grad_box, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RPN proposals after the per-level top-k (mmdet/models/dense_heads/rpn_head.py:103-235, batched over the images;
  * delta2bbox of mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:184-..., mmcv batched_nms's class offset): csrc/proposals.hip.
  * A level descriptor: the level's bbox_pred (fp32 = dtype 0 / bf16 = 1, logical [N, 4A, H, W] with element strides

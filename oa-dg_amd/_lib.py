@@ -21,6 +21,12 @@ class RpnLevel(Structure):
                 ('dtype', c_int), ('first', c_int)]
 
 
+class RpnLossLevel(Structure):
+    """oadg_rpn_loss_level (include/oadg_hip.h)"""
+    _fields_ = [('y', c_void_p), ('gy', c_void_p), ('sN', c_long), ('sC', c_long), ('sH', c_long), ('sW', c_long),
+                ('H', c_int), ('W', c_int), ('Cy', c_int), ('first', c_long), ('pix0', c_long)]
+
+
 class RegionOp(Structure):
     """oadg_region_op (include/oadg_hip.h)"""
     _fields_ = [('kind', c_int), ('param', c_int), ('image', c_void_p), ('minv', c_double * 6)]
@@ -45,6 +51,9 @@ SIGNATURES = {
     'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
     'oadg_roi_align_bwd_tiles': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, cf, vp, ci, ci, ci,
                                       ci, ci, vp, vp, vp, vp, vp]),
+    'oadg_rpn_loss_workspace_bytes': (cs, []),
+    'oadg_rpn_loss_fwd': (ci, [vp, ci, ci, ci, cl, ci, vp, vp, vp, vp, cf, cf, cf, cf, vp, cs, vp, vp]),
+    'oadg_rpn_loss_bwd': (ci, [vp, ci, ci, ci, cl, ci, vp, vp, vp, vp, cf, cf, cf, cf, vp, vp, vp]),
     'oadg_rpn_decode': (ci, [vp, ci, ci, vp, vp, cf, vp, ci, cf, vp, vp, vp, vp]),
     'oadg_rpn_order': (ci, [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_rpn_gather': (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]),

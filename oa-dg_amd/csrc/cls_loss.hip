@@ -20,6 +20,7 @@
 // deterministic), one pass to write d(logits).  Algorithmic traffic RPN: 2 x (4 B logit) + 8 B label +
 // 4 B weight per pair forward, + 8 B of gradient backward.
 #include "common.h"
+#include "../../include/oadg_hip.h"
 
 namespace {
 
@@ -201,6 +202,172 @@ __global__ void cls_fin_kernel(const double* __restrict__ part, int nblocks, flo
     }
 }
 
+// ================================================================================================ fused RPN loss
+// AnchorHead.loss (mmdet/models/dense_heads/anchor_head.py:402-544) for ALL pyramid levels in one forward and one backward
+// launch, reading the RPN head's output where it lies: the fused cls+reg head writes one channel-padded NHWC map per level
+// (channels [0, A) = objectness logits, [A, 5A) = box deltas, rest padding).  Per level the reference permutes / casts /
+// reshapes both outputs and the four target tensors, runs CrossEntropyLossPlus (BCE on the view-1 rows + JSD between the
+// views, cross_entropy_loss_plus.py:82-130,264-319) and L1LossPlus (view-1 rows, smooth_l1_loss_plus.py), and autograd
+// walks all of that back: ~75 launches forward and ~50 backward per step.  The sum over the levels is what the detector
+// logs (base.py:234-277 sums the per-level list), so one fp64 accumulation over all levels replaces five fp32 ones.
+// Rows: anchor j = level offset + (h*W + w)*A + a of image i pairs with the same anchor of image i + B/2 (view 2).
+struct RpnLossLevels {
+    oadg_rpn_loss_level l[8];
+    int n;
+    long pixels;            // sum of H*W
+};
+
+__device__ __forceinline__ float ld_map(const void* p, long off, int dtype) {
+    if (dtype == 0) return reinterpret_cast<const float*>(p)[off];
+    return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[off] << 16);
+}
+
+__device__ __forceinline__ int level_of_pixel(const RpnLossLevels& lv, long q) {
+    int li = 0;
+    while (li + 1 < lv.n && q >= lv.l[li + 1].pix0) ++li;
+    return li;
+}
+
+__global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossLevels lv, int B, int A, long At, int dtype,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ label_w,
+                                                           const float* __restrict__ bbox_t,
+                                                           const float* __restrict__ bbox_w, double* __restrict__ part) {
+    __shared__ double red[16];
+    const long total = (long)(B / 2) * lv.pixels;
+    double ce = 0.0, js = 0.0, l1 = 0.0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int img = (int)(idx / lv.pixels);
+        const long q = idx - (long)img * lv.pixels;
+        const int li = level_of_pixel(lv, q);
+        const oadg_rpn_loss_level L = lv.l[li];
+        const int pix = (int)(q - L.pix0), w = pix % L.W, h = pix / L.W;
+        const long o1 = (long)img * L.sN + (long)h * L.sH + (long)w * L.sW;
+        const long o2 = o1 + (long)(B / 2) * L.sN;
+        const long j0 = (long)L.first + (long)pix * A;
+        for (int a = 0; a < A; ++a) {
+            const long row = (long)img * At + j0 + a;
+            const float x1 = ld_map(L.y, o1 + (long)a * L.sC, dtype), x2 = ld_map(L.y, o2 + (long)a * L.sC, dtype);
+            const int64_t lab = labels[row];
+            const bool valid = lab >= 0 && lab != IGNORE_INDEX;
+            const float t = (valid && lab == 0) ? 1.0f : 0.0f;
+            const float wv = valid ? label_w[row] : 0.f;
+            const float p1 = sigmoidf_(x1), q1 = 1.0f - p1, p2 = sigmoidf_(x2), q2 = 1.0f - p2;
+            const float mp = fminf(fmaxf((p1 + p2) / 2.0f, 1e-7f), 1.0f), mq = fminf(fmaxf((q1 + q2) / 2.0f, 1e-7f), 1.0f);
+            const float lmp = logf(mp), lmq = logf(mq);
+            ce += (double)(wv * bce_logits(x1, t));
+            js += (double)(((xlogy_term(p1, lmp) + xlogy_term(q1, lmq)) + (xlogy_term(p2, lmp) + xlogy_term(q2, lmq))) / 2.0f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float bw = bbox_w[row * 4 + c];
+                if (bw != 0.f) {
+                    const float pr = ld_map(L.y, o1 + (long)(A + a * 4 + c) * L.sC, dtype);
+                    l1 += (double)(fabsf(pr - bbox_t[row * 4 + c]) * bw);
+                }
+            }
+        }
+    }
+    const double s0 = block_sum_d(ce, red), s1 = block_sum_d(js, red), s2 = block_sum_d(l1, red);
+    if (threadIdx.x == 0) { part[3 * blockIdx.x] = s0; part[3 * blockIdx.x + 1] = s1; part[3 * blockIdx.x + 2] = s2; }
+}
+
+__global__ void rpn_loss_fin_kernel(const double* __restrict__ part, int nblocks, float k_ce, float k_jsd, float k_l1,
+                                    float* __restrict__ out) {
+    __shared__ double red[16];
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { a += part[3 * i]; b += part[3 * i + 1]; c += part[3 * i + 2]; }
+    a = block_sum_d(a, red); b = block_sum_d(b, red); c = block_sum_d(c, red);
+    if (threadIdx.x == 0) {
+        const float ce = (float)a * k_ce, js = (float)b * k_jsd;
+        out[0] = ce + js; out[1] = ce; out[2] = js; out[3] = (float)c * k_l1;
+    }
+}
+
+// one thread per (image, pixel): the whole Cy-channel gradient row of the head output (bf16 / fp32 like y), padding zeroed
+__global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int B, int A, long At, int dtype,
+                                                           const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ label_w,
+                                                           const float* __restrict__ bbox_t,
+                                                           const float* __restrict__ bbox_w, float k_ce, float k_jsd,
+                                                           float k_l1, const float* __restrict__ g_cls,
+                                                           const float* __restrict__ g_box) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * lv.pixels) return;
+    const int img = (int)(idx / lv.pixels);
+    const long q = idx - (long)img * lv.pixels;
+    const int li = level_of_pixel(lv, q);
+    const oadg_rpn_loss_level L = lv.l[li];
+    const int pix = (int)(q - L.pix0), w = pix % L.W, h = pix / L.W;
+    const bool v1 = img < B / 2;
+    const int i1 = v1 ? img : img - B / 2;                    // the view-1 image of the pair (labels / targets live there)
+    const long o1 = (long)i1 * L.sN + (long)h * L.sH + (long)w * L.sW, o2 = o1 + (long)(B / 2) * L.sN;
+    const long j0 = (long)L.first + (long)pix * A;
+    const float gc = g_cls ? g_cls[0] : 1.0f, gb = g_box ? g_box[0] : 1.0f;
+    const size_t grow = (((size_t)img * L.H + h) * L.W + w) * L.Cy;      // gy: dense NHWC [N, H, W, Cy]
+    for (int c8 = 0; c8 < L.Cy; c8 += 8) {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ch = c8 + e;
+            float v = 0.f;
+            if (ch < A) {
+                const long row = (long)i1 * At + j0 + ch;
+                const float x1 = ld_map(L.y, o1 + (long)ch * L.sC, dtype), x2 = ld_map(L.y, o2 + (long)ch * L.sC, dtype);
+                const int64_t lab = labels[row];
+                const bool valid = lab >= 0 && lab != IGNORE_INDEX;
+                const float t = (valid && lab == 0) ? 1.0f : 0.0f;
+                const float wv = valid ? label_w[row] : 0.f;
+                const float p1 = sigmoidf_(x1), q1 = 1.0f - p1, p2 = sigmoidf_(x2), q2 = 1.0f - p2;
+                const float mpr = (p1 + p2) / 2.0f, mqr = (q1 + q2) / 2.0f;
+                const float mp = fminf(fmaxf(mpr, 1e-7f), 1.0f), mq = fminf(fmaxf(mqr, 1e-7f), 1.0f);
+                const float lmp = logf(mp), lmq = logf(mq);
+                if (v1) {
+                    const float d1 = jsd_dterm(p1, p2, mpr, mp, lmp) - jsd_dterm(q1, q2, mqr, mq, lmq);
+                    v = gc * (k_ce * wv * (p1 - t) + k_jsd * p1 * (1.0f - p1) * d1);
+                } else {
+                    const float d2 = jsd_dterm(p2, p1, mpr, mp, lmp) - jsd_dterm(q2, q1, mqr, mq, lmq);
+                    v = gc * (k_jsd * p2 * (1.0f - p2) * d2);
+                }
+            } else if (ch < 5 * A && v1) {
+                const int a = (ch - A) >> 2, c = (ch - A) & 3;
+                const long row = (long)i1 * At + j0 + a;
+                const float bw = bbox_w[row * 4 + c];
+                if (bw != 0.f) {
+                    const float d = ld_map(L.y, o1 + (long)ch * L.sC, dtype) - bbox_t[row * 4 + c];
+                    v = gb * k_l1 * bw * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
+                }
+            }
+            g[e] = v;
+        }
+        if (dtype == 0) {
+            float* o = reinterpret_cast<float*>(L.gy) + grow + c8;
+            *reinterpret_cast<f32x4*>(o) = f32x4{g[0], g[1], g[2], g[3]};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{g[4], g[5], g[6], g[7]};
+        } else {
+            bf16x8 v8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = (short)f32_to_bf16(g[e]);
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned short*>(L.gy) + grow + c8) = v8;
+        }
+    }
+}
+
+int fill_rpn_loss(RpnLossLevels& lv, const oadg_rpn_loss_level* levels, int n_levels, int A, bool need_gy) {
+    if (!levels || n_levels < 1 || n_levels > 8 || A < 1) return OADG_EARG;
+    lv.n = n_levels;
+    long pix = 0, first = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        lv.l[i] = levels[i];
+        if (!levels[i].y || (need_gy && !levels[i].gy) || levels[i].H < 1 || levels[i].W < 1 || levels[i].Cy < 5 * A ||
+            (levels[i].Cy & 7) || levels[i].pix0 != pix || levels[i].first != first)
+            return OADG_EARG;
+        pix += (long)levels[i].H * levels[i].W;
+        first += (long)levels[i].H * levels[i].W * A;
+    }
+    lv.pixels = pix;
+    return OADG_OK;
+}
+
 int grid_for(long items, int per_block) {
     long g = (items + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -259,6 +426,53 @@ int oadg_ce_jsd_bwd(const float* logits, const int64_t* labels, const float* wei
         hipLaunchKernelGGL((sm_kernel<true>), dim3(grid_for(half, 4)), dim3(256), 0, st, logits, labels,
                            weights, half, C, k_ce, k_jsd, grad_out, (double*)nullptr, dlogits);
     }
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+// Fused RPN loss (see above).  levels: per pyramid level the head output y (dtype 0 fp32 / 1 bf16; logical [B, Cy, H, W]
+// with element strides sN, sC, sH, sW; channels [0, A) logits, [A, 5A) deltas), its gradient map gy (dense NHWC
+// [B, H, W, Cy], backward only), first = anchors before the level, pix0 = pixels before it.  labels / label_weights
+// [B, At], bbox_targets / bbox_weights [B, At, 4] (only the view-1 half is read), At = anchors per image.  out4 = {loss_cls
+// (= BCE + lambda JSD), BCE part, JSD part, loss_bbox}, each already multiplied by its weight and divided by avg_factor.
+size_t oadg_rpn_loss_workspace_bytes(void) { return (size_t)MAXBLOCKS * 3 * sizeof(double); }
+
+int oadg_rpn_loss_fwd(const oadg_rpn_loss_level* levels, int n_levels, int B, int A, long At, int dtype,
+                      const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                      const float* bbox_weights, float avg_factor, float w_cls, float lambda_jsd, float w_box,
+                      void* workspace, size_t workspace_bytes, float* out4, void* stream) {
+    RpnLossLevels lv;
+    const int rc = fill_rpn_loss(lv, levels, n_levels, A, false);
+    if (rc) return rc;
+    if (B < 2 || (B & 1) || !labels || !label_weights || !bbox_targets || !bbox_weights || !workspace || !out4 ||
+        !(avg_factor > 0.f) || (dtype != 0 && dtype != 1))
+        return OADG_EARG;
+    if (workspace_bytes < oadg_rpn_loss_workspace_bytes()) return OADG_ESIZE;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = grid_for((long)(B / 2) * lv.pixels, 256 * 2);
+    hipLaunchKernelGGL(rpn_loss_fwd_kernel, dim3(g), dim3(256), 0, st, lv, B, A, At, dtype, labels, label_weights,
+                       bbox_targets, bbox_weights, (double*)workspace);
+    OADG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rpn_loss_fin_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, g, w_cls / avg_factor,
+                       lambda_jsd / avg_factor, w_box / avg_factor, out4);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_rpn_loss_bwd(const oadg_rpn_loss_level* levels, int n_levels, int B, int A, long At, int dtype,
+                      const int64_t* labels, const float* label_weights, const float* bbox_targets,
+                      const float* bbox_weights, float avg_factor, float w_cls, float lambda_jsd, float w_box,
+                      const float* grad_cls, const float* grad_box, void* stream) {
+    RpnLossLevels lv;
+    const int rc = fill_rpn_loss(lv, levels, n_levels, A, true);
+    if (rc) return rc;
+    if (B < 2 || (B & 1) || !labels || !label_weights || !bbox_targets || !bbox_weights || !(avg_factor > 0.f) ||
+        (dtype != 0 && dtype != 1))
+        return OADG_EARG;
+    const long total = (long)B * lv.pixels;
+    hipLaunchKernelGGL(rpn_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lv, B,
+                       A, At, dtype, labels, label_weights, bbox_targets, bbox_weights, w_cls / avg_factor,
+                       lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -191,6 +191,7 @@ class AnchorHead(nn.Module):
                                          _lib.ptr(bbox_weights), _lib.stream_ptr()), 'oadg_anchor_targets')
         num_total_pos = sum(max(r.pos_inds.numel(), 1) for r in srs)
         num_total_neg = sum(max(r.neg_inds.numel(), 1) for r in srs)
+        self._whole_targets = (labels, label_weights, bbox_targets, bbox_weights)      # for the fused loss (all levels)
         out, start = [[], [], [], []], 0
         for n in num_level_anchors:              # images_to_levels: [B, n_level(, 4)] per level
             for lst, t in zip(out, (labels, label_weights, bbox_targets, bbox_weights)):
@@ -253,6 +254,34 @@ class AnchorHead(nn.Module):
         loss_bbox = self.loss_bbox(bbox_pred, bbox_targets, bbox_weights, avg_factor=num_total_samples)
         return loss_cls, loss_bbox
 
+    FUSED_LOSS = os.environ.get('OADG_FUSED_RPN_LOSS', '1') == '1'
+
+    def _fused_loss(self, cls_scores, bbox_preds, num_total_samples):
+        """anchor_head.py:402-452,530-544 for all levels in one launch each way (hip_ops.rpn_loss) when the head wrote its
+        fused channel-padded maps, the targets came from the batch kernel and the losses are the OA-DG pair (sigmoid
+        CrossEntropyLossPlus with / without JSD, L1LossPlus, 2 views); None otherwise."""
+        from .losses import CrossEntropyLossPlus, L1LossPlus
+        whole = getattr(self, '_whole_targets', None)
+        ys = [getattr(c, '_oadg_y', None) for c in cls_scores]
+        lc, lb = self.loss_cls, self.loss_bbox
+        if not self.FUSED_LOSS or whole is None or any(y is None for y in ys) or not ys[0].is_cuda or \
+                type(lc) is not CrossEntropyLossPlus or type(lb) is not L1LossPlus or not lc.use_sigmoid or \
+                lc.num_views != 2 or lb.num_views != 2 or lb.reduction != 'mean' or lc.reduction != 'mean' or \
+                self.cls_out_channels != 1 or self.reg_decoded_bbox or not torch.is_grad_enabled():
+            return None
+        A = cls_scores[0].shape[1]
+        B = ys[0].shape[0]
+        if whole[0].shape[0] != B or (B & 1) or whole[0].shape[1] != sum(c.shape[2] * c.shape[3] * A for c in cls_scores) or \
+                any(y.shape[1] < 5 * A or (y.shape[1] & 7) or not y.is_contiguous(memory_format=torch.channels_last)
+                    for y in ys):
+            return None
+        lam = lc.lambda_weight if lc.with_jsd else 0.0
+        loss_cls, loss_bbox, parts = hip_ops.rpn_loss(ys, A, whole, float(num_total_samples), lc.loss_weight, lam,
+                                                       lb.loss_weight)
+        lc.wandb_features[f'ce_loss({lc.wandb_name})'] = parts[1]
+        lc.wandb_features[f'lam_additional_loss({lc.wandb_name})'] = parts[2]
+        return dict(loss_cls=[loss_cls], loss_bbox=[loss_bbox])
+
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         """anchor_head.py:455-544."""
         featmap_sizes = [f.size()[-2:] for f in cls_scores]
@@ -260,6 +289,7 @@ class AnchorHead(nn.Module):
         device = cls_scores[0].device
         anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
         label_channels = self.cls_out_channels if self.use_sigmoid_cls else 1
+        self._whole_targets = None
         with _rf('sec:rpn_get_targets'):
             targets = self.get_targets(anchor_list, valid_flag_list, gt_bboxes, img_metas,
                                        gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=gt_labels,
@@ -269,6 +299,9 @@ class AnchorHead(nn.Module):
         self.rpn_targets = targets
         labels_l, lw_l, bt_l, bw_l, num_pos, num_neg = targets
         num_total_samples = num_pos + num_neg if self.sampling else num_pos
+        fused = self._fused_loss(cls_scores, bbox_preds, num_total_samples)
+        if fused is not None:
+            return fused
         losses_cls, losses_bbox = multi_apply(self.loss_single, cls_scores, bbox_preds, labels_l, lw_l, bt_l,
                                               bw_l, num_total_samples=num_total_samples)
         return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
@@ -357,7 +390,9 @@ class RPNHead(AnchorHead):
             if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
                 w, b = self._fused_head_params()
                 y = conv2d(x, w, b, 1, 0, 1, in_token=tok)
-                return _SplitHeads.apply(y, n_cls, n_reg)
+                cls, reg = _SplitHeads.apply(y, n_cls, n_reg)
+                cls._oadg_y = y          # (AnchorHead._fused_loss reads the head's map in place)
+                return cls, reg
             return self.rpn_cls(x), self.rpn_reg(x)
         x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True)   # relu(rpn_conv(x))
         return self.rpn_cls(x), self.rpn_reg(x)

@@ -122,6 +122,74 @@ def ce_jsd_loss(logits, labels, weights, use_sigmoid, avg_factor, loss_weight=1.
                         lambda_jsd)
 
 
+# --------------------------------------------------------------------------------------- fused RPN loss
+class _RpnLoss(torch.autograd.Function):
+    """AnchorHead.loss for all pyramid levels on the RPN head's channel-padded NHWC outputs (csrc/cls_loss.hip
+    oadg_rpn_loss_fwd / _bwd): (loss_cls, loss_bbox, parts[4]) - sums over the levels."""
+
+    @staticmethod
+    def forward(ctx, A, targets, avg_factor, w_cls, lam, w_box, *ys):
+        L = _lib.lib()
+        labels, label_w, bbox_t, bbox_w = targets
+        B, At = labels.shape
+        dt = ys[0].dtype
+        assert dt in (torch.float32, torch.bfloat16) and all(y.dtype == dt and y.shape[0] == B for y in ys)
+        nbytes = L.oadg_rpn_loss_workspace_bytes()
+        ws = _ws(nbytes, labels.device)
+        out = torch.empty(4, dtype=torch.float32, device=labels.device)
+        levels = _rpn_loss_levels(ys, None, A)
+        check(L.oadg_rpn_loss_fwd(levels, len(ys), B, A, At, 0 if dt == torch.float32 else 1, ptr(labels), ptr(label_w),
+                                  ptr(bbox_t), ptr(bbox_w), float(avg_factor), float(w_cls), float(lam), float(w_box),
+                                  ptr(ws), nbytes, ptr(out), stream_ptr()), 'oadg_rpn_loss_fwd')
+        ctx.save_for_backward(labels, label_w, bbox_t, bbox_w, *ys)
+        ctx.args = (A, float(avg_factor), float(w_cls), float(lam), float(w_box))
+        ctx.mark_non_differentiable(out)
+        return out[0].clone(), out[3].clone(), out
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, _g):
+        labels, label_w, bbox_t, bbox_w, *ys = ctx.saved_tensors
+        A, avg, w_cls, lam, w_box = ctx.args
+        L = _lib.lib()
+        B, At = labels.shape
+        dt = ys[0].dtype
+        gys = [torch.empty(y.shape, dtype=dt, device=y.device, memory_format=torch.channels_last) for y in ys]
+        levels = _rpn_loss_levels(ys, gys, A)
+        gc = g_cls.contiguous().float().view(1) if g_cls is not None else None
+        gb = g_box.contiguous().float().view(1) if g_box is not None else None
+        if gc is None:
+            gc = torch.zeros(1, device=labels.device)
+        if gb is None:
+            gb = torch.zeros(1, device=labels.device)
+        check(L.oadg_rpn_loss_bwd(levels, len(ys), B, A, At, 0 if dt == torch.float32 else 1, ptr(labels), ptr(label_w),
+                                  ptr(bbox_t), ptr(bbox_w), avg, w_cls, lam, w_box, ptr(gc), ptr(gb), stream_ptr()),
+              'oadg_rpn_loss_bwd')
+        return (None, None, None, None, None, None, *gys)
+
+
+def _rpn_loss_levels(ys, gys, A):
+    levels = (_lib.RpnLossLevel * len(ys))()
+    first = pix = 0
+    for i, y in enumerate(ys):
+        N, Cy, H, W = y.shape
+        lv = levels[i]
+        lv.y = y.data_ptr()
+        lv.gy = gys[i].data_ptr() if gys is not None else None
+        lv.sN, lv.sC, lv.sH, lv.sW = (int(v) for v in y.stride())
+        lv.H, lv.W, lv.Cy, lv.first, lv.pix0 = int(H), int(W), int(Cy), first, pix
+        first += H * W * A
+        pix += H * W
+    return levels
+
+
+def rpn_loss(ys, num_anchors, targets, avg_factor, w_cls, lambda_jsd, w_box):
+    """(loss_cls, loss_bbox, parts) of AnchorHead.loss over all levels; ``ys``: the fused RPN head outputs [B, Cy, H, W]
+    (channels [0, A) logits, [A, 5A) deltas), ``targets`` = (labels [B, At] int64, label_weights [B, At], bbox_targets
+    [B, At, 4], bbox_weights [B, At, 4]), images [0, B/2) = view 1."""
+    require_cuda(*ys, *targets)
+    return _RpnLoss.apply(int(num_anchors), tuple(targets), avg_factor, w_cls, lambda_jsd, w_box, *ys)
+
+
 # --------------------------------------------------------------------------------------- RoIAlign
 def _pyramid_args(maps, scales):
     n = len(maps)
