@@ -460,6 +460,35 @@ int oadg_anchor_targets(const float* anchors, const float* gts, const int64_t* g
                         int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
                         void* stream);
 
+/* BBoxHead.get_targets for all sampled images + bbox2roi of the sampled boxes in ONE launch
+ *   serves BBoxHead._get_target_single / get_targets   mmdet/models/roi_heads/bbox_heads/bbox_head.py:190-257,328-394
+ *          (the fork's contrastive head adds the absolute gt boxes: contrastive_head.py get_targets)
+ *          bbox2roi                                      mmdet/core/bbox/transforms.py:75-94
+ *          SamplingResult.pos_bboxes / pos_gt_bboxes / pos_gt_labels / bboxes   core/bbox/samplers/sampling_result.py
+ * entries_host [n_entries] is a HOST array (copied into the launch arguments; device pointers inside).  Entries
+ * [0, n_target) are sampled images: rows = positives (pos_inds order) then negatives (neg_inds order), image blocks
+ * in entry order; labels (fill_label on negatives), label_weights (pos_weight <= 0 -> 1 on positives, 1 on
+ * negatives), bbox_targets = DeltaXYWHBBoxCoder.encode(box, its gt) with the fork's zero-size guard in row-wise form
+ * (see oadg_anchor_targets), bbox_weights, absolute (gt box of a positive; may be NULL).  Entries [n_target,
+ * n_entries) are raw box lists (npos = 0, nneg rows copied in order, neg_inds NULL) that only produce roi rows
+ * (the fork's random proposals, contrastive_roi_head.py:131-137).  rois [all rows][5] = (entry.batch, x1, y1, x2, y2).
+ * means4 / stds4 are HOST pointers. */
+#define OADG_ROI_TARGET_MAX_ENTRIES 32
+typedef struct oadg_roi_target_entry {
+    const float* bboxes;       /* [n][stride] candidate boxes, device */
+    const float* gt_bboxes;    /* [G][4] */
+    const int64_t* gt_inds;    /* [n] 1-based assigned gt of a candidate, 0 = negative */
+    const int64_t* labels;     /* [n] assigned labels */
+    const int64_t* pos_inds;   /* [npos] */
+    const int64_t* neg_inds;   /* [nneg] */
+    int npos, nneg;
+    int stride;                /* floats per row of bboxes (>= 4) */
+    int batch;                 /* value of the roi's batch-index column */
+} oadg_roi_target_entry;
+int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, int n_target, int64_t fill_label,
+                     float pos_weight, const float* means4, const float* stds4, float* rois, int64_t* labels,
+                     float* label_weights, float* bbox_targets, float* bbox_weights, float* absolute, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

@@ -27,6 +27,16 @@ class RpnLossLevel(Structure):
                 ('H', c_int), ('W', c_int), ('Cy', c_int), ('first', c_long), ('pix0', c_long)]
 
 
+class RoiTargetEntry(Structure):
+    """oadg_roi_target_entry (include/oadg_hip.h)"""
+    _fields_ = [('bboxes', c_void_p), ('gt_bboxes', c_void_p), ('gt_inds', c_void_p), ('labels', c_void_p),
+                ('pos_inds', c_void_p), ('neg_inds', c_void_p), ('npos', c_int), ('nneg', c_int), ('stride', c_int),
+                ('batch', c_int)]
+
+
+ROI_TARGET_MAX_ENTRIES = 32
+
+
 class RegionOp(Structure):
     """oadg_region_op (include/oadg_hip.h)"""
     _fields_ = [('kind', c_int), ('param', c_int), ('image', c_void_p), ('minv', c_double * 6)]
@@ -91,6 +101,7 @@ SIGNATURES = {
     'oadg_sample_select_workspace_bytes': (ctypes.c_size_t, [ci, cl]),
     'oadg_sample_select': (ci, [vp, ci, cl, ci, vp, vp, vp, ctypes.c_size_t, vp]),
     'oadg_anchor_targets': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp]),
+    'oadg_roi_targets': (ci, [vp, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -4,6 +4,7 @@
 //        ascending order, chosen = candidates[perm[:num]], then .unique() = sorted)
 //   oadg_anchor_targets - AnchorHead._get_targets_single for all images (anchor_head.py:201-297 with
 //        DeltaXYWHBBoxCoder.encode, delta_xywh_bbox_coder.py:119-180 incl. the fork's zero-size guard :152-160)
+#include <cstring>
 #include "common.h"
 #include "../../include/oadg_hip.h"
 
@@ -163,6 +164,66 @@ __global__ __launch_bounds__(256) void targets_scatter_kernel(TargetArgs a) {
     }
 }
 
+// ---- RoI head: rois + targets of all sampled rows in one launch ---------------------------------------------------
+struct RoiTargetArgs {
+    oadg_roi_target_entry e[OADG_ROI_TARGET_MAX_ENTRIES];
+    int row_off[OADG_ROI_TARGET_MAX_ENTRIES + 1];
+    int n_entries, n_target;       // entries [n_target, n_entries) only produce rois
+    int target_rows;               // row_off[n_target]
+    int rows;                      // all rows
+    float* rois;                   // [rows][5]
+    long long* labels;             // [target_rows]
+    float* label_weights;
+    float* bbox_targets;           // [target_rows][4]
+    float* bbox_weights;
+    float* absolute;               // [target_rows][4] or null
+    long long fill_label;
+    float pos_weight;
+    float mean[4], stdv[4];
+};
+
+__global__ __launch_bounds__(256) void roi_targets_kernel(const RoiTargetArgs a) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.rows) return;
+    // compile-time entry indices only: a dynamically indexed by-value argument block would be copied to scratch
+    const float* bboxes = nullptr; const float* gtb = nullptr;
+    const long long *gt_inds = nullptr, *lab = nullptr, *pos = nullptr, *neg = nullptr;
+    int npos = 0, stride = 4, batch = 0, base = 0, ei = 0;
+#pragma unroll
+    for (int i = 0; i < OADG_ROI_TARGET_MAX_ENTRIES; ++i)
+        if (i < a.n_entries && r >= a.row_off[i]) {
+            bboxes = a.e[i].bboxes; gtb = a.e[i].gt_bboxes; gt_inds = (const long long*)a.e[i].gt_inds;
+            lab = (const long long*)a.e[i].labels; pos = (const long long*)a.e[i].pos_inds;
+            neg = (const long long*)a.e[i].neg_inds; npos = a.e[i].npos; stride = a.e[i].stride;
+            batch = a.e[i].batch; base = a.row_off[i]; ei = i;
+        }
+    const int j = r - base;
+    const bool is_pos = j < npos;
+    const long long idx = is_pos ? pos[j] : (neg ? neg[j - npos] : (long long)(j - npos));
+    const float* bp = bboxes + idx * stride;
+    const float4 p = make_float4(bp[0], bp[1], bp[2], bp[3]);
+    float* ro = a.rois + (long)r * 5;
+    ro[0] = (float)batch; ro[1] = p.x; ro[2] = p.y; ro[3] = p.z; ro[4] = p.w;
+    if (ei >= a.n_target) return;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), w = t, ab = t;
+    long long l = a.fill_label;
+    float lw = 1.f;
+    if (is_pos) {
+        const long long gi = gt_inds[idx] - 1;
+        const float4 g = reinterpret_cast<const float4*>(gtb)[gi];
+        t = encode_delta(p, g, a.mean, a.stdv);
+        w = make_float4(1.f, 1.f, 1.f, 1.f);
+        ab = g;
+        l = lab[idx];
+        lw = a.pos_weight <= 0.f ? 1.f : a.pos_weight;
+    }
+    a.labels[r] = l;
+    a.label_weights[r] = lw;
+    reinterpret_cast<float4*>(a.bbox_targets)[r] = t;
+    reinterpret_cast<float4*>(a.bbox_weights)[r] = w;
+    if (a.absolute) reinterpret_cast<float4*>(a.absolute)[r] = ab;
+}
+
 }  // namespace
 
 extern "C" size_t oadg_sample_select_workspace_bytes(int jobs, long max_n) {
@@ -212,5 +273,41 @@ extern "C" int oadg_anchor_targets(const float* anchors, const float* gts, const
         hipLaunchKernelGGL(targets_scatter_kernel, dim3((max_k + 255) / 256, 2 * B), dim3(256), 0, st, a);
         OADG_LAUNCH_CHECK();
     }
+    return OADG_OK;
+}
+
+extern "C" int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, int n_target,
+                                int64_t fill_label, float pos_weight, const float* means4, const float* stds4,
+                                float* rois, int64_t* labels, float* label_weights, float* bbox_targets,
+                                float* bbox_weights, float* absolute, void* stream) {
+    if (!entries_host || n_entries < 1 || n_entries > OADG_ROI_TARGET_MAX_ENTRIES || n_target < 0 ||
+        n_target > n_entries || !rois || !means4 || !stds4)
+        return OADG_EARG;
+    if (n_target > 0 && (!labels || !label_weights || !bbox_targets || !bbox_weights)) return OADG_EARG;
+    RoiTargetArgs a;
+    std::memset(&a, 0, sizeof(a));
+    long rows = 0;
+    for (int i = 0; i < n_entries; ++i) {
+        const oadg_roi_target_entry& e = entries_host[i];
+        if (e.npos < 0 || e.nneg < 0 || e.stride < 4) return OADG_EARG;
+        const bool raw = i >= n_target;
+        if (e.npos + e.nneg > 0 && !e.bboxes) return OADG_EARG;
+        if (raw && e.npos != 0) return OADG_EARG;
+        if (!raw && ((e.npos > 0 && (!e.pos_inds || !e.gt_inds || !e.labels || !e.gt_bboxes)) ||
+                     (e.nneg > 0 && !e.neg_inds)))
+            return OADG_EARG;
+        a.e[i] = e;
+        a.row_off[i] = (int)rows;
+        rows += (long)e.npos + e.nneg;
+        if (rows > 0x7fffffffL) return OADG_ESIZE;
+    }
+    for (int i = n_entries; i <= OADG_ROI_TARGET_MAX_ENTRIES; ++i) a.row_off[i] = (int)rows;
+    a.n_entries = n_entries; a.n_target = n_target; a.target_rows = a.row_off[n_target]; a.rows = (int)rows;
+    a.rois = rois; a.labels = (long long*)labels; a.label_weights = label_weights; a.bbox_targets = bbox_targets;
+    a.bbox_weights = bbox_weights; a.absolute = absolute; a.fill_label = fill_label; a.pos_weight = pos_weight;
+    for (int i = 0; i < 4; ++i) { a.mean[i] = means4[i]; a.stdv[i] = stds4[i]; }
+    if (rows == 0) return OADG_OK;
+    hipLaunchKernelGGL(roi_targets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

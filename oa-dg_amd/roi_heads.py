@@ -3,6 +3,9 @@
 RoI feature extraction is one HIP launch over the whole pyramid (level mapping in-kernel) instead of the
 reference's per-level nonzero/gather/scatter loop; every pyramid level is therefore always in the autograd
 graph (the reference needs a dummy-graph trick for that, single_level_roi_extractor.py:136-145)."""
+import ctypes
+import os
+
 import numpy as np
 import torch
 from torch.profiler import record_function as _rf
@@ -156,6 +159,65 @@ class BBoxHead(nn.Module):
             bbox_weights.index_fill_(0, pos_rows, 1.0)
             absolute.index_copy_(0, pos_rows, pg)
         return labels, label_weights, bbox_targets, bbox_weights, absolute
+
+    FUSED_TARGETS = os.environ.get('OADG_FUSED_ROI_TARGETS', '1') != '0'
+
+    def rois_and_targets(self, sampling_results, rcnn_train_cfg, extra=()):
+        """``bbox2roi([r.bboxes ...])`` + ``get_targets_with_absolute`` (+ ``bbox2roi`` of the ``extra`` box lists,
+        appended) in ONE launch of csrc/targets.hip (``oadg_roi_targets``) instead of ≈ 75 gathers, concatenations
+        and the tensor form of the encoder.  Returns (rois [K + K_extra, 5], K, targets) or None when the inputs are
+        outside the kernel's domain (callers then take the tensor path).  bbox_head.py:190-257,328-394,
+        transforms.py:75-94."""
+        from . import _lib
+        n_t, n_all = len(sampling_results), len(sampling_results) + len(extra)
+        if not self.FUSED_TARGETS or n_t == 0 or n_all > _lib.ROI_TARGET_MAX_ENTRIES:
+            return None
+        first = sampling_results[0]
+        if not first.pos_inds.is_cuda:
+            return None
+        dev = first.pos_inds.device
+        entries = (_lib.RoiTargetEntry * n_all)()
+        keep, K = [], 0
+        for i, r in enumerate(sampling_results):
+            bboxes, gtb, ar, _ = r._src
+            if ar.labels is None or bboxes.dtype != torch.float32 or bboxes.dim() != 2 or bboxes.stride(1) != 1:
+                return None
+            gtb = gtb.view(-1, 4) if gtb.dim() < 2 else gtb
+            if gtb.dtype != torch.float32 or not gtb.is_contiguous():
+                gtb = gtb.float().contiguous()
+            gi, lab = ar.gt_inds, ar.labels
+            if gi.dtype != torch.long or lab.dtype != torch.long:
+                return None
+            gi, lab = gi.contiguous(), lab.contiguous()
+            pi, ni = r.pos_inds.contiguous(), r.neg_inds.contiguous()
+            keep.extend((gtb, gi, lab, pi, ni))
+            e = entries[i]
+            e.bboxes, e.gt_bboxes, e.gt_inds, e.labels = bboxes.data_ptr(), gtb.data_ptr(), gi.data_ptr(), lab.data_ptr()
+            e.pos_inds, e.neg_inds, e.npos, e.nneg = pi.data_ptr(), ni.data_ptr(), pi.numel(), ni.numel()
+            e.stride, e.batch = bboxes.stride(0), i
+            K += pi.numel() + ni.numel()
+        K_all = K
+        for j, b in enumerate(extra):
+            if b.dtype != torch.float32 or b.dim() != 2 or b.size(1) < 4 or b.stride(1) != 1 or b.device != dev:
+                return None
+            e = entries[n_t + j]
+            e.bboxes, e.npos, e.nneg, e.stride, e.batch = b.data_ptr(), 0, b.size(0), b.stride(0), j
+            K_all += b.size(0)
+        rois = torch.empty((K_all, 5), dtype=torch.float32, device=dev)
+        labels = torch.empty((K,), dtype=torch.long, device=dev)
+        label_weights = torch.empty((K,), dtype=torch.float32, device=dev)
+        bbox_targets = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        bbox_weights = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        absolute = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        means = (ctypes.c_float * 4)(*[float(v) for v in self.bbox_coder.means])
+        stds = (ctypes.c_float * 4)(*[float(v) for v in self.bbox_coder.stds])
+        _lib.check(_lib.lib().oadg_roi_targets(
+            ctypes.cast(entries, ctypes.c_void_p), n_all, n_t, int(self.num_classes), float(rcnn_train_cfg.pos_weight),
+            ctypes.cast(means, ctypes.c_void_p), ctypes.cast(stds, ctypes.c_void_p), _lib.ptr(rois), _lib.ptr(labels),
+            _lib.ptr(label_weights), _lib.ptr(bbox_targets), _lib.ptr(bbox_weights), _lib.ptr(absolute),
+            _lib.stream_ptr()), 'oadg_roi_targets')
+        del keep
+        return rois, K, (labels, label_weights, bbox_targets, bbox_weights, absolute)
 
     def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
         return self.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg,
@@ -509,9 +571,15 @@ class StandardRoIHead(BaseRoIHead):
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=feats)
 
     def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas, **kwargs):
-        rois = bbox2roi([r.bboxes for r in sampling_results])
-        res = self._bbox_forward(x, rois)
-        targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        fused = self.bbox_head.rois_and_targets(sampling_results, self.train_cfg)
+        if fused is not None:
+            rois, _, targets = fused
+            targets = targets[:4]
+            res = self._bbox_forward(x, rois)
+        else:
+            rois = bbox2roi([r.bboxes for r in sampling_results])
+            res = self._bbox_forward(x, rois)
+            targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
         num_sampled, pos_rows = self._host_counts(sampling_results)
         res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], rois, *targets,
                                                  num_sampled=num_sampled, pos_rows=pos_rows))
@@ -530,24 +598,31 @@ class ContrastiveRoIHead(StandardRoIHead):
     def _bbox_forward_train(self, x, sampling_results, gt_bboxes, gt_labels, img_metas,
                             gt_instance_inds=None, **kwargs):
         with _rf('sec:roi_bbox_forward'):
-            rois = bbox2roi([r.bboxes for r in sampling_results])
+            extra = [r[:, :4] for r in kwargs['random_proposal_list']] if 'random_proposal_list' in kwargs else []
+            fused = self.bbox_head.rois_and_targets(sampling_results, self.train_cfg, extra)
+            if fused is not None:
+                rois_all, K, targets = fused
+                rois = rois_all[:K]
+            else:
+                rois = bbox2roi([r.bboxes for r in sampling_results])
+                K, targets = rois.shape[0], None
+                rois_all = torch.cat([rois, bbox2roi(extra)], dim=0) if extra else rois
             self._last_rois = [rois.detach()]
-            if 'random_proposal_list' in kwargs:
+            if extra:
                 # the reference runs extractor + head a second time on the random proposals and keeps only their
                 # contrastive features (contrastive_roi_head.py:131-137); one pass over both RoI sets is the same
                 # function row for row and halves the RoIAlign backward's full-pyramid gradient traffic (one fp32
                 # scatter buffer, one cast, no accumulation add per level)
-                rois2 = bbox2roi([r[:, :4] for r in kwargs['random_proposal_list']])
-                K = rois.shape[0]
-                both = self._bbox_forward(x, torch.cat([rois, rois2], dim=0))
+                both = self._bbox_forward(x, rois_all)
                 res = dict(cls_score=both['cls_score'][:K], bbox_pred=both['bbox_pred'][:K],
                            cont_feats=both['cont_feats'], bbox_feats=both['bbox_feats'][:K])
-                self._last_rois.append(rois2.detach())
+                self._last_rois.append(rois_all[K:].detach())
             else:
                 res = self._bbox_forward(x, rois)
         with _rf('sec:roi_targets'):
-            targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
-                                                               self.train_cfg)
+            if targets is None:
+                targets = self.bbox_head.get_targets_with_absolute(sampling_results, gt_bboxes, gt_labels,
+                                                                   self.train_cfg)
             self.bbox_targets = targets
             num_sampled, pos_rows = self._host_counts(sampling_results)
         with _rf('sec:roi_loss'):

@@ -114,3 +114,57 @@ def test_fused_rpn_targets_equal_reference_order(dev):
         for x, y in zip(la, lb):
             assert x.shape == y.shape and torch.equal(x, y)
     assert out['reference_rng'] == out['fused_rng']
+
+
+@pytest.mark.parametrize('pos_weight', [-1, 2.5])
+def test_fused_roi_targets_equal_tensor_path(dev, pos_weight):
+    """oadg_roi_targets (rois + labels / weights / encoded deltas / absolute gts of every sampled row, plus the roi rows
+    of extra box lists) against bbox2roi + BBoxHead._get_targets_batched on real sampling results: bit-identical.
+    Images with many, few and no gts; padded proposals (score -1 rows); two views sharing the sampling results."""
+    import numpy as np
+    from oadg_amd.config import ConfigDict
+    from oadg_amd.core import bbox2roi
+    from oadg_amd.core.bbox import MaxIoUAssigner, RandomSampler, sample_many_begin
+    from oadg_amd.roi_heads import Shared2FCBBoxHead
+    gen = torch.Generator(device=dev).manual_seed(3)
+    rs = np.random.RandomState(5)
+    head = Shared2FCBBoxHead(in_channels=8, fc_out_channels=16, roi_feat_size=7, num_classes=8,
+                             loss_bbox=dict(type='L1Loss', loss_weight=1.0)).to(dev)
+    cfg = ConfigDict(pos_weight=pos_weight)
+    asg = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False)
+    smp = RandomSampler(num=128, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    props, gts, labels = [], [], []
+    for n_gt in (12, 3, 0, 40):
+        g = _boxes(gen, n_gt, dev, lo=16., hi=180.)
+        p = _boxes(gen, 300, dev, lo=8., hi=220.)
+        if n_gt:                                            # some proposals close to gts so that positives exist
+            jit = (torch.rand(60, 4, generator=gen, device=dev) - 0.5) * 8
+            p[:60] = g[torch.arange(60, device=dev) % n_gt] + jit
+        score = torch.rand(300, 1, generator=gen, device=dev)
+        score[280:] = -1.                                   # padding rows of a fixed-size proposal list
+        props.append(torch.cat([p, score], 1))
+        gts.append(g)
+        labels.append(torch.tensor(rs.randint(0, 8, n_gt), device=dev, dtype=torch.long))
+    valids = [p[:, 4] >= 0 for p in props]
+    ars, counts = asg.assign_many(props, valids, gts, labels)
+    torch.manual_seed(2)
+    first = sample_many_begin(smp, ars, props, gts, labels, counts=counts).finish()
+    results = list(first) + list(first)                     # two views (contrastive_roi_head.py:84-97)
+    extra = [_boxes(gen, n, dev) for n in (17, 0, 5)]
+    extra[2] = torch.cat([extra[2], torch.ones(5, 1, device=dev)], 1)[:, :4]     # row stride 5
+    head.FUSED_TARGETS = True
+    fused = head.rois_and_targets(results, cfg, extra)
+    assert fused is not None
+    rois_all, K, t = fused
+    ref_rois = bbox2roi([r.bboxes for r in results])
+    ref_t = head._get_targets_batched(results, cfg)
+    assert K == ref_rois.shape[0] and K > 0
+    assert torch.equal(rois_all[:K], ref_rois)
+    ref_extra = torch.cat([torch.cat([b.new_full((b.size(0), 1), j), b[:, :4]], 1) for j, b in enumerate(extra)])
+    assert torch.equal(rois_all[K:], ref_extra)
+    assert int((t[0] < 8).sum()) > 0 and int((t[0] == 8).sum()) > 0
+    for a, b, name in zip(t, ref_t, ('labels', 'label_weights', 'bbox_targets', 'bbox_weights', 'absolute')):
+        assert a.dtype == b.dtype and a.shape == b.shape, name
+        assert torch.equal(a, b), name
+    # more box lists than the launch arguments hold: the caller is told to take the tensor path
+    assert head.rois_and_targets(results * 5, cfg) is None
