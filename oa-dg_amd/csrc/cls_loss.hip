@@ -228,11 +228,28 @@ __device__ __forceinline__ int level_of_pixel(const RpnLossLevels& lv, long q) {
     return li;
 }
 
-__global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossLevels lv, int B, int A, long At, int dtype,
+// AF > 0: the number of anchors per pixel is the compile-time constant AF (5*AF <= 16) and the map is channel-contiguous
+// bf16 with 16-byte aligned rows - the 16 leading channels of both views arrive as two 16-byte loads each and the box
+// weights / targets of an anchor as one float4 (the generic form issues 2-byte loads 2*Cy bytes apart: latency-bound).
+// Same expressions in the same order: bit-identical results.
+__device__ __forceinline__ void ld_row16(const void* y, long off, float* x) {
+    const bf16x8* p = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned short*>(y) + off);
+    const bf16x8 lo = p[0], hi = p[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        x[e] = __builtin_bit_cast(float, (unsigned)(unsigned short)lo[e] << 16);
+        x[8 + e] = __builtin_bit_cast(float, (unsigned)(unsigned short)hi[e] << 16);
+    }
+}
+
+template <int AF>
+__global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossLevels lv, int B, int A_rt, long At, int dtype,
                                                            const int64_t* __restrict__ labels,
                                                            const float* __restrict__ label_w,
                                                            const float* __restrict__ bbox_t,
                                                            const float* __restrict__ bbox_w, double* __restrict__ part) {
+    constexpr bool FAST = AF > 0;
+    const int A = FAST ? AF : A_rt;
     __shared__ double red[16];
     const long total = (long)(B / 2) * lv.pixels;
     double ce = 0.0, js = 0.0, l1 = 0.0;
@@ -245,9 +262,12 @@ __global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossLevels lv, int
         const long o1 = (long)img * L.sN + (long)h * L.sH + (long)w * L.sW;
         const long o2 = o1 + (long)(B / 2) * L.sN;
         const long j0 = (long)L.first + (long)pix * A;
-        for (int a = 0; a < A; ++a) {
+        float xa[16], xb[16];
+        if (FAST) { ld_row16(L.y, o1, xa); ld_row16(L.y, o2, xb); }
+        for (int a = 0; a < A; ++a) {       // (constant trip count in the FAST form: unrolled, xa / xb stay in registers)
             const long row = (long)img * At + j0 + a;
-            const float x1 = ld_map(L.y, o1 + (long)a * L.sC, dtype), x2 = ld_map(L.y, o2 + (long)a * L.sC, dtype);
+            const float x1 = FAST ? xa[a] : ld_map(L.y, o1 + (long)a * L.sC, dtype);
+            const float x2 = FAST ? xb[a] : ld_map(L.y, o2 + (long)a * L.sC, dtype);
             const int64_t lab = labels[row];
             const bool valid = lab >= 0 && lab != IGNORE_INDEX;
             const float t = (valid && lab == 0) ? 1.0f : 0.0f;
@@ -257,12 +277,23 @@ __global__ __launch_bounds__(256) void rpn_loss_fwd_kernel(RpnLossLevels lv, int
             const float lmp = logf(mp), lmq = logf(mq);
             ce += (double)(wv * bce_logits(x1, t));
             js += (double)(((xlogy_term(p1, lmp) + xlogy_term(q1, lmq)) + (xlogy_term(p2, lmp) + xlogy_term(q2, lmq))) / 2.0f);
+            if (FAST) {
+                const float4 bw4 = reinterpret_cast<const float4*>(bbox_w)[row];
+                if (bw4.x != 0.f || bw4.y != 0.f || bw4.z != 0.f || bw4.w != 0.f) {
+                    const float4 bt4 = reinterpret_cast<const float4*>(bbox_t)[row];
+                    const float bwv[4] = {bw4.x, bw4.y, bw4.z, bw4.w}, btv[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float bw = bbox_w[row * 4 + c];
-                if (bw != 0.f) {
-                    const float pr = ld_map(L.y, o1 + (long)(A + a * 4 + c) * L.sC, dtype);
-                    l1 += (double)(fabsf(pr - bbox_t[row * 4 + c]) * bw);
+                    for (int c = 0; c < 4; ++c)
+                        if (bwv[c] != 0.f) l1 += (double)(fabsf(xa[(FAST ? AF : 0) + a * 4 + c] - btv[c]) * bwv[c]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float bw = bbox_w[row * 4 + c];
+                    if (bw != 0.f) {
+                        const float pr = ld_map(L.y, o1 + (long)(A + a * 4 + c) * L.sC, dtype);
+                        l1 += (double)(fabsf(pr - bbox_t[row * 4 + c]) * bw);
+                    }
                 }
             }
         }
@@ -283,16 +314,30 @@ __global__ void rpn_loss_fin_kernel(const double* __restrict__ part, int nblocks
     }
 }
 
-// one thread per (image, pixel): the whole Cy-channel gradient row of the head output (bf16 / fp32 like y), padding zeroed
-__global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int B, int A, long At, int dtype,
+// one thread per (image, pixel) computes the 5A live channels of its gradient row; the workgroup then writes the Cy-channel
+// rows (bf16 / fp32 like y, padding zeroed) cooperatively in 16-byte pieces, consecutive lanes on consecutive pieces: a
+// thread writing its own 256-byte row put every store instruction on 64 different cache lines (0.42 ms for 358 MB)
+template <bool COOP, int AF>
+__global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int B, int A_rt, long At, int dtype,
                                                            const int64_t* __restrict__ labels,
                                                            const float* __restrict__ label_w,
                                                            const float* __restrict__ bbox_t,
                                                            const float* __restrict__ bbox_w, float k_ce, float k_jsd,
                                                            float k_l1, const float* __restrict__ g_cls,
                                                            const float* __restrict__ g_box) {
+    extern __shared__ unsigned char smem_bwd[];
+    constexpr bool FAST = AF > 0;                                     // see rpn_loss_fwd_kernel
+    static_assert(!FAST || COOP, "the vector-load form always stores cooperatively");
+    const int A = FAST ? AF : A_rt;
+    const int esz = dtype == 0 ? 4 : 2;
+    const int NZ = FAST ? 16 : (5 * A + 7) & ~7;                       // live channels, whole 8-channel chunks
+    unsigned char** rowptr = reinterpret_cast<unsigned char**>(smem_bwd);          // [256]
+    unsigned char* vals = smem_bwd + 256 * sizeof(unsigned char*);                 // [256][NZ] elements
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)B * lv.pixels) return;
+    const bool live = idx < (long)B * lv.pixels;
+    if (!COOP && !live) return;
+    int Cy_blk = 0;
+    if (live) {
     const int img = (int)(idx / lv.pixels);
     const long q = idx - (long)img * lv.pixels;
     const int li = level_of_pixel(lv, q);
@@ -304,7 +349,12 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int
     const long j0 = (long)L.first + (long)pix * A;
     const float gc = g_cls ? g_cls[0] : 1.0f, gb = g_box ? g_box[0] : 1.0f;
     const size_t grow = (((size_t)img * L.H + h) * L.W + w) * L.Cy;      // gy: dense NHWC [N, H, W, Cy]
-    for (int c8 = 0; c8 < L.Cy; c8 += 8) {
+    Cy_blk = L.Cy;
+    if (COOP) rowptr[threadIdx.x] = reinterpret_cast<unsigned char*>(L.gy) + grow * esz;
+    const int cend = COOP ? NZ : L.Cy;
+    float xa[16], xb[16];
+    if (FAST) { ld_row16(L.y, o1, xa); ld_row16(L.y, o2, xb); }
+    for (int c8 = 0; c8 < cend; c8 += 8) {  // (two iterations in the FAST form: unrolled, xa / xb stay in registers)
         float g[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -312,16 +362,17 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int
             float v = 0.f;
             if (ch < A) {
                 const long row = (long)i1 * At + j0 + ch;
-                const float x1 = ld_map(L.y, o1 + (long)ch * L.sC, dtype), x2 = ld_map(L.y, o2 + (long)ch * L.sC, dtype);
-                const int64_t lab = labels[row];
-                const bool valid = lab >= 0 && lab != IGNORE_INDEX;
-                const float t = (valid && lab == 0) ? 1.0f : 0.0f;
-                const float wv = valid ? label_w[row] : 0.f;
+                const float x1 = FAST ? xa[ch & 15] : ld_map(L.y, o1 + (long)ch * L.sC, dtype);
+                const float x2 = FAST ? xb[ch & 15] : ld_map(L.y, o2 + (long)ch * L.sC, dtype);
                 const float p1 = sigmoidf_(x1), q1 = 1.0f - p1, p2 = sigmoidf_(x2), q2 = 1.0f - p2;
                 const float mpr = (p1 + p2) / 2.0f, mqr = (q1 + q2) / 2.0f;
                 const float mp = fminf(fmaxf(mpr, 1e-7f), 1.0f), mq = fminf(fmaxf(mqr, 1e-7f), 1.0f);
                 const float lmp = logf(mp), lmq = logf(mq);
                 if (v1) {
+                    const int64_t lab = labels[row];
+                    const bool valid = lab >= 0 && lab != IGNORE_INDEX;
+                    const float t = (valid && lab == 0) ? 1.0f : 0.0f;
+                    const float wv = valid ? label_w[row] : 0.f;
                     const float d1 = jsd_dterm(p1, p2, mpr, mp, lmp) - jsd_dterm(q1, q2, mqr, mq, lmq);
                     v = gc * (k_ce * wv * (p1 - t) + k_jsd * p1 * (1.0f - p1) * d1);
                 } else {
@@ -333,23 +384,53 @@ __global__ __launch_bounds__(256) void rpn_loss_bwd_kernel(RpnLossLevels lv, int
                 const long row = (long)i1 * At + j0 + a;
                 const float bw = bbox_w[row * 4 + c];
                 if (bw != 0.f) {
-                    const float d = ld_map(L.y, o1 + (long)ch * L.sC, dtype) - bbox_t[row * 4 + c];
+                    const float d = (FAST ? xa[ch & 15] : ld_map(L.y, o1 + (long)ch * L.sC, dtype)) - bbox_t[row * 4 + c];
                     v = gb * k_l1 * bw * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
                 }
             }
             g[e] = v;
         }
         if (dtype == 0) {
-            float* o = reinterpret_cast<float*>(L.gy) + grow + c8;
+            float* o = COOP ? reinterpret_cast<float*>(vals) + (size_t)threadIdx.x * NZ + c8
+                            : reinterpret_cast<float*>(L.gy) + grow + c8;
             *reinterpret_cast<f32x4*>(o) = f32x4{g[0], g[1], g[2], g[3]};
             *reinterpret_cast<f32x4*>(o + 4) = f32x4{g[4], g[5], g[6], g[7]};
         } else {
             bf16x8 v8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = (short)f32_to_bf16(g[e]);
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<unsigned short*>(L.gy) + grow + c8) = v8;
+            unsigned short* o = COOP ? reinterpret_cast<unsigned short*>(vals) + (size_t)threadIdx.x * NZ + c8
+                                     : reinterpret_cast<unsigned short*>(L.gy) + grow + c8;
+            *reinterpret_cast<bf16x8*>(o) = v8;
         }
     }
+    } else if (COOP) {
+        rowptr[threadIdx.x] = nullptr;
+    }
+    if (!COOP) return;
+    // every level has the same Cy (checked by the launcher for this form): P 16-byte pieces per row
+    __shared__ int cy_sh;
+    if (threadIdx.x == 0) cy_sh = Cy_blk;                              // thread 0 of a launched block is always live
+    __syncthreads();
+    const int P = cy_sh * esz / 16, liveP = NZ * esz / 16;
+    for (int k = threadIdx.x; k < 256 * P; k += 256) {
+        const int px = k / P, piece = k - px * P;
+        unsigned char* rp = rowptr[px];
+        if (!rp) continue;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (piece < liveP) v = *reinterpret_cast<const f32x4*>(vals + ((size_t)px * NZ * esz) + (size_t)piece * 16);
+        *reinterpret_cast<f32x4*>(rp + (size_t)piece * 16) = v;
+    }
+}
+
+// the vector-load kernels: 3 anchors per pixel, bf16, channels contiguous, every pixel row 16-byte aligned
+bool rpn_loss_fast3(const RpnLossLevels& lv, int A, int dtype) {
+    if (A != 3 || dtype != 1) return false;
+    for (int i = 0; i < lv.n; ++i) {
+        const oadg_rpn_loss_level& l = lv.l[i];
+        if (l.sC != 1 || l.Cy < 16 || (l.sN & 7) || (l.sH & 7) || (l.sW & 7) || ((uintptr_t)l.y & 15)) return false;
+    }
+    return true;
 }
 
 int fill_rpn_loss(RpnLossLevels& lv, const oadg_rpn_loss_level* levels, int n_levels, int A, bool need_gy) {
@@ -450,8 +531,12 @@ int oadg_rpn_loss_fwd(const oadg_rpn_loss_level* levels, int n_levels, int B, in
     if (workspace_bytes < oadg_rpn_loss_workspace_bytes()) return OADG_ESIZE;
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for((long)(B / 2) * lv.pixels, 256 * 2);
-    hipLaunchKernelGGL(rpn_loss_fwd_kernel, dim3(g), dim3(256), 0, st, lv, B, A, At, dtype, labels, label_weights,
-                       bbox_targets, bbox_weights, (double*)workspace);
+    if (rpn_loss_fast3(lv, A, dtype))
+        hipLaunchKernelGGL(rpn_loss_fwd_kernel<3>, dim3(g), dim3(256), 0, st, lv, B, A, At, dtype, labels, label_weights,
+                           bbox_targets, bbox_weights, (double*)workspace);
+    else
+        hipLaunchKernelGGL(rpn_loss_fwd_kernel<0>, dim3(g), dim3(256), 0, st, lv, B, A, At, dtype, labels, label_weights,
+                           bbox_targets, bbox_weights, (double*)workspace);
     OADG_LAUNCH_CHECK();
     hipLaunchKernelGGL(rpn_loss_fin_kernel, dim3(1), dim3(256), 0, st, (const double*)workspace, g, w_cls / avg_factor,
                        lambda_jsd / avg_factor, w_box / avg_factor, out4);
@@ -470,9 +555,25 @@ int oadg_rpn_loss_bwd(const oadg_rpn_loss_level* levels, int n_levels, int B, in
         (dtype != 0 && dtype != 1))
         return OADG_EARG;
     const long total = (long)B * lv.pixels;
-    hipLaunchKernelGGL(rpn_loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lv, B,
-                       A, At, dtype, labels, label_weights, bbox_targets, bbox_weights, w_cls / avg_factor,
-                       lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
+    // cooperative row stores need one Cy for all levels and the live channels of 256 pixels in LDS
+    const int esz = dtype == 0 ? 4 : 2, NZ = (5 * A + 7) & ~7;
+    bool coop = (size_t)256 * NZ * esz <= 48 * 1024;
+    for (int i = 1; i < lv.n; ++i) coop = coop && lv.l[i].Cy == lv.l[0].Cy;
+    if (coop && rpn_loss_fast3(lv, A, dtype) && ((uintptr_t)bbox_targets & 15) == 0 && ((uintptr_t)bbox_weights & 15) == 0) {
+        const size_t smem = 256 * sizeof(void*) + (size_t)256 * 16 * esz;
+        hipLaunchKernelGGL((rpn_loss_bwd_kernel<true, 3>), dim3((unsigned)((total + 255) / 256)), dim3(256), smem,
+                           (hipStream_t)stream, lv, B, A, At, dtype, labels, label_weights, bbox_targets, bbox_weights,
+                           w_cls / avg_factor, lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
+    } else if (coop) {
+        const size_t smem = 256 * sizeof(void*) + (size_t)256 * NZ * esz;
+        hipLaunchKernelGGL((rpn_loss_bwd_kernel<true, 0>), dim3((unsigned)((total + 255) / 256)), dim3(256), smem,
+                           (hipStream_t)stream, lv, B, A, At, dtype, labels, label_weights, bbox_targets, bbox_weights,
+                           w_cls / avg_factor, lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
+    } else {
+        hipLaunchKernelGGL((rpn_loss_bwd_kernel<false, 0>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, lv, B, A, At, dtype, labels, label_weights, bbox_targets, bbox_weights,
+                           w_cls / avg_factor, lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
+    }
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -77,3 +77,33 @@ def test_fused_rpn_loss_is_reproducible(dev):
     a, b = _run(dev, True, 0.1, seed=3), _run(dev, True, 0.1, seed=3)
     assert a[:2] == b[:2]
     assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+
+
+@pytest.mark.parametrize('A', [3, 2])
+def test_rpn_loss_kernel_forms_agree_bit_for_bit(dev, A):
+    """The vector-load kernels (3 anchors, channel-contiguous bf16 maps: two 16-byte loads per view and pixel, rows stored
+    cooperatively) against the generic kernels (any strides: here the same values as NCHW-contiguous maps; any anchor
+    count): same losses and the same gradient maps bit for bit, padding channels exactly zero."""
+    from oadg_amd import hip_ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    B, Cy, shapes = 4, 32, [(24, 40), (12, 20), (6, 10), (3, 5)]
+    At = sum(h * w for h, w in shapes) * A
+    labels = torch.randint(0, 3, (B, At), device=dev, generator=g) - 1                 # -1 ignore, 0 fg, 1 bg
+    label_w = (labels >= 0).float()
+    pos = (labels == 0)
+    bbox_w = pos[..., None].float().expand(B, At, 4).contiguous()
+    bbox_t = torch.randn(B, At, 4, device=dev, generator=g)
+    targets = (labels, label_w, bbox_t, bbox_w)
+    vals = [torch.randn(B, Cy, h, w, device=dev, generator=g).bfloat16() for h, w in shapes]
+    out = []
+    for nhwc in (True, False):
+        ys = [(v.contiguous(memory_format=torch.channels_last) if nhwc else v.contiguous()).clone().requires_grad_(True)
+              for v in vals]
+        lc, lb, parts = hip_ops.rpn_loss(ys, A, targets, 256.0, 1.0, 0.1, 1.0)
+        (lc * 1.5 + lb * 0.5).backward()
+        out.append((lc.detach().clone(), lb.detach().clone(), [y.grad.clone() for y in ys]))
+    (lc1, lb1, g1), (lc2, lb2, g2) = out
+    assert torch.equal(lc1, lc2) and torch.equal(lb1, lb2) and float(lc1) > 0 and float(lb1) > 0
+    for x, y in zip(g1, g2):
+        assert torch.equal(x, y)
+        assert float(x[:, :5 * A].abs().sum()) > 0 and float(x[:, 5 * A:].abs().sum()) == 0.0

@@ -136,11 +136,24 @@ def main():
         return
     if '--torchprof' in sys.argv:
         from torch.profiler import ProfilerActivity, profile
+        # the bench's arrangement: the pipeline of batch i+1 runs in the worker thread while this thread runs step i
+        thread = '--no-thread' not in sys.argv
+        if thread:
+            nxt.get()
+            nxt = pipe.prefetch(*batches[0], worker_seed=1000)
+            for i in range(4):
+                data = nxt.get()
+                nxt = pipe.prefetch(*batches[(i + 1) % 3], worker_seed=1000)
+                eng.step(data)
+            torch.cuda.synchronize()
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as p:
             for i in range(2):
                 data = nxt.get()
+                if thread:
+                    nxt = pipe.prefetch(*batches[(i + 1) % 3], worker_seed=1000)
                 eng.step(data)
-                nxt = pipe.prefetch(*batches[(i + 1) % 3])
+                if not thread:
+                    nxt = pipe.prefetch(*batches[(i + 1) % 3])
             torch.cuda.synchronize()
         p.export_chrome_trace('/tmp/trace.json')
         import collections
@@ -190,6 +203,11 @@ def main():
         print('idle on the main stream: %.2f ms total; gaps > 50 us:' % (sum(g for g, _, _ in gaps if g > 0) / 1e3))
         for g, a_, b_ in sorted(gaps, reverse=True)[:25]:
             print(f'  {g:8.1f} us  after {a_}  before {b_}')
+        for i in range(len(main) - 1):          # context of the largest gaps: three kernels either side
+            if main[i + 1][0] - main[i][1] > 300:
+                print('  gap %.0f us at +%.2f ms:' % (main[i + 1][0] - main[i][1], (main[i][1] - t0) / 1e3))
+                for j in range(max(0, i - 3), min(len(main), i + 5)):
+                    print('     %s %8.1f us  %s' % ('>>' if j == i + 1 else '  ', main[j][1] - main[j][0], main[j][2][:100]))
         # which host section launched the kernel that ENDS each gap?  (kernel -> launch call by correlation id -> section)
         launch_ts = {e['args'].get('correlation'): e['ts'] for e in ev
                      if e.get('cat') in ('cuda_runtime', 'cuda_driver') and 'aunch' in e['name']}
@@ -216,6 +234,20 @@ def main():
                         gap = main[i][0] - main[i - 1][1]
                         if gap > 15 or i < first + 3:
                             print(f'  #{i - first:4d} {gap:7.1f} {main[i][1] - main[i][0]:7.1f}  after {main[i - 1][2][:50]:50s} before {main[i][2][:60]}')
+        # library / ATen kernels of 15 us and more on the main stream, with the section that launched them
+        big = collections.defaultdict(lambda: [0, 0.0])
+        for a_, b_, nm in main:
+            if b_ - a_ >= 15 and ('at::native' in nm or 'rocclr' in nm or 'Cijk' in nm or 'Memcpy' in nm or 'rocprim' in nm):
+                ts = launch_ts.get(kcorr.get((a_, nm[:60])))
+                sec = 'unknown'
+                if ts is not None:
+                    inside = [sct for sct in secs if sct['ts'] <= ts <= sct['ts'] + sct['dur']]
+                    sec = min(inside, key=lambda q: q['dur'])['name'] if inside else 'outside sections'
+                big[(sec, nm[:110])][0] += 1
+                big[(sec, nm[:110])][1] += b_ - a_
+        print('ATen / library kernels >= 15 us on the main stream, per step:')
+        for (sec, nm), (c, t) in sorted(big.items(), key=lambda kv: -kv[1][1])[:40]:
+            print(f'  {c / 2:5.1f} x {t / 2e3:6.3f} ms  [{sec}]  {nm}')
         print('idle (gaps > 5 us) by the section that launched the kernel after the gap, ms per step:')
         for nm, g in sorted(per_sec.items(), key=lambda kv: -kv[1]):
             print(f'  {nm:28s} {g / 2e3:7.2f}')
