@@ -460,6 +460,15 @@ int oadg_anchor_targets(const float* anchors, const float* gts, const int64_t* g
                         int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
                         void* stream);
 
+/* The first FC of the RoI head on RoIAlign's (ph, pw, c)-ordered features: permute the weight's columns instead of the
+ * features
+ *   serves ConvFCBBoxHead.forward `x = x.flatten(1)` + shared_fcs[0]   mmdet/models/roi_heads/bbox_heads/convfc_bbox_head.py
+ *          (NCHW flatten: column c*P + p; P = roi_feat_area) together with autocast's fp32 -> bf16 weight cast
+ * mode 0: src fp32 [O][C][P] -> dst bf16 [O][P][C]        (forward: cast + permute)
+ * mode 1: src bf16 [O][P][C] -> dst fp32 [O][C][P]        (the weight gradient back in the parameter's layout)
+ * C % 64 == 0, P <= 256, O <= 65535. */
+int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, int P, int mode, void* stream);
+
 /* BBoxHead.get_targets for all sampled images + bbox2roi of the sampled boxes in ONE launch
  *   serves BBoxHead._get_target_single / get_targets   mmdet/models/roi_heads/bbox_heads/bbox_head.py:190-257,328-394
  *          (the fork's contrastive head adds the absolute gt boxes: contrastive_head.py get_targets)

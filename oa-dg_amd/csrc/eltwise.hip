@@ -357,3 +357,52 @@ extern "C" int oadg_colsum_reduce(const float* part, long rows, int K, float* ou
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }
+
+// ---- first FC of the RoI head on RoIAlign's own (ph, pw, c) feature order ---------------------------------------------
+// The reference flattens NCHW RoI features, so column c*P + p of the FC weight meets channel c of bin p
+// (convfc_bbox_head.py: x.flatten(1), P = 7*7).  RoIAlign here writes [K][ph][pw][C]; instead of permuting 105 MB of
+// features forward (and their gradient backward) every step, the weight's columns are permuted inside the two passes
+// autocast makes anyway: fp32 -> bf16 forward (mode 0) and bf16 -> fp32 for the gradient (mode 1).
+namespace {
+constexpr int FCP_TC = 64;        // channels per workgroup tile
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fc_weight_permute_kernel(const void* __restrict__ src, void* __restrict__ dst, int C,
+                                                                int P) {
+    extern __shared__ float fcp_tile[];                       // [FCP_TC][P + 1]
+    const int o = blockIdx.y, c0 = blockIdx.x * FCP_TC, n = FCP_TC * P, ld = P + 1;
+    const size_t cp_base = ((size_t)o * C + c0) * P;          // [o][c0 ..][p]: FCP_TC * P contiguous elements
+    if (MODE == 0) {
+        const float* s = reinterpret_cast<const float*>(src) + cp_base;
+        for (int e = threadIdx.x; e < n; e += 256) fcp_tile[(e / P) * ld + e % P] = s[e];
+        __syncthreads();
+        unsigned short* d = reinterpret_cast<unsigned short*>(dst);
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int p = e / FCP_TC, c = e % FCP_TC;
+            d[((size_t)o * P + p) * C + c0 + c] = f32_to_bf16(fcp_tile[c * ld + p]);
+        }
+    } else {
+        const unsigned short* s = reinterpret_cast<const unsigned short*>(src);
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int p = e / FCP_TC, c = e % FCP_TC;
+            fcp_tile[c * ld + p] = bf16_to_f32(s[((size_t)o * P + p) * C + c0 + c]);
+        }
+        __syncthreads();
+        float* d = reinterpret_cast<float*>(dst) + cp_base;
+        for (int e = threadIdx.x; e < n; e += 256) d[e] = fcp_tile[(e / P) * ld + e % P];
+    }
+}
+}  // namespace
+
+extern "C" int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, int P, int mode, void* stream) {
+    if (!src || !dst || O < 1 || C < FCP_TC || (C % FCP_TC) || P < 1 || P > 256 || (mode != 0 && mode != 1) || O > 65535)
+        return OADG_EARG;
+    const size_t smem = (size_t)FCP_TC * (P + 1) * sizeof(float);
+    const dim3 grid(C / FCP_TC, O);
+    if (mode == 0)
+        hipLaunchKernelGGL(fc_weight_permute_kernel<0>, grid, dim3(256), smem, (hipStream_t)stream, src, dst, C, P);
+    else
+        hipLaunchKernelGGL(fc_weight_permute_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, src, dst, C, P);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}

@@ -12,6 +12,21 @@ from .core.bbox import _pinned_to
 from .registry import DETECTORS, build_backbone, build_head, build_neck
 
 
+def _adjacent_views(views):
+    """the tensor the views are consecutive batch slices of (the device pipeline writes all views into one allocation
+    and tags the first with it), or None: then the caller concatenates"""
+    parent = getattr(views[0], '_oadg_batch', None)
+    if parent is None or parent.shape[0] != sum(v.shape[0] for v in views):
+        return None
+    at = parent.data_ptr()
+    for v in views:
+        if v.data_ptr() != at or v.dtype != parent.dtype or v.shape[1:] != parent.shape[1:] or \
+                v.stride() != parent.stride():
+            return None
+        at += v.shape[0] * v.stride(0) * v.element_size()
+    return parent
+
+
 def integrate_data(data, train_cfg):
     """base.py:22-48: concatenate the views along the batch axis (all originals first, then all OA-Mix
     images) and extend/duplicate the per-image lists to match; inject ``num_views`` / ``batch_size``."""
@@ -20,7 +35,10 @@ def integrate_data(data, train_cfg):
         if train_cfg['inv']:
             data['img'] = torch.cat([data['img2'], data['img']], dim=0)
     else:
-        data['img'] = torch.cat([v for k, v in data.items() if ('img' in k) and ('img_metas' not in k)], dim=0)
+        views = [v for k, v in data.items() if ('img' in k) and ('img_metas' not in k)]
+        data['img'] = views[0] if len(views) == 1 else _adjacent_views(views)
+        if data['img'] is None:
+            data['img'] = torch.cat(views, dim=0)
     num_views = int(len(data['img']) / batch_size)
     for i in range(2, num_views + 1):
         for key in ['img', 'gt_bboxes', 'gt_labels', 'gt_instance_inds', 'img_metas', 'multilevel_boxes',

@@ -190,6 +190,42 @@ def rpn_loss(ys, num_anchors, targets, avg_factor, w_cls, lambda_jsd, w_box):
     return _RpnLoss.apply(int(num_anchors), tuple(targets), avg_factor, w_cls, lambda_jsd, w_box, *ys)
 
 
+# --------------------------------------------------------------------------------------- FC weight on NHWC features
+class _FcWeightPermute(torch.autograd.Function):
+    """W fp32 [O, C*P] (column c*P + p, the reference's NCHW flatten) -> bf16 [O, P*C] (column p*C + c, the order of
+    RoIAlign's NHWC output); backward: the bf16 gradient back as fp32 in the parameter's layout.  These are the two
+    passes autocast makes over the weight anyway (cast forward, cast of the gradient), so the 105 MB feature permutation
+    of ``x.flatten(1)`` and its backward disappear (csrc/eltwise.hip oadg_fc_weight_permute)."""
+
+    @staticmethod
+    def forward(ctx, w, C, P):
+        require_cuda(w)
+        O = w.shape[0]
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == C * P
+        out = torch.empty((O, P * C), dtype=torch.bfloat16, device=w.device)
+        check(_lib.lib().oadg_fc_weight_permute(ptr(w), ptr(out), O, C, P, 0, stream_ptr()), 'oadg_fc_weight_permute')
+        ctx.meta = (O, C, P)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        O, C, P = ctx.meta
+        g = g.contiguous()
+        if g.dtype != torch.bfloat16:
+            g = g.to(torch.bfloat16)
+        out = torch.empty((O, C * P), dtype=torch.float32, device=g.device)
+        check(_lib.lib().oadg_fc_weight_permute(ptr(g), ptr(out), O, C, P, 1, stream_ptr()), 'oadg_fc_weight_permute')
+        return out, None, None
+
+
+def fc_weight_permuted(weight, C, P):
+    """bf16 copy of an FC weight with its input columns in (p, c) order - see :class:`_FcWeightPermute`"""
+    return _FcWeightPermute.apply(weight, int(C), int(P))
+
+
+FC_PERMUTE = os.environ.get('OADG_FC_PERMUTE', '1') == '1'
+
+
 # --------------------------------------------------------------------------------------- RoIAlign
 def _pyramid_args(maps, scales):
     n = len(maps)

@@ -251,7 +251,15 @@ class DevicePipeline:
         mk = lambda: torch.empty((N, 3, Hp, Wp), dtype=self.dtype, device=dev,  # noqa: E731
                                  memory_format=torch.channels_last)
         out = dict()
-        img = mk()
+        two_views = self.oamix is not None and self.oamix.num_views > 1
+        if two_views:
+            # both views in one allocation, originals first: integrate_data's torch.cat([img, img2]) (base.py:22-48) becomes
+            # a view of it (detectors.integrate_data) instead of a 100 MB copy per step
+            both = torch.empty((2 * N, 3, Hp, Wp), dtype=self.dtype, device=dev, memory_format=torch.channels_last)
+            img = both[:N]
+            img._oadg_batch = both
+        else:
+            img = mk()
         for i in range(N):   # physical NHWC slice i is contiguous
             check(L.oadg_oamix_normalize(ptr(imgs_u8[i].contiguous() if per_image else imgs_u8[i]), shapes[i][0],
                                          shapes[i][1], mean, stdinv, int(na['to_rgb']),
@@ -278,7 +286,7 @@ class DevicePipeline:
             # host long before its object-aware mixing step needs them
             states = [_ImageState(imgs_u8[i].contiguous(), gt_bboxes[i], om.spatial_ratio, om.sigma_ratio)
                       for i in range(N)]                  # (each with its own H x W)
-            img2 = mk()
+            img2 = both[N:]
             ml, oa = [], []
             for i, st in enumerate(states):
                 om._history = {}

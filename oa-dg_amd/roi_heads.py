@@ -327,8 +327,21 @@ class ConvFCBBoxHead(BBoxHead):
                 xavier_init(m, distribution='uniform')
 
     def _trunk(self, x):
-        x = x.flatten(1)            # (c, ph, pw) order, as the reference's NCHW flatten
-        for fc in self.shared_fcs:
+        fcs = list(self.shared_fcs)
+        if hip_ops.FC_PERMUTE and x.dim() == 4 and x.is_cuda and x.dtype == torch.bfloat16 and \
+                torch.is_autocast_enabled() and x.shape[1] % 64 == 0 and x.shape[2] * x.shape[3] <= 256 and \
+                x.is_contiguous(memory_format=torch.channels_last) and fcs[0].weight.dtype == torch.float32 and \
+                fcs[0].weight.is_contiguous():
+            # RoIAlign wrote [K][ph][pw][C]: the features stay where they are (a view) and the first FC's weight columns
+            # are permuted to that order inside autocast's cast pass (hip_ops._FcWeightPermute) - the same products as
+            # the reference's NCHW flatten, summed in another order
+            fc = fcs.pop(0)
+            K, C, PH, PW = x.shape
+            w = hip_ops.fc_weight_permuted(fc.weight, C, PH * PW)
+            x = self.relu(F.linear(x.permute(0, 2, 3, 1).reshape(K, PH * PW * C), w, fc.bias))
+        else:
+            x = x.flatten(1)        # (c, ph, pw) order, as the reference's NCHW flatten
+        for fc in fcs:
             x = self.relu(fc(x))
         x_cls, x_reg = x, x
         for fc in self.cls_fcs:

@@ -115,3 +115,30 @@ def test_real_files_through_the_reference_pipeline_and_a_train_step(dev, tmp_pat
     hip_conv.enable()
     out = TrainEngine(det, build_optimizer(det, cfg.optimizer), amp_dtype=torch.bfloat16).step(data)
     assert np.isfinite(float(out['loss'])) and float(out['loss']) > 0
+
+
+def test_integrate_data_uses_the_shared_allocation_of_adjacent_views():
+    """base.py:22-48 concatenates the views; when the pipeline wrote them into one allocation (tagged on the first view)
+    integrate_data hands that tensor out instead of copying - same values, same order - and still concatenates anything
+    that is not laid out that way"""
+    import torch
+    from oadg_amd.config import ConfigDict
+    from oadg_amd.detectors import integrate_data
+    both = torch.arange(4 * 3 * 2 * 5, dtype=torch.float32).reshape(4, 3, 2, 5).contiguous(memory_format=torch.channels_last)
+    img, img2 = both[:2], both[2:]
+    img._oadg_batch = both
+
+    def data(a, b):
+        return dict(img=a, img2=b, img_metas=[dict(), dict()], gt_bboxes=[torch.zeros(1, 4)] * 2, gt_labels=[torch.zeros(1)] * 2)
+    cfg = ConfigDict(dict())
+    out = integrate_data(data(img, img2), cfg)
+    assert out['img'].data_ptr() == both.data_ptr() and torch.equal(out['img'], both)
+    assert out['num_views'] == 2 and out['batch_size'] == 2 and len(out['img_metas']) == 4
+    # a second view that lives elsewhere: plain concatenation
+    other = img2.clone()
+    out = integrate_data(data(img, other), cfg)
+    assert out['img'].data_ptr() != both.data_ptr() and torch.equal(out['img'], both)
+    # the tag on a tensor whose neighbour has different strides
+    odd = img2.contiguous()
+    out = integrate_data(data(img, odd), cfg)
+    assert torch.equal(out['img'], both)

@@ -168,3 +168,43 @@ def test_roi_align_bf16_backward_by_tiles(dev, C, K, monkeypatch):
         assert a.dtype == torch.bfloat16 and torch.equal(a, a2)
         assert (a.float().cpu() - rg).abs().max().item() <= 1e-2 * scale
         assert (a.float() - b.float()).abs().max().item() <= 1e-2 * scale
+
+
+def test_fc_weight_permute_is_the_exact_column_permutation(dev):
+    """oadg_fc_weight_permute: bf16(W)[o][p*C + c] = W[o][c*P + p] and the gradient back - both bit-exact"""
+    from oadg_amd import hip_ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    for O, C, P in ((24, 64, 49), (8, 256, 49), (5, 128, 9)):
+        w = torch.randn(O, C * P, device=dev, generator=g, requires_grad=True)
+        out = hip_ops.fc_weight_permuted(w, C, P)
+        ref = w.detach().view(O, C, P).permute(0, 2, 1).reshape(O, P * C).to(torch.bfloat16)
+        assert out.dtype == torch.bfloat16 and torch.equal(out, ref)
+        go = torch.randn(O, P * C, device=dev, generator=g).to(torch.bfloat16)
+        out.backward(go)
+        assert torch.equal(w.grad, go.view(O, P, C).permute(0, 2, 1).reshape(O, C * P).float())
+
+
+def test_bbox_head_on_nhwc_features_matches_the_flatten_path(dev):
+    """Shared2FC head under autocast: first FC on the (ph, pw, c) view with permuted weight columns against
+    x.flatten(1) with the weight as stored: the same products in another summation order (bf16 GEMM, fp32 accumulate)"""
+    from oadg_amd import hip_ops
+    from oadg_amd.roi_heads import Shared2FCBBoxHead
+    torch.manual_seed(0)
+    head = Shared2FCBBoxHead(in_channels=64, fc_out_channels=128, roi_feat_size=7, num_classes=8).to(dev)
+    x0 = torch.randn(96, 64, 7, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for on in (True, False):
+        hip_ops.FC_PERMUTE = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            head.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                cls, reg = head(x)
+            (cls.float().square().sum() + reg.float().square().sum()).backward()
+            res.append((cls.float(), reg.float(), x.grad.float(), head.shared_fcs[0].weight.grad.clone()))
+        finally:
+            hip_ops.FC_PERMUTE = True
+    for a, b in zip(*res):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-6
+        assert (a - b).abs().mean().item() <= 4e-3 * b.abs().mean().item() + 1e-7
