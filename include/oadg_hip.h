@@ -460,6 +460,26 @@ int oadg_anchor_targets(const float* anchors, const float* gts, const int64_t* g
                         int64_t* labels, float* label_weights, float* bbox_targets, float* bbox_weights,
                         void* stream);
 
+/* SGD (momentum, weight decay; no dampening, no nesterov) for a list of fp32 tensors in ONE launch
+ *   serves torch.optim.SGD.step as the reference runs it (configs/_base_/schedules/schedule_1x.py optimizer,
+ *          mmcv OptimizerHook after mmdet/apis/train.py:150-161), torch/optim/sgd.py _multi_tensor_sgd arithmetic:
+ *          g' = fma(wd, p, g); m = g' on a tensor's first step, else m*momentum + g'; p = fma(-lr, m, p)
+ * table_dev [n] on the DEVICE, entries in ascending first_block order: entry i owns blocks [first_block_i,
+ * first_block_i + oadg_sgd_blocks(numel_i)); total_blocks = their sum.  param / grad / momentum: dense fp32 storage of
+ * numel elements in the same element order (any alignment; 16-byte aligned triples take the vector path). */
+typedef struct oadg_sgd_tensor {
+    void* param;
+    const void* grad;
+    void* momentum;
+    long long numel;
+    long long first_block;
+    int first_step;            /* != 0: the momentum buffer is uninitialised and receives g' */
+    int pad;
+} oadg_sgd_tensor;
+long long oadg_sgd_blocks(long long numel);
+int oadg_sgd_step_multi(const oadg_sgd_tensor* table_dev, int n, long long total_blocks, float lr, float momentum,
+                        float weight_decay, void* stream);
+
 /* The first FC of the RoI head on RoIAlign's (ph, pw, c)-ordered features: permute the weight's columns instead of the
  * features
  *   serves ConvFCBBoxHead.forward `x = x.flatten(1)` + shared_fcs[0]   mmdet/models/roi_heads/bbox_heads/convfc_bbox_head.py
