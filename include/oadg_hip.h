@@ -321,6 +321,22 @@ int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, co
 long oadg_conv2d_pixel_tiles(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil,
                              int variant);
 int oadg_colsum_reduce(const float* part, long rows, int K, float* out, void* stream);
+/* several column-sum reductions in ONE launch (the per-layer launches of a backward pass, deferred to its end):
+ * jobs_dev [n] on the DEVICE in ascending first_block order, job i owns blocks [first_block_i, first_block_i +
+ * (K_i + 15) / 16); out[k] = sum over rows of part[row][k] in oadg_colsum_reduce's order (bit-identical).  dgamma != NULL:
+ * the BN scale gradient of that layer was left as a raw dot product by oadg_prep_conv_weights_bwd(_parts) (w_krsc bit
+ * 1) and is finished here: dgamma[k] = (dgamma[k] - out[k] * mean[k]) * rsqrt(var[k] + eps) - the expression those
+ * functions evaluate when they are given the reduced bias gradient. */
+typedef struct oadg_colsum_job {
+    const float* part;         /* [rows][K] */
+    float* out;                /* [K] */
+    float* dgamma;             /* [K] or NULL */
+    const float* mean;
+    const float* var;
+    int rows, K, first_block;
+    float eps;
+} oadg_colsum_job;
+int oadg_colsum_reduce_multi(const oadg_colsum_job* jobs_dev, int n, int total_blocks, void* stream);
 /* the variant (2, 3 or 4) variant 0 resolves to for a problem BY ITS GEOMETRY; 0 = shape not covered.  A launch with a
  * bf16 mask operand (or mask_bits together with relu_bits_out) runs 3 where this says 4: callers that need
  * colsum_part pass the variant they resolved explicitly, to oadg_conv2d_pixel_tiles (variant 4: one row per pixel
@@ -337,7 +353,9 @@ int oadg_conv2d_wgrad_nhwc_bf16(const void* x, const void* dy, float* dw, const 
 /* the weight gradient as split partials + their consumer: oadg_conv2d_wgrad_parts_nhwc_bf16 leaves
  * workspace = [*splits][K][R*S][C] fp32; oadg_prep_conv_weights_bwd_parts sums the splits in fp32 and applies the
  * backward of oadg_prep_conv_weights (dw [K,C,R,S], dgamma) in the same launch - no reduction kernel, no bf16 round
- * trip of the weight gradient.  C*R*S <= 3000 (five fp32 copies of a filter in LDS). */
+ * trip of the weight gradient.  C*R*S <= 3000 (five fp32 copies of a filter in LDS).  w_krsc: bit 0 = the weight lies
+ * [K][R][S][C] in memory (channels_last parameter), bit 1 = gbias is not available yet: dgamma receives the raw dot
+ * product and oadg_colsum_reduce_multi finishes it (also for oadg_prep_conv_weights_bwd). */
 int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, const void* zeros16, void* workspace,
                                       size_t workspace_bytes, int N, int H, int W, int C, int K, int R, int S,
                                       int stride, int pad, int dil, int* splits, void* stream);

@@ -282,6 +282,8 @@ class FlatGradReducer:
             self._next += 1
 
     def _launch(self, b):
+        from . import hip_conv
+        hip_conv.flush_colsums()          # bias gradients whose reduction was deferred (hip_conv.DEFER_COLSUM) are read now
         flat = self.flat[b['start']:b['end']]
         if all(p.grad is not None for p in b['params']):
             torch.cat([self._memory_order(p.grad, p) for p in b['params']], out=flat)     # ONE packing launch
@@ -369,10 +371,17 @@ class TrainEngine:
         return out
 
     def _step(self, data):
+        from . import hip_conv
         self.optimizer.zero_grad(set_to_none=True)
-        (loss, log_vars), n = self.forward_losses(data)
+        # (torch DDP copies gradients into its buckets from autograd hooks: nothing may be pending there)
+        hip_conv.begin_step(defer=self.amp_dtype is torch.bfloat16 and self.ddp is None)
+        try:
+            (loss, log_vars), n = self.forward_losses(data)
+            with _rf('sec:backward'):
+                loss.backward()
+        finally:
+            hip_conv.end_backward()      # the deferred column-sum reductions of this backward pass: one launch
         with _rf('sec:backward'):
-            loss.backward()
             if self.reducer is not None:
                 self.reducer.finish()
         with _rf('sec:optimizer'):
@@ -380,7 +389,6 @@ class TrainEngine:
             if self.amp_dtype is torch.bfloat16:
                 # the parameters just changed: re-prepare every convolution's weights (BN fold, bf16 layouts) in one launch,
                 # so that the next forward pass prepares nothing (hip_conv.refresh_prepared)
-                from . import hip_conv
                 hip_conv.refresh_prepared()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
 

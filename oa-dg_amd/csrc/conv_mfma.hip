@@ -1834,8 +1834,9 @@ __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned sh
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ var, float eps, int K, int C,
                                                                int R, int S, float* __restrict__ dw,
-                                                               float* __restrict__ dgamma, int w_krsc) {
+                                                               float* __restrict__ dgamma, int w_flags) {
     __shared__ float red[16];
+    const int w_krsc = w_flags & 1;
     const int k = blockIdx.x;
     const int RS = R * S, n = C * RS;
     const float sc = scale ? scale[k] : 1.f;
@@ -1849,7 +1850,10 @@ __global__ __launch_bounds__(256) void prep_weights_bwd_kernel(const unsigned sh
     }
     if (dgamma) {
         const float tot = block_sum(dot, red);
-        if (threadIdx.x == 0) dgamma[k] = (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
+        // (w_krsc bit 1: the bias gradient is not reduced yet - store the raw dot product; oadg_colsum_reduce_multi
+        // finishes dgamma with the same expression once the column sums exist)
+        if (threadIdx.x == 0)
+            dgamma[k] = (w_flags & 2) ? tot : (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
     }
 }
 
@@ -1892,9 +1896,10 @@ __global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const floa
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ var, float eps, int K,
                                                                      int C, int R, int S, float* __restrict__ dw,
-                                                                     float* __restrict__ dgamma, int w_krsc) {
+                                                                     float* __restrict__ dgamma, int w_flags) {
     extern __shared__ float gsum[];            // [R*S][C]
     __shared__ float red[16];
+    const int w_krsc = w_flags & 1;
     const int k = blockIdx.x;
     const int RS = R * S, n = C * RS;
     const size_t stride = (size_t)K * n;
@@ -1927,7 +1932,10 @@ __global__ __launch_bounds__(1024) void prep_weights_bwd_parts_kernel(const floa
     }
     if (dgamma) {
         const float tot = block_sum(dot, red);
-        if (threadIdx.x == 0) dgamma[k] = (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
+        // (w_krsc bit 1: the bias gradient is not reduced yet - store the raw dot product; oadg_colsum_reduce_multi
+        // finishes dgamma with the same expression once the column sums exist)
+        if (threadIdx.x == 0)
+            dgamma[k] = (w_flags & 2) ? tot : (tot - (gbias ? gbias[k] : 0.f) * mean[k]) * rsqrtf(var[k] + eps);
     }
 }
 }  // namespace

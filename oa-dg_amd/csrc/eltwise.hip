@@ -128,6 +128,37 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restr
     }
 }
 
+// colsum_reduce_kernel for a table of jobs in one launch (same slices, same order: the same sums bit for bit), plus the
+// finish of a BN scale gradient that prep_weights_bwd*_kernel left as a raw dot product (w_krsc bit 1)
+__global__ __launch_bounds__(256) void colsum_reduce_multi_kernel(const oadg_colsum_job* __restrict__ jobs, int n) {
+    __shared__ float red[16][17];
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const oadg_colsum_job j = jobs[lo];
+    const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int k = ((int)blockIdx.x - j.first_block) * 16 + c;
+    const int K = j.K, nblocks = j.rows;
+    float s = 0.f;
+    if (k < K) {
+        const int per = (nblocks + 15) >> 4;
+        const int b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += j.part[(long)b * K + k];
+    }
+    red[sl][c] = s;
+    __syncthreads();
+    if (sl == 0 && k < K) {
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][c];
+        j.out[k] = tot;
+        if (j.dgamma) j.dgamma[k] = (j.dgamma[k] - tot * j.mean[k]) * rsqrtf(j.var[k] + j.eps);
+    }
+}
+
 int plan_blocks(long M, int K, long* rows_per_block) {
     const int G = K >> 3;
     const int RP = EB_THREADS / G > 0 ? EB_THREADS / G : 1;
@@ -403,6 +434,16 @@ extern "C" int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, 
         hipLaunchKernelGGL(fc_weight_permute_kernel<0>, grid, dim3(256), smem, (hipStream_t)stream, src, dst, C, P);
     else
         hipLaunchKernelGGL(fc_weight_permute_kernel<1>, grid, dim3(256), smem, (hipStream_t)stream, src, dst, C, P);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+// the reductions of several producers in one launch: jobs_dev [n] on the DEVICE in ascending first_block order, job i owns
+// blocks [first_block_i, first_block_i + (K_i + 15) / 16)
+extern "C" int oadg_colsum_reduce_multi(const oadg_colsum_job* jobs_dev, int n, int total_blocks, void* stream) {
+    if (!jobs_dev || n < 1 || total_blocks < 1) return OADG_EARG;
+    hipLaunchKernelGGL(colsum_reduce_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev,
+                       n);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

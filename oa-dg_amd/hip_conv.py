@@ -7,6 +7,7 @@ Forward, data gradients (stride 1 and 2) and weight gradients run on the hand-wr
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -65,6 +66,116 @@ def supported(x, weight, stride, padding, dilation):
             padding[0] == padding[1] and dilation[0] == dilation[1] and R == S)
 
 
+# ---- deferred column sums -------------------------------------------------------------------------------------------
+# A data-gradient launch leaves the producer's bias gradient as per-tile partial sums; reducing them is a 6 us launch
+# per layer (48 per step).  Nothing on the device needs the reduced vector before the optimizer (it only travels up the
+# graph to AccumulateGrad, and into the BN-fold chain rule of _PrepWeights.backward as ONE term of dgamma), so inside
+# TrainEngine's backward the reductions are collected and run as one launch at the end (or before a gradient bucket is
+# packed): DEFER_COLSUM.  A pending vector is never read early: the producer resolves it on the spot unless its
+# prepared weights are used exactly once this step (shared convolutions get their bias gradients SUMMED by autograd),
+# and _PrepWeights.backward leaves dgamma raw for the deferred launch to finish with the same expression.
+DEFER_COLSUM = False
+_PENDING = []
+_STEP = 0                   # training-step counter: a bank entry counts the forward uses of its parameters per step
+
+
+def begin_step(defer):
+    """TrainEngine: a new step starts; ``defer``: collect the column-sum reductions of its backward pass"""
+    global _STEP, DEFER_COLSUM
+    _STEP += 1
+    DEFER_COLSUM = bool(defer) and os.environ.get('OADG_DEFER_COLSUM', '1') == '1'
+
+
+def end_backward():
+    """TrainEngine: the backward pass has been enqueued - run what was deferred, stop deferring"""
+    global DEFER_COLSUM
+    DEFER_COLSUM = False
+    return flush_colsums()
+
+
+_CS_JOB = np.dtype([('part', np.uint64), ('out', np.uint64), ('dgamma', np.uint64), ('mean', np.uint64),
+                    ('var', np.uint64), ('rows', np.int32), ('K', np.int32), ('first_block', np.int32),
+                    ('eps', np.float32)])                                                           # oadg_colsum_job
+_CS_STAGE = {}
+
+
+class _PendingColsum:
+    __slots__ = ('part', 'out', 'fix', 'done', 'targets')
+
+    def __init__(self, part, out):
+        # ``out`` / the tensors of ``fix`` are ALIASES (detach()) of the vectors that travel up the graph: they keep the
+        # storage alive without adding a reference to the travelling tensor itself - AccumulateGrad only adopts a
+        # gradient it holds the last reference to, otherwise it copies it (here: before the flush has written it)
+        self.part, self.out, self.fix, self.done = part, out.detach(), None, False
+        self.targets = []           # (parameter, alias): where the vector is expected to end up as .grad
+
+
+def _colsum(part, K):
+    """the reduced column sums of ``part`` [rows][K] - now, or (DEFER_COLSUM) as a pending vector of flush_colsums()"""
+    cs = torch.empty((K,), dtype=torch.float32, device=part.device)
+    if DEFER_COLSUM:
+        ent = _PendingColsum(part, cs)
+        cs._oadg_pending = ent
+        _PENDING.append(ent)
+    else:
+        check(_lib.lib().oadg_colsum_reduce(ptr(part), part.shape[0], K, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
+    return cs
+
+
+def pending_colsum(t):
+    ent = getattr(t, '_oadg_pending', None) if t is not None else None
+    return ent if (ent is not None and not ent.done) else None
+
+
+def resolve_colsum(t):
+    """reduce a pending vector now (its consumer is about to read it on the device)"""
+    ent = pending_colsum(t)
+    if ent is not None:
+        check(_lib.lib().oadg_colsum_reduce(ptr(ent.part), ent.part.shape[0], ent.out.shape[0], ptr(ent.out),
+                                            stream_ptr()), 'oadg_colsum_reduce')
+        ent.done, ent.part = True, None
+        _PENDING.remove(ent)
+    return t
+
+
+def flush_colsums():
+    """all pending reductions (and the dgamma terms that wait for them) in one launch on the current stream"""
+    global _PENDING
+    pend, _PENDING = _PENDING, []
+    if not pend:
+        return 0
+    dev = pend[0].out.device
+    tab = np.zeros(len(pend), dtype=_CS_JOB)
+    blocks = 0
+    for i, e in enumerate(pend):
+        K = e.out.shape[0]
+        r = tab[i]
+        r['part'], r['out'], r['rows'], r['K'], r['first_block'] = e.part.data_ptr(), e.out.data_ptr(), e.part.shape[0], K, blocks
+        if e.fix is not None:
+            dg, mean, var, eps = e.fix
+            r['dgamma'], r['mean'], r['var'], r['eps'] = dg.data_ptr(), mean.data_ptr(), var.data_ptr(), eps
+        blocks += (K + 15) // 16
+    st = _CS_STAGE.get(dev)
+    if st is None or st[0][0].numel() < tab.nbytes:
+        n = max(tab.nbytes, 256 * _CS_JOB.itemsize)
+        st = _CS_STAGE[dev] = ([torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(4)],
+                               [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(4)], [0])
+    st[2][0] = (st[2][0] + 1) % 4          # a few flushes per step at most (one per gradient bucket): four slots
+    pin, tdev = st[0][st[2][0]], st[1][st[2][0]]
+    pin.numpy()[:tab.nbytes] = tab.view(np.uint8)
+    tdev[:tab.nbytes].copy_(pin[:tab.nbytes], non_blocking=True)
+    check(_lib.lib().oadg_colsum_reduce_multi(ptr(tdev), len(pend), blocks, stream_ptr()), 'oadg_colsum_reduce_multi')
+    for e in pend:
+        for prm, alias in e.targets:
+            # AccumulateGrad adopts a gradient it holds the last reference to - then .grad IS the vector just finished.
+            # Had it copied instead (a tensor hook, an extra reference), the copy was taken too early: refresh it.
+            g = prm.grad
+            if g is not None and g.data_ptr() != alias.data_ptr() and g.shape == alias.shape:
+                g.copy_(alias)
+        e.done, e.part, e.fix, e.targets = True, None, None, []
+    return len(pend)
+
+
 def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False, mask_bits=None,
                  bits_out=None):
     """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last.
@@ -106,9 +217,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
                        % ('true' if (residual is not None or mask is not None or mask_bits is not None) else 'false'),
                        (N, H, W, C, K, R, stride, residual is not None, mask is not None)))
     if want_colsum:
-        cs = torch.empty((K,), dtype=torch.float32, device=x.device)
-        check(L.oadg_colsum_reduce(ptr(part), part.shape[0], K, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
-        return y, cs
+        return y, _colsum(part, K)
     return y
 
 
@@ -149,9 +258,7 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
                                               ptr(mask_bits), stream_ptr()), 'oadg_conv2d_nhwc_bf16_scatter')
         row += tiles
     if want_colsum:
-        cs = torch.empty((C,), dtype=torch.float32, device=gy.device)
-        check(L.oadg_colsum_reduce(ptr(part), part.shape[0], C, ptr(cs), stream_ptr()), 'oadg_colsum_reduce')
-        return gx, cs
+        return gx, _colsum(part, C)
     return gx
 
 
@@ -292,6 +399,11 @@ class _PrepWeights(torch.autograd.Function):
         ctx.cfg = (float(eps), gamma is not None, bias_in is not None, K, C, R, S, krsc)
         ctx.leaf_inputs = leaf      # False: autograd ops (not AccumulateGrad) consume the gradients next
         ctx.wtoken = wtoken
+        ctx.entry = entry
+        if entry is not None:       # forward uses of these parameters in the current step (see DEFER_COLSUM)
+            if entry.step != _STEP:
+                entry.step, entry.count = _STEP, 0
+            entry.count += 1
         if entry is not None:       # the bank's tensors live across steps: hand out fresh aliases (autograd stamps outputs)
             wf, bias, wt = wf.detach(), (bias.detach() if bias is not None else None), (wt.detach() if wt is not None else None)
         outs = (wf, bias if bias is not None else w.new_zeros(0), wt if wt is not None else w.new_zeros(0))
@@ -305,6 +417,17 @@ class _PrepWeights(torch.autograd.Function):
         L = _lib.lib()
         dw = dgamma = dbeta = dbias_in = None
         gb = gbias.float().contiguous() if (gbias is not None and gbias.numel()) else None
+        pend = pending_colsum(gbias)
+        ent = ctx.entry
+        if pend is not None and not (gb is gbias and ctx.leaf_inputs and ent is not None and ent.step == _STEP and
+                                     ent.count == 1 and all(t.grad is None for t in ent.src)):
+            # the vector can only wait when it goes, as it is, to AccumulateGrad of parameters used ONCE in this step that
+            # hold no gradient yet (a shared convolution's bias gradients, or a second micro-batch, are summed there as
+            # they arrive)
+            resolve_colsum(gbias)
+            pend = None
+        gb_now = None if pend is not None else gb
+        raw = 2 if pend is not None else 0
         tok = ctx.wtoken
         parts = None
         if tok is not None and tok.parts is not None:
@@ -312,17 +435,24 @@ class _PrepWeights(torch.autograd.Function):
         if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
             dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
-            check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb), ptr(w), ptr(scale), ptr(mean),
-                                                     ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), krsc,
+            check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb_now), ptr(w), ptr(scale), ptr(mean),
+                                                     ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), int(krsc) | raw,
                                                      stream_ptr()),
                   'oadg_prep_conv_weights_bwd_parts')
         elif gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             dw = torch.empty_like(w)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
-            check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
-                                               R, S, ptr(dw), ptr(dgamma), krsc, stream_ptr()),
+            check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb_now), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
+                                               R, S, ptr(dw), ptr(dgamma), int(krsc) | raw, stream_ptr()),
                   'oadg_prep_conv_weights_bwd')
+        if pend is not None:
+            src = ent.src
+            pend.targets.append((src[2] if has_bn else src[-1], pend.out))
+            if dgamma is not None:
+                pend.fix = (dgamma.detach(), mean, var, float(eps))   # flush_colsums() finishes it from the raw dot product
+                pend.targets.append((src[1], pend.fix[0]))
+            # (dgamma None: the weight received no gradient; the vector itself is still the BN shift gradient)
         if has_bn:
             dbeta = gb
         elif has_bias_in:
@@ -349,11 +479,13 @@ def _wt_useful(x, K, C, stride, pad, dil, R):
 class _BankEntry:
     """The prepared tensors of one trainable convolution, kept across steps (weights change only in optimizer.step()):
     ``valid`` while the version counters of the source parameters are the ones the tensors were prepared from."""
-    __slots__ = ('src', 'versions', 'args', 'wf', 'wt', 'bias', 'scale', 'mean', 'var', 'want_wt', '__weakref__')
+    __slots__ = ('src', 'versions', 'args', 'wf', 'wt', 'bias', 'scale', 'mean', 'var', 'want_wt', 'step', 'count',
+                 '__weakref__')
 
     def __init__(self, src, want_wt):
         self.src, self.want_wt = src, int(want_wt)           # src: the tensors whose versions define validity
         self.versions = None
+        self.step, self.count = -1, 0
         self.wf = self.wt = self.bias = self.scale = self.mean = self.var = self.args = None
 
     def current_versions(self):
@@ -548,6 +680,8 @@ class _Conv2dMFMA(torch.autograd.Function):
                 gy.dtype == torch.bfloat16 and gy.is_contiguous(memory_format=torch.channels_last):
             gb = out_token.colsum if want_b else None     # masked and reduced by the consumer's dgrad epilogue
             want_b = False
+            if pending_colsum(gb) is not None and not (ctx.wtoken is not None and ctx.wtoken.uses == 1):
+                resolve_colsum(gb)      # shared / unknown weights: autograd may sum this vector with others right away
         elif (y is not None or want_b) and gy.dtype in (torch.bfloat16, torch.float32) and K % 8 == 0 and \
                 gy.is_contiguous(memory_format=torch.channels_last):
             gy, gb = relu_bias_bwd(gy, y, want_b)            # mask + cast + bias gradient: one pass over dy

@@ -835,3 +835,62 @@ def test_grad_token_late_depositor_taints_the_token(dev):
             assert (a - b).abs().max().item() <= 3e-2 * b.abs().max().item() + 1e-6, k
     finally:
         hip_conv.enable(False)
+
+
+def test_deferred_column_sums_give_the_same_gradients_bit_for_bit(dev):
+    """hip_conv.DEFER_COLSUM (TrainEngine's backward): the per-layer reductions of the bias-gradient partial sums run as
+    ONE launch after the backward pass (oadg_colsum_reduce_multi), BN scale gradients are left raw by the weight
+    preparation's backward and finished there.  Every parameter gradient of ResNet-50 + FPN + RPN head (shared across
+    the five levels: its vectors must NOT wait, autograd sums them on arrival) equals the immediate form bit for bit;
+    the deferred pass really defers (one multi launch with many jobs)."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import ResNet
+    from oadg_amd.dense_heads import RPNHead
+    from oadg_amd.necks import FPN
+    hip_conv.enable(True)
+    try:
+        torch.manual_seed(0)
+        bb = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                    norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+        neck = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)
+        neck.init_weights()
+        head = RPNHead(in_channels=256, feat_channels=256,
+                       anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0],
+                                             strides=[4, 8, 16, 32, 64]),
+                       loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                       loss_bbox=dict(type='L1Loss', loss_weight=1.0))
+        net = torch.nn.ModuleList([bb, neck, head]).to(dev).to(memory_format=torch.channels_last)
+        net.train()
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+                torch.nn.init.normal_(m.bias, 0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.2)
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn(2, 3, 128, 192, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        res, jobs = {}, {}
+        for mode in ('immediate', 'deferred', 'deferred_again'):
+            net.zero_grad(set_to_none=True)
+            hip_conv.begin_step(defer=mode != 'immediate')
+            assert hip_conv.DEFER_COLSUM == (mode != 'immediate')
+            try:
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    cls, reg = head(neck(bb(x)))
+                loss = sum((c.float() ** 2).mean() for c in cls) + sum(r.float().abs().mean() for r in reg)
+                loss.backward()
+                jobs[mode] = len(hip_conv._PENDING)
+            finally:
+                flushed = hip_conv.end_backward()
+            assert flushed == jobs[mode] and not hip_conv._PENDING and not hip_conv.DEFER_COLSUM
+            torch.cuda.synchronize()
+            res[mode] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert jobs['immediate'] == 0 and jobs['deferred'] >= 30, jobs
+        assert set(res['immediate']) == set(res['deferred']) and len(res['immediate']) > 100
+        for n, a in res['immediate'].items():
+            assert torch.equal(a, res['deferred'][n]), n
+            assert torch.equal(a, res['deferred_again'][n]), n
+        assert any('bn' in n and n.endswith('weight') and float(v.abs().sum()) > 0 for n, v in res['deferred'].items())
+    finally:
+        hip_conv.enable(False)
+        hip_conv.DEFER_COLSUM = False
