@@ -507,6 +507,32 @@ int oadg_sgd_step_multi(const oadg_sgd_tensor* table_dev, int n, long long total
  * C % 64 == 0, P <= 256, O <= 65535. */
 int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, int P, int mode, void* stream);
 
+/* RoI head: MaxIoUAssigner over the proposals of every image + "add the gts as proposals" in three launches
+ *   serves StandardRoIHead.forward_train's per-image loop   mmdet/models/roi_heads/standard_roi_head.py:88-101
+ *          (bbox_assigner.assign, max_iou_assigner.py:61-213) and the head of BaseSampler.sample
+ *          (core/bbox/samplers/base_sampler.py:38-78: bboxes = cat([gt_bboxes, bboxes]), assign_result.add_gt_(gt_labels)
+ *          core/bbox/assigners/assign_result.py add_gt_, gt_flags)
+ * images_host [B] is a HOST array (device pointers inside): proposals [N][stride] (stride >= 5: column 4 is a score,
+ * rows with score < 0 are padding and never candidates), gt_bboxes [num_gts][4], gt_labels [num_gts].
+ * Outputs, rows of image b: [Gmax - num_gts_b, Gmax) = its gts (gt_inds j + 1, their labels, overlap 1), [Gmax,
+ * Gmax + N) = its proposals with the assignment of oadg_max_iou_assign - so image b's tensors are the contiguous row
+ * ranges [Gmax - num_gts_b, Gmax + N) of boxes_full [B][Gmax + N][4], gt_inds_full / labels_full / max_ov_full
+ * [B][Gmax + N].  counts [B][2] = candidates among the PROPOSALS only (#gt_inds > 0, #gt_inds == 0).  valid [B][N],
+ * gts_pad [B][Gmax][4], gl_pad [B][Gmax], gt_counts [B], workspace (oadg_max_iou_assign_workspace_bytes) are scratch. */
+#define OADG_ROI_ASSIGN_MAX_IMAGES 32
+typedef struct oadg_roi_assign_image {
+    const float* proposals;
+    const float* gt_bboxes;
+    const int64_t* gt_labels;
+    int stride;
+    int num_gts;
+} oadg_roi_assign_image;
+int oadg_roi_assign_add_gt(const oadg_roi_assign_image* images_host, int B, int N, int Gmax, float pos_iou_thr,
+                           float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                           float* boxes_full, int64_t* gt_inds_full, int64_t* labels_full, float* max_ov_full,
+                           unsigned char* valid, float* gts_pad, int64_t* gl_pad, int* gt_counts, void* workspace,
+                           size_t workspace_bytes, int* counts, void* stream);
+
 /* BBoxHead.get_targets for all sampled images + bbox2roi of the sampled boxes in ONE launch
  *   serves BBoxHead._get_target_single / get_targets   mmdet/models/roi_heads/bbox_heads/bbox_head.py:190-257,328-394
  *          (the fork's contrastive head adds the absolute gt boxes: contrastive_head.py get_targets)

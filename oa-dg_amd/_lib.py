@@ -27,6 +27,15 @@ class RpnLossLevel(Structure):
                 ('H', c_int), ('W', c_int), ('Cy', c_int), ('first', c_long), ('pix0', c_long)]
 
 
+class RoiAssignImage(Structure):
+    """oadg_roi_assign_image (include/oadg_hip.h)"""
+    _fields_ = [('proposals', c_void_p), ('gt_bboxes', c_void_p), ('gt_labels', c_void_p), ('stride', c_int),
+                ('num_gts', c_int)]
+
+
+ROI_ASSIGN_MAX_IMAGES = 32
+
+
 class RoiTargetEntry(Structure):
     """oadg_roi_target_entry (include/oadg_hip.h)"""
     _fields_ = [('bboxes', c_void_p), ('gt_bboxes', c_void_p), ('gt_inds', c_void_p), ('labels', c_void_p),
@@ -105,6 +114,8 @@ SIGNATURES = {
     'oadg_sgd_blocks': (ctypes.c_longlong, [ctypes.c_longlong]),
     'oadg_sgd_step_multi': (ci, [vp, ci, ctypes.c_longlong, cf, cf, cf, vp]),
     'oadg_fc_weight_permute': (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    'oadg_roi_assign_add_gt': (ci, [vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t,
+                                    vp, vp]),
     'oadg_roi_targets': (ci, [vp, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),

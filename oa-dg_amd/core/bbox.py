@@ -3,6 +3,7 @@
 Sampling consumes the global CPU torch generator exactly like the reference (random_sampler.py:58:
 ``torch.randperm(n)`` with n = number of candidates), so seeded runs pick identical indices.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -276,7 +277,9 @@ class SamplingResult:
             elif name == 'neg_bboxes':
                 c[name] = bboxes[self.neg_inds]
             elif name == 'pos_is_gt':
-                c[name] = gt_flags[self.pos_inds]
+                # (an int: that many leading rows of ``bboxes`` are the gts added as proposals - no flag tensor was built)
+                c[name] = (self.pos_inds < gt_flags).to(torch.uint8) if isinstance(gt_flags, int) \
+                    else gt_flags[self.pos_inds]
             elif name == 'pos_assigned_gt_inds':
                 c[name] = ar.gt_inds[self.pos_inds] - 1
             elif name == 'pos_gt_bboxes':
@@ -495,6 +498,82 @@ def sample_many_begin(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_l
         counts = torch.stack([torch.stack([p[3]().sum(), p[4]().sum()]) for p in prepared])
         added = None                                  # the masks already contain the added gts
     return PendingSampling(sampler, prepared, gt_bboxes_list, counts, added)
+
+
+ROI_ASSIGN_FUSED = os.environ.get('OADG_FUSED_ROI_ASSIGN', '1') == '1'
+
+
+def roi_assign_sample_begin(assigner, sampler, proposals, gt_bboxes_list, gt_labels_list):
+    """``assigner.assign`` over the proposals of every image + the head of ``sampler.sample`` (gts added as proposals:
+    boxes, gt_inds, labels, overlaps with the gt rows in front) in THREE launches of csrc/assign.hip
+    (``oadg_roi_assign_add_gt``) instead of ~48 (per image: validity mask, stack, assignment, arange / ones / five
+    concatenations): every image's tensors are contiguous row ranges of four batch tensors.  Returns the
+    :class:`PendingSampling` handle ``sample_many_begin`` would, or None when the inputs are outside the kernels' domain
+    (standard_roi_head.py:88-101, base_sampler.py:38-78, assign_result.py add_gt_)."""
+    from .. import _lib
+    B = len(proposals)
+    if not (ROI_ASSIGN_FUSED and 0 < B <= _lib.ROI_ASSIGN_MAX_IMAGES and sampler.add_gt_as_proposals and
+            assigner.gt_max_assign_all and isinstance(assigner.neg_iou_thr, (float, tuple)) and
+            gt_labels_list is not None and len(gt_bboxes_list) == B):
+        return None
+    first = proposals[0]
+    N = first.shape[0]
+    if not (first.is_cuda and N > 0):
+        return None
+    counts_host = [int(g.shape[0]) for g in gt_bboxes_list]
+    Gmax = max(counts_host)
+    if Gmax > 1024:
+        return None
+    images = (_lib.RoiAssignImage * B)()
+    keep = []
+    for i in range(B):
+        p, g, l = proposals[i], gt_bboxes_list[i], gt_labels_list[i]
+        if p.dtype != torch.float32 or p.dim() != 2 or p.shape[0] != N or p.stride(1) != 1 or \
+                not (p.shape[1] == 5 or (p.shape[1] == 4 and p.stride(0) == 4)) or \
+                l is None or g.dtype != torch.float32 or l.dtype != torch.long or g.device != p.device:
+            return None         # ([N, 5]: column 4 is the score, negative on padding rows; [N, 4] dense: all rows valid)
+        g = g.view(-1, 4) if g.dim() < 2 else g[:, :4]
+        g, l = g.contiguous(), l.contiguous()
+        keep.extend((g, l))
+        im = images[i]
+        im.proposals, im.stride, im.num_gts = p.data_ptr(), p.stride(0), counts_host[i]
+        im.gt_bboxes, im.gt_labels = (g.data_ptr(), l.data_ptr()) if counts_host[i] else (None, None)
+    dev, rows = first.device, Gmax + N
+    boxes_full = torch.empty((B, rows, 4), dtype=torch.float32, device=dev)
+    gt_inds_full = torch.empty((B, rows), dtype=torch.long, device=dev)
+    labels_full = torch.empty((B, rows), dtype=torch.long, device=dev)
+    max_ov_full = torch.empty((B, rows), dtype=torch.float32, device=dev)
+    L = _lib.lib()
+    nws = L.oadg_max_iou_assign_workspace_bytes(B, Gmax)
+    # scratch in one allocation: valid [B][N] u8 | gts_pad [B][Gmax][4] f32 | gl_pad [B][Gmax] i64 | gt_counts [B] i32 |
+    # workspace | counts [B][2] i32, each part 16-byte aligned
+    sizes = [B * N, B * Gmax * 16, B * Gmax * 8, B * 4, nws, B * 8]
+    offs, at = [], 0
+    for n in sizes:
+        offs.append(at)
+        at += (n + 15) // 16 * 16
+    scratch = torch.empty(max(at, 16), dtype=torch.uint8, device=dev)
+    base = scratch.data_ptr()
+    pp = [ctypes.c_void_p(base + o) for o in offs]
+    counts = scratch[offs[5]:offs[5] + B * 8].view(torch.int32).view(B, 2)
+    lo, hi = (0.0, assigner.neg_iou_thr) if isinstance(assigner.neg_iou_thr, float) else assigner.neg_iou_thr
+    _lib.check(L.oadg_roi_assign_add_gt(ctypes.cast(images, ctypes.c_void_p), B, N, Gmax, float(assigner.pos_iou_thr),
+                                        float(lo), float(hi), float(assigner.min_pos_iou),
+                                        int(bool(assigner.match_low_quality)), _lib.ptr(boxes_full),
+                                        _lib.ptr(gt_inds_full), _lib.ptr(labels_full), _lib.ptr(max_ov_full), pp[0],
+                                        pp[1] if Gmax else None, pp[2] if Gmax else None, pp[3], pp[4], nws, pp[5],
+                                        _lib.stream_ptr()), 'oadg_roi_assign_add_gt')
+    del keep
+    prepared, added = [], []
+    for i in range(B):
+        s0 = Gmax - counts_host[i]
+        ar = AssignResult(counts_host[i], gt_inds_full[i, s0:], max_ov_full[i, s0:], labels=labels_full[i, s0:])
+        prepared.append((ar, boxes_full[i, s0:], counts_host[i],
+                         (lambda a_=ar: a_.gt_inds > 0), (lambda a_=ar: a_.gt_inds == 0)))
+        added.append(counts_host[i])
+    pend = PendingSampling(sampler, prepared, gt_bboxes_list, counts, added)
+    pend._scratch = scratch          # (counts is a view of it; the asynchronous read-back has its own pinned copy)
+    return pend
 
 
 def sample_many(sampler, assign_results, bboxes_list, gt_bboxes_list, gt_labels_list=None):

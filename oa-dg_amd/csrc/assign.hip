@@ -8,6 +8,7 @@
 //           matching "every box that attains a gt's maximum (>= min_pos_iou) is assigned to it; later gts
 //           overwrite earlier ones" (:195-201); optional labels; candidate counts for the sampler.
 // The IoU of pass 2 is recomputed by the same code as pass 1, so `iou == gt_max` is an exact comparison.
+#include <cstring>
 #include "common.h"
 #include "../../include/oadg_hip.h"
 
@@ -31,6 +32,7 @@ struct AssignArgs {
     float* max_overlaps;       // [B][N]
     int64_t* labels;           // [B][N] or null
     int* counts;               // [B][2] (#gt_inds > 0, #gt_inds == 0), zeroed by the caller-side memset
+    long out_stride;           // elements between the images' rows of gt_inds / max_overlaps / labels (N when dense)
 };
 
 __device__ __forceinline__ unsigned fkey(float f) {      // order-preserving float -> unsigned
@@ -123,9 +125,9 @@ __global__ __launch_bounds__(AS_THREADS) void assign_kernel(AssignArgs a) {
             if (last > 0) ind = last;
         }
         if (!ok) ind = -1;                             // filtered-out box (anchor_inside_flags / padding row)
-        a.gt_inds[(long)b * a.N + n] = ind;
-        a.max_overlaps[(long)b * a.N + n] = mo;
-        if (a.labels) a.labels[(long)b * a.N + n] = ind > 0 ? a.gt_labels[(long)b * a.Gmax + (ind - 1)] : -1;
+        a.gt_inds[(long)b * a.out_stride + n] = ind;
+        a.max_overlaps[(long)b * a.out_stride + n] = mo;
+        if (a.labels) a.labels[(long)b * a.out_stride + n] = ind > 0 ? a.gt_labels[(long)b * a.Gmax + (ind - 1)] : -1;
         npos += ind > 0;
         nneg += ind == 0;
     }
@@ -148,6 +150,65 @@ __global__ void assign_init_kernel(unsigned* gt_max, int n, int* counts, int m) 
     if (i < m) counts[i] = 0;
 }
 
+// ---- RoI head: assignment of the proposals + "add the gts as proposals" for the whole batch --------------------------
+// Row r of image b in the [Gmax + N]-row outputs: r >= Gmax = proposal r - Gmax; r in [Gmax - G_b, Gmax) = gt
+// r - (Gmax - G_b), self-matched (gt_inds j + 1, its label, overlap 1: AssignResult.add_gt_); rows below are unused, so
+// image b's tensors are the contiguous row ranges [Gmax - G_b, Gmax + N).
+struct RoiPrepArgs {
+    oadg_roi_assign_image img[OADG_ROI_ASSIGN_MAX_IMAGES];
+    int B, N, Gmax;
+    float* boxes_full;         // [B][Gmax + N][4]
+    int64_t* gt_inds_full;     // [B][Gmax + N]
+    int64_t* labels_full;      // [B][Gmax + N]
+    float* max_ov_full;        // [B][Gmax + N]
+    unsigned char* valid;      // [B][N]
+    float* gts_pad;            // [B][Gmax][4]
+    int64_t* gl_pad;           // [B][Gmax]
+    int* gt_counts;            // [B]
+    unsigned* gt_max;          // [B][max(Gmax, 1)]
+    int* counts;               // [B][2]
+};
+
+__global__ __launch_bounds__(256) void roi_assign_prep_kernel(const RoiPrepArgs a) {
+    const int b = blockIdx.y;
+    const float* props = nullptr; const float* gts = nullptr; const int64_t* gl = nullptr;
+    int stride = 4, G = 0;
+#pragma unroll
+    for (int i = 0; i < OADG_ROI_ASSIGN_MAX_IMAGES; ++i)          // compile-time indices into the argument block
+        if (i == b) { props = a.img[i].proposals; gts = a.img[i].gt_bboxes; gl = a.img[i].gt_labels;
+                      stride = a.img[i].stride; G = a.img[i].num_gts; }
+    const int rows = a.Gmax + a.N;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) {
+        a.gt_counts[b] = G;
+        a.counts[2 * b] = 0; a.counts[2 * b + 1] = 0;
+        if (a.Gmax == 0) a.gt_max[b] = fkey(-1.f);
+    }
+    if (r >= rows) return;
+    const long o = (long)b * rows + r;
+    if (r < a.Gmax) {
+        // padded per-image gt tables for the assignment kernels (+ their per-gt maxima reset)
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t l = 0;
+        if (r < G) { g = reinterpret_cast<const float4*>(gts)[r]; l = gl[r]; }
+        reinterpret_cast<float4*>(a.gts_pad)[(long)b * a.Gmax + r] = g;
+        a.gl_pad[(long)b * a.Gmax + r] = l;
+        a.gt_max[(long)b * a.Gmax + r] = fkey(-1.f);
+        const int j = r - (a.Gmax - G);
+        if (j >= 0) {
+            reinterpret_cast<float4*>(a.boxes_full)[o] = reinterpret_cast<const float4*>(gts)[j];
+            a.gt_inds_full[o] = j + 1;
+            a.labels_full[o] = gl[j];
+            a.max_ov_full[o] = 1.0f;
+        }
+        return;
+    }
+    const int n = r - a.Gmax;
+    const float* p = props + (long)n * stride;
+    reinterpret_cast<float4*>(a.boxes_full)[o] = make_float4(p[0], p[1], p[2], p[3]);
+    a.valid[(long)b * a.N + n] = stride >= 5 ? (p[4] >= 0.f ? 1 : 0) : 1;
+}
+
 }  // namespace
 
 extern "C" size_t oadg_max_iou_assign_workspace_bytes(int B, int Gmax) {
@@ -168,13 +229,57 @@ extern "C" int oadg_max_iou_assign(const float* boxes, long box_stride, const un
     a.pos_thr = pos_iou_thr; a.neg_lo = neg_iou_lo; a.neg_hi = neg_iou_hi; a.min_pos = min_pos_iou;
     a.match_low_quality = match_low_quality;
     a.gt_max = (unsigned*)workspace; a.gt_inds = gt_inds; a.max_overlaps = max_overlaps; a.labels = labels;
-    a.counts = counts;
+    a.counts = counts; a.out_stride = N;
     hipStream_t st = (hipStream_t)stream;
     const int ninit = B * (Gmax > 0 ? Gmax : 1) > 2 * B ? B * (Gmax > 0 ? Gmax : 1) : 2 * B;
     hipLaunchKernelGGL(assign_init_kernel, dim3((ninit + 255) / 256), dim3(256), 0, st, a.gt_max,
                        B * (Gmax > 0 ? Gmax : 1), counts, 2 * B);
     OADG_LAUNCH_CHECK();
     if (N == 0) return OADG_OK;
+    int bx = (N + AS_THREADS - 1) / AS_THREADS;
+    if (bx > 256) bx = 256;
+    if (Gmax > 0) {
+        hipLaunchKernelGGL(assign_gtmax_kernel, dim3(bx, B), dim3(AS_THREADS), 0, st, a);
+        OADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(assign_kernel, dim3(bx, B), dim3(AS_THREADS), 0, st, a);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+extern "C" int oadg_roi_assign_add_gt(const oadg_roi_assign_image* images_host, int B, int N, int Gmax, float pos_iou_thr,
+                                      float neg_iou_lo, float neg_iou_hi, float min_pos_iou, int match_low_quality,
+                                      float* boxes_full, int64_t* gt_inds_full, int64_t* labels_full, float* max_ov_full,
+                                      unsigned char* valid, float* gts_pad, int64_t* gl_pad, int* gt_counts,
+                                      void* workspace, size_t workspace_bytes, int* counts, void* stream) {
+    if (!images_host || B < 1 || B > OADG_ROI_ASSIGN_MAX_IMAGES || N < 1 || Gmax < 0 || Gmax > AS_MAXG || !boxes_full ||
+        !gt_inds_full || !labels_full || !max_ov_full || !valid || !gt_counts || !workspace || !counts ||
+        (Gmax > 0 && (!gts_pad || !gl_pad)))
+        return OADG_EARG;
+    if (workspace_bytes < oadg_max_iou_assign_workspace_bytes(B, Gmax)) return OADG_ESIZE;
+    RoiPrepArgs p;
+    std::memset(&p, 0, sizeof(p));
+    for (int i = 0; i < B; ++i) {
+        const oadg_roi_assign_image& im = images_host[i];
+        if (!im.proposals || im.stride < 4 || im.num_gts < 0 || im.num_gts > Gmax ||
+            (im.num_gts > 0 && (!im.gt_bboxes || !im.gt_labels)))
+            return OADG_EARG;
+        p.img[i] = im;
+    }
+    p.B = B; p.N = N; p.Gmax = Gmax; p.boxes_full = boxes_full; p.gt_inds_full = gt_inds_full;
+    p.labels_full = labels_full; p.max_ov_full = max_ov_full; p.valid = valid; p.gts_pad = gts_pad; p.gl_pad = gl_pad;
+    p.gt_counts = gt_counts; p.gt_max = (unsigned*)workspace; p.counts = counts;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = Gmax + N;
+    hipLaunchKernelGGL(roi_assign_prep_kernel, dim3((rows + 255) / 256, B), dim3(256), 0, st, p);
+    OADG_LAUNCH_CHECK();
+    AssignArgs a;
+    a.boxes = boxes_full + (size_t)Gmax * 4; a.box_stride = (long)rows * 4; a.valid = valid; a.gts = gts_pad;
+    a.gt_counts = gt_counts; a.gt_labels = gl_pad; a.B = B; a.N = N; a.Gmax = Gmax;
+    a.pos_thr = pos_iou_thr; a.neg_lo = neg_iou_lo; a.neg_hi = neg_iou_hi; a.min_pos = min_pos_iou;
+    a.match_low_quality = match_low_quality; a.gt_max = (unsigned*)workspace;
+    a.gt_inds = gt_inds_full + Gmax; a.max_overlaps = max_ov_full + Gmax; a.labels = labels_full + Gmax;
+    a.counts = counts; a.out_stride = rows;
     int bx = (N + AS_THREADS - 1) / AS_THREADS;
     if (bx > 256) bx = 256;
     if (Gmax > 0) {

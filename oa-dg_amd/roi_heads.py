@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import hip_ops
 from .core import bbox2roi, multi_apply
-from .core.bbox import _pinned_to, sample_many, sample_many_begin
+from .core.bbox import _pinned_to, roi_assign_sample_begin, sample_many, sample_many_begin
 from .layers import normal_init, xavier_init
 from .losses import accuracy
 from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_bbox_coder, build_head,
@@ -450,6 +450,10 @@ class StandardRoIHead(BaseRoIHead):
         if all(g is None for g in gt_bboxes_ignore[:n]) and hasattr(self.bbox_sampler, 'random_choice') and \
                 hasattr(self.bbox_assigner, 'assign_masked'):
             props = proposal_list[:n]
+            if all(l is not None for l in gt_labels[:n]):
+                pend = roi_assign_sample_begin(self.bbox_assigner, self.bbox_sampler, props, gt_bboxes[:n], gt_labels[:n])
+                if pend is not None:          # assignment + gts added as proposals: three launches for the batch
+                    return pend if defer else pend.finish()
             valids = [p[:, 4] >= 0 if p.size(1) == 5 else None for p in props]
             out = self.bbox_assigner.assign_many(props, valids, gt_bboxes[:n], gt_labels[:n]) \
                 if hasattr(self.bbox_assigner, 'assign_many') else None

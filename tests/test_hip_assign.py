@@ -168,3 +168,57 @@ def test_fused_roi_targets_equal_tensor_path(dev, pos_weight):
         assert torch.equal(a, b), name
     # more box lists than the launch arguments hold: the caller is told to take the tensor path
     assert head.rois_and_targets(results * 5, cfg) is None
+
+
+@pytest.mark.parametrize('match_low_quality', [False, True])
+def test_fused_roi_assign_add_gt_equals_tensor_path(dev, match_low_quality):
+    """oadg_roi_assign_add_gt (assignment of the proposals + gts added as proposals, three launches for the batch) against
+    assign_many + sample_many_begin (the per-image concatenations of base_sampler.py:38-78 / assign_result.add_gt_): the
+    same boxes / gt_inds / labels / overlaps per image, the same candidate counts, and - with the same CPU generator state -
+    the same sampled indices and pos_is_gt flags.  Images with many, few and no gts; padding rows (score -1)."""
+    import numpy as np
+    from oadg_amd.core import bbox as B
+    gen = torch.Generator(device=dev).manual_seed(3)
+    rs = np.random.RandomState(5)
+    asg = B.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=match_low_quality)
+    smp = B.RandomSampler(num=128, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    props, gts, labels = [], [], []
+    for n_gt in (12, 3, 0, 40):
+        g = _boxes(gen, n_gt, dev, lo=16., hi=180.)
+        p = _boxes(gen, 300, dev, lo=8., hi=220.)
+        if n_gt:
+            jit = (torch.rand(60, 4, generator=gen, device=dev) - 0.5) * 8
+            p[:60] = g[torch.arange(60, device=dev) % n_gt] + jit
+        score = torch.rand(300, 1, generator=gen, device=dev)
+        score[280:] = -1.
+        props.append(torch.cat([p, score], 1))
+        gts.append(g)
+        labels.append(torch.tensor(rs.randint(0, 8, n_gt), device=dev, dtype=torch.long))
+    out = {}
+    for mode in ('tensor', 'fused'):
+        torch.manual_seed(2)
+        if mode == 'fused':
+            pend = B.roi_assign_sample_begin(asg, smp, props, gts, labels)
+            assert pend is not None
+        else:
+            valids = [p[:, 4] >= 0 for p in props]
+            ars, counts = asg.assign_many(props, valids, gts, labels)
+            pend = B.sample_many_begin(smp, ars, props, gts, labels, counts=counts)
+        pre = [(p[0].gt_inds.clone(), p[0].labels.clone(), p[0].max_overlaps.clone(), p[1].clone(), p[0].num_gts)
+               for p in pend.prepared]
+        res = pend.finish()
+        out[mode] = (pre, [(r.pos_inds.clone(), r.neg_inds.clone(), r.pos_is_gt.clone(), r.bboxes.clone(),
+                            r.pos_gt_labels.clone(), r.pos_assigned_gt_inds.clone()) for r in res],
+                     torch.rand(1).item())
+    a, b = out['tensor'], out['fused']
+    assert a[2] == b[2]                                  # the CPU generator was consumed identically
+    for i, (x, y) in enumerate(zip(a[0], b[0])):
+        assert x[4] == y[4]
+        for u, v, name in zip(x[:4], y[:4], ('gt_inds', 'labels', 'max_overlaps', 'bboxes')):
+            assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v), (i, name)
+    assert sum(int(r[0].numel()) for r in b[1]) > 0
+    for i, (x, y) in enumerate(zip(a[1], b[1])):
+        for u, v, name in zip(x, y, ('pos_inds', 'neg_inds', 'pos_is_gt', 'bboxes', 'pos_gt_labels', 'pos_assigned_gt_inds')):
+            assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v), (i, name)
+    # proposal lists of different lengths are outside the kernels' domain: the caller is told to loop
+    assert B.roi_assign_sample_begin(asg, smp, [props[0], props[1][:200]], gts[:2], labels[:2]) is None
