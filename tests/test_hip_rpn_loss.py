@@ -53,7 +53,7 @@ def _run(dev, fused, lam, seed=0, n_img=2, H=192, W=320):
     finally:
         hip_conv.enable(False)
         AnchorHead.FUSED_LOSS = True
-    return (float(lc), float(lb), [f.grad.float().clone() for f in feats],
+    return (float(lc.detach()), float(lb.detach()), [f.grad.float().clone() for f in feats],
             {n: p.grad.float().clone() for n, p in head.named_parameters()}, len(losses['loss_rpn_cls']))
 
 
