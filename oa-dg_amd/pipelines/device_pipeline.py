@@ -96,11 +96,17 @@ class Compose:
 class DevicePipeline:
     """Batched device execution of [OAMix,] Normalize, Pad, DefaultFormatBundle, Collect."""
 
-    def __init__(self, pipeline_cfg, dtype=torch.float32, one_scale_per_batch=False):
+    def __init__(self, pipeline_cfg, dtype=torch.float32, one_scale_per_batch=False, oamix_workers=None):
         """``one_scale_per_batch``: a multi-scale Resize draws its scale once per batch instead of once per sample - an
         opt-in shortcut (one tensor shape per step).  The default follows the reference: one draw per sample
         (transforms.py:177-243), differently sized samples padded into one batch tensor like mmcv's collate does."""
         self.one_scale_per_batch = one_scale_per_batch
+        # OA-Mix of the images of a batch on several helper threads, each with its own HIP stream, numpy stream and
+        # scratch buffers (the analogue of the reference's ``workers_per_gpu`` DataLoader processes, each of which
+        # augments whole samples with a private random stream): see _oamix_parallel.  1 = in the calling thread.
+        self.oamix_workers = max(1, int(oamix_workers if oamix_workers is not None
+                                        else os.environ.get('OADG_OAMIX_WORKERS', '1')))
+        self._helpers = None
         ts = Compose(pipeline_cfg).transforms
         # test_robustness.py:269-277 inserts Corrupt right after the image loading step, before MultiScaleFlipAug
         self.corrupt = next((t for t in ts if isinstance(t, Corrupt)), None)
@@ -287,18 +293,75 @@ class DevicePipeline:
             states = [_ImageState(imgs_u8[i].contiguous(), gt_bboxes[i], om.spatial_ratio, om.sigma_ratio)
                       for i in range(N)]                  # (each with its own H x W)
             img2 = both[N:]
-            ml, oa = [], []
-            for i, st in enumerate(states):
-                om._history = {}
-                view = ctypes.c_void_p(img2.data_ptr() + i * img2.stride(0) * img2.element_size())
-                om.oamix(st, out_u8=None, out_norm=_PtrView(view, self.dtype), norm=na, pad_shape=(Hp, Wp))
-                ml.append(torch.from_numpy(np.asarray(om._history['random_box_list'])))
-                oa.append(torch.from_numpy(np.stack(om._history['oa_random_box_list'], axis=0)))
+            views = [ctypes.c_void_p(img2.data_ptr() + i * img2.stride(0) * img2.element_size()) for i in range(N)]
+            if self.oamix_workers > 1 and N > 1:
+                ml, oa = self._oamix_parallel(states, views, na, (Hp, Wp))
+            else:
+                ml, oa = [], []
+                for i, st in enumerate(states):
+                    om._history = {}
+                    om.oamix(st, out_u8=None, out_norm=_PtrView(views[i], self.dtype), norm=na, pad_shape=(Hp, Wp))
+                    ml.append(torch.from_numpy(np.asarray(om._history['random_box_list'])))
+                    oa.append(torch.from_numpy(np.stack(om._history['oa_random_box_list'], axis=0)))
             out['img2'] = img2
             out['gt_bboxes2'] = [b.clone() for b in out['gt_bboxes']]
             out['multilevel_boxes'] = ml
             out['oamix_boxes'] = oa
         return {k: v for k, v in out.items() if k in self.keys or k == 'img_metas'}
+
+
+def _oamix_parallel(self, states, views, na, pad_shape):
+    """OA-Mix of the batch's images on ``oamix_workers`` helper threads.  Helper k owns a HIP stream, an OAMix clone with
+    its own scratch buffers and a ``RandomState`` seeded from the caller's stream when the helpers are created; it takes
+    the images i = k (mod workers), in order, after an event recorded behind the (already enqueued) image states, and
+    the caller's stream waits for every helper's event before the batch is handed on.  The host side of a
+    ``bboxes_only_*`` op is mostly two C calls (plan + level launches) that run without the interpreter lock, so the
+    helpers overlap: BASELINE configs[4] (4096 boxes per image) is host-bound at one worker.  Draw-for-draw
+    reproducibility against a single numpy stream holds for one worker only - as with DataLoader workers, each helper's
+    stream is private."""
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+    from .oa_mix import rng, use_random_state
+    dev = states[0].img.device
+    K = min(self.oamix_workers, len(states))
+    if self._helpers is None or len(self._helpers) < K:
+        self._helpers = []
+        for k in range(self.oamix_workers):
+            om = copy.copy(self.oamix)
+            om._bufs, om._history = {}, {}
+            seed = int(rng.randint(0, 2 ** 31 - 1))
+
+            def init(seed=seed):
+                torch.cuda.set_device(dev)
+                use_random_state(np.random.RandomState(seed))
+            self._helpers.append(dict(om=om, stream=torch.cuda.Stream(device=dev),
+                                      pool=ThreadPoolExecutor(1, thread_name_prefix=f'oadg-oamix-{k}', initializer=init)))
+    cur = torch.cuda.current_stream()
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    results = [None] * len(states)
+
+    def task(k):
+        h = self._helpers[k]
+        om = h['om']
+        om.stats = self.oamix.stats
+        with torch.cuda.stream(h['stream']):
+            h['stream'].wait_event(ready)
+            for i in range(k, len(states), K):
+                om._history = {}
+                om.oamix(states[i], out_u8=None, out_norm=_PtrView(views[i], self.dtype), norm=na, pad_shape=pad_shape)
+                results[i] = (torch.from_numpy(np.asarray(om._history['random_box_list'])),
+                              torch.from_numpy(np.stack(om._history['oa_random_box_list'], axis=0)))
+            ev = torch.cuda.Event()
+            ev.record()
+        return ev
+    futs = [self._helpers[k]['pool'].submit(task, k) for k in range(K)]
+    for f in futs:
+        cur.wait_event(f.result())
+    return [r[0] for r in results], [r[1] for r in results]
+
+
+DevicePipeline._oamix_parallel = _oamix_parallel
 
 
 class _PrefetchedFuture:

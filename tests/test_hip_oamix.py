@@ -243,3 +243,45 @@ def test_bbox_chain_rect_areas_not_multiple_of_4(dev, H, W):
         if fg and any(abs(s - 10) < 0.2 for s in fg[0] if s >= 0):
             continue
         assert np.array_equal(a, ref['img2']), seed
+
+
+def test_oamix_helper_threads_equal_independent_sequential_workers(dev):
+    """DevicePipeline(oamix_workers=2): helper k augments the images k, k + 2, ... on its own HIP stream with its own numpy
+    stream (seeded from the caller's stream) - byte for byte what a single-threaded pipeline produces for those images
+    with that RandomState installed, like independent DataLoader workers; the batch is complete when the call returns
+    its stream's work (both views of every image, boxes lists in image order)."""
+    import os
+    from oadg_amd import Config
+    from oadg_amd.pipelines import DevicePipeline
+    from oadg_amd.pipelines.oa_mix import use_random_state
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
+    cases = [_case(20 + i, 256, 384, 6 + i, small=True) for i in range(5)]
+    imgs = torch.from_numpy(np.stack([c[0] for c in cases])).to(dev)
+    gts = [c[1] for c in cases]
+    labels = [np.zeros(len(g), np.int64) for g in gts]
+    np.random.seed(5)
+    par = DevicePipeline(cfg.data.train.pipeline, dtype=torch.float32, oamix_workers=2)
+    out = par(imgs, gts, labels)
+    torch.cuda.synchronize()
+    np.random.seed(5)
+    seeds = [int(np.random.randint(0, 2 ** 31 - 1)) for _ in range(2)]
+    try:
+        for k in range(2):
+            idx = list(range(k, 5, 2))
+            seq = DevicePipeline(cfg.data.train.pipeline, dtype=torch.float32)
+            use_random_state(np.random.RandomState(seeds[k]))
+            ref = seq(imgs[idx], [gts[i] for i in idx], [labels[i] for i in idx])
+            torch.cuda.synchronize()
+            for j, i in enumerate(idx):
+                assert torch.equal(out['img2'][i], ref['img2'][j]), i
+                assert torch.equal(out['img'][i], ref['img'][j]), i
+                assert np.array_equal(out['oamix_boxes'][i].numpy(), ref['oamix_boxes'][j].numpy())
+                assert np.array_equal(out['multilevel_boxes'][i].numpy(), ref['multilevel_boxes'][j].numpy())
+    finally:
+        use_random_state(None)
+    # a second batch through the same helpers (their streams continue): still one result per image, finite
+    out2 = par(imgs, gts, labels)
+    torch.cuda.synchronize()
+    assert out2['img2'].shape == out['img2'].shape and bool(torch.isfinite(out2['img2']).all())
+    assert not torch.equal(out2['img2'], out['img2'])

@@ -37,8 +37,11 @@ def bench_pipeline(name, H, W, n_boxes, box_size, batch, iters, version='augmix'
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
     imgs, boxes, labels = ds.batch(range(batch))
     res = {}
-    for mode in ('batched', 'per_box'):     # two launches per dependency level (host side in one C call) / per box
-        oa_mix.BATCH_BOXES = mode == 'batched'
+    modes = ('batched', 'per_box', 'workers4') if batch >= 4 else ('batched', 'per_box')
+    for mode in modes:  # two launches per dependency level (host side in one C call) / per box / 4 helper threads
+        oa_mix.BATCH_BOXES = mode != 'per_box'
+        if mode == 'workers4':      # the images of a batch on four helper threads + streams (DevicePipeline._oamix_parallel)
+            pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16, oamix_workers=4)
         np.random.seed(0)
         pipe(imgs, boxes, labels)                       # warm-up (buffers, first-touch)
         torch.cuda.synchronize()
