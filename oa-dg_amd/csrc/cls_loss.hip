@@ -531,7 +531,7 @@ int oadg_rpn_loss_fwd(const oadg_rpn_loss_level* levels, int n_levels, int B, in
     if (workspace_bytes < oadg_rpn_loss_workspace_bytes()) return OADG_ESIZE;
     hipStream_t st = (hipStream_t)stream;
     const int g = grid_for((long)(B / 2) * lv.pixels, 256 * 2);
-    if (rpn_loss_fast3(lv, A, dtype))
+    if (rpn_loss_fast3(lv, A, dtype) && ((uintptr_t)bbox_targets & 15) == 0 && ((uintptr_t)bbox_weights & 15) == 0)
         hipLaunchKernelGGL(rpn_loss_fwd_kernel<3>, dim3(g), dim3(256), 0, st, lv, B, A, At, dtype, labels, label_weights,
                            bbox_targets, bbox_weights, (double*)workspace);
     else
