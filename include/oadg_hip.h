@@ -507,6 +507,25 @@ int oadg_sgd_step_multi(const oadg_sgd_tensor* table_dev, int n, long long total
  * C % 64 == 0, P <= 256, O <= 65535. */
 int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, int P, int mode, void* stream);
 
+/* RoI head: the regression term of BBoxHead.loss and the logged accuracy in one forward and one backward launch
+ *   serves BBoxHead.loss   mmdet/models/roi_heads/bbox_heads/bbox_head.py:397-460 (pos_inds = labels in [0, C),
+ *          bbox_pred.view(K, -1, 4)[pos, labels[pos]], loss_bbox(pos_pred, targets[pos], weights[pos], avg_factor=K)),
+ *          L1Loss / SmoothL1Loss (mmdet/models/losses/smooth_l1_loss.py) and the fork's L1LossPlus / SmoothL1LossPlus
+ *          (losses/oadg/smooth_l1_loss_plus.py:350-552: the leading chunk of the positives = view 1), accuracy()
+ *          mmdet/models/losses/accuracy.py (top-1, percent)
+ * bbox_pred [K][n_reg] (n_reg = 4 * num_classes, or 4: class-agnostic), cls_score [K][n_cls] (NULL: no accuracy), dtypes
+ * 0 = fp32 / 1 = bf16; labels [K] int64; bbox_targets / bbox_weights [K][4] fp32.  Rows r < reg_limit with a label in
+ * [0, num_classes) take part in the box loss; beta = 0: L1, > 0: SmoothL1.  out2 = {loss_weight * sum / avg_factor,
+ * 100 * #(argmax == label) / K}.  The backward writes grad_pred [K][n_reg] in bbox_pred's dtype (zeros elsewhere);
+ * grad_out: the loss's incoming gradient, one float on the device. */
+int oadg_roi_reg_acc_fwd(const void* bbox_pred, int pred_dtype, const void* cls_score, int cls_dtype, const int64_t* labels,
+                         const float* bbox_targets, const float* bbox_weights, int K, int num_classes, int n_reg,
+                         int n_cls, int reg_limit, float beta, float avg_factor, float loss_weight, float* out2,
+                         void* stream);
+int oadg_roi_reg_bwd(const void* bbox_pred, int pred_dtype, const int64_t* labels, const float* bbox_targets,
+                     const float* bbox_weights, int K, int num_classes, int n_reg, int reg_limit, float beta,
+                     float avg_factor, float loss_weight, const float* grad_out, void* grad_pred, void* stream);
+
 /* RoI head: MaxIoUAssigner over the proposals of every image + "add the gts as proposals" in three launches
  *   serves StandardRoIHead.forward_train's per-image loop   mmdet/models/roi_heads/standard_roi_head.py:88-101
  *          (bbox_assigner.assign, max_iou_assigner.py:61-213) and the head of BaseSampler.sample

@@ -456,6 +456,89 @@ int grid_for(long items, int per_block) {
     return (int)g;
 }
 
+
+// ================================================================================================ RoI head: box loss + accuracy
+// BBoxHead.loss's regression term and its logged accuracy (mmdet/models/roi_heads/bbox_heads/bbox_head.py:397-460,
+// mmdet/models/losses/accuracy.py) in one forward and one backward launch.  The reference gathers the positive rows
+// (pos_inds = labels in [0, C)), picks each row's 4 deltas of ITS class (bbox_pred.view(K, -1, 4)[pos, labels[pos]]),
+// gathers targets and weights likewise and runs L1 / SmoothL1 (the fork's ...LossPlus: on the leading chunk of the
+// positives = view 1 - `reg_limit` = one past the last row that takes part): ~17 launches forward, ~28 backward (index
+// put with a sort).  Here: thread r owns row r; the loss is accumulated in fp64 in a fixed order (deterministic), the
+// backward writes the whole [K, 4 C] gradient (zeros + the positives' 4 entries) in bbox_pred's dtype.
+__device__ __forceinline__ float ld_any(const void* p, long i, int dtype) {
+    return dtype == 0 ? reinterpret_cast<const float*>(p)[i] : bf16_to_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+}
+
+__global__ __launch_bounds__(1024) void roi_reg_acc_fwd_kernel(const void* __restrict__ bbox_pred, int pred_dtype,
+                                                               const void* __restrict__ cls, int cls_dtype,
+                                                               const int64_t* __restrict__ labels,
+                                                               const float* __restrict__ targets,
+                                                               const float* __restrict__ weights, int K, int C, int n_reg,
+                                                               int n_cls, int reg_limit, float beta, float avg_factor,
+                                                               float loss_weight, float* __restrict__ out) {
+    __shared__ double red[16];
+    double sum = 0.0, correct = 0.0;
+    for (int r = threadIdx.x; r < K; r += blockDim.x) {
+        const int64_t l = labels[r];
+        if (cls) {                                     // top-1 of the row (first maximum), compared with the label
+            float best = ld_any(cls, (long)r * n_cls, cls_dtype);
+            int arg = 0;
+            for (int c = 1; c < n_cls; ++c) {
+                const float v = ld_any(cls, (long)r * n_cls + c, cls_dtype);
+                if (v > best) { best = v; arg = c; }
+            }
+            correct += (arg == (int)l) ? 1.0 : 0.0;
+        }
+        if (r < reg_limit && l >= 0 && l < C) {
+            const long col = n_reg == 4 ? 0 : (long)l * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float pv = ld_any(bbox_pred, (long)r * n_reg + col + c, pred_dtype);
+                const float d = fabsf(pv - targets[(long)r * 4 + c]);
+                const float e = beta > 0.f ? (d < beta ? 0.5f * d * d / beta : d - 0.5f * beta) : d;
+                sum += (double)(e * weights[(long)r * 4 + c]);
+            }
+        }
+    }
+    const double s = block_sum_d(sum, red), k = block_sum_d(correct, red);
+    if (threadIdx.x == 0) {
+        out[0] = loss_weight * ((float)s / avg_factor);
+        out[1] = (float)k * (100.0f / (float)(K > 0 ? K : 1));
+    }
+}
+
+__global__ __launch_bounds__(256) void roi_reg_bwd_kernel(const void* __restrict__ bbox_pred, int pred_dtype,
+                                                          const int64_t* __restrict__ labels,
+                                                          const float* __restrict__ targets,
+                                                          const float* __restrict__ weights, int K, int C, int n_reg,
+                                                          int reg_limit, float beta, float avg_factor, float loss_weight,
+                                                          const float* __restrict__ gout, void* __restrict__ grad) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;            // one 4-element group of the [K, n_reg] gradient
+    const int groups = n_reg / 4;
+    if (i >= (long)K * groups) return;
+    const int r = (int)(i / groups), gcol = (int)(i - (long)r * groups);
+    const int64_t l = labels[r];
+    float g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < reg_limit && l >= 0 && l < C && (n_reg == 4 || gcol == (int)l)) {
+        const float k = (gout[0] * loss_weight) / avg_factor;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = ld_any(bbox_pred, (long)r * n_reg + gcol * 4 + c, pred_dtype) - targets[(long)r * 4 + c];
+            const float ad = fabsf(d);
+            const float de = (beta > 0.f && ad < beta) ? d / beta : (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.f));
+            g[c] = k * weights[(long)r * 4 + c] * de;
+        }
+    }
+    if (pred_dtype == 0) {
+        reinterpret_cast<f32x4*>(grad)[i] = f32x4{g[0], g[1], g[2], g[3]};
+    } else {
+        unsigned short* o = reinterpret_cast<unsigned short*>(grad) + i * 4;
+        const unsigned lo = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
+        const unsigned hi = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
+        reinterpret_cast<uint2*>(o)[0] = make_uint2(lo, hi);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -574,6 +657,36 @@ int oadg_rpn_loss_bwd(const oadg_rpn_loss_level* levels, int n_levels, int B, in
                            (hipStream_t)stream, lv, B, A, At, dtype, labels, label_weights, bbox_targets, bbox_weights,
                            w_cls / avg_factor, lambda_jsd / avg_factor, w_box / avg_factor, grad_cls, grad_box);
     }
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_roi_reg_acc_fwd(const void* bbox_pred, int pred_dtype, const void* cls_score, int cls_dtype, const int64_t* labels,
+                         const float* bbox_targets, const float* bbox_weights, int K, int num_classes, int n_reg,
+                         int n_cls, int reg_limit, float beta, float avg_factor, float loss_weight, float* out2,
+                         void* stream) {
+    if (!bbox_pred || !labels || !bbox_targets || !bbox_weights || !out2 || K < 0 || num_classes < 1 ||
+        (n_reg != 4 && n_reg != 4 * num_classes) || (cls_score && n_cls < 1) || !(avg_factor > 0.f) || beta < 0.f ||
+        (pred_dtype != 0 && pred_dtype != 1) || (cls_dtype != 0 && cls_dtype != 1))
+        return OADG_EARG;
+    hipLaunchKernelGGL(roi_reg_acc_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, bbox_pred, pred_dtype, cls_score,
+                       cls_dtype, labels, bbox_targets, bbox_weights, K, num_classes, n_reg, n_cls, reg_limit, beta,
+                       avg_factor, loss_weight, out2);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_roi_reg_bwd(const void* bbox_pred, int pred_dtype, const int64_t* labels, const float* bbox_targets,
+                     const float* bbox_weights, int K, int num_classes, int n_reg, int reg_limit, float beta,
+                     float avg_factor, float loss_weight, const float* grad_out, void* grad_pred, void* stream) {
+    if (!bbox_pred || !labels || !bbox_targets || !bbox_weights || !grad_out || !grad_pred || K < 0 || num_classes < 1 ||
+        (n_reg != 4 && n_reg != 4 * num_classes) || !(avg_factor > 0.f) || beta < 0.f || (pred_dtype != 0 && pred_dtype != 1))
+        return OADG_EARG;
+    const long total = (long)K * (n_reg / 4);
+    if (total == 0) return OADG_OK;
+    hipLaunchKernelGGL(roi_reg_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bbox_pred,
+                       pred_dtype, labels, bbox_targets, bbox_weights, K, num_classes, n_reg, reg_limit, beta, avg_factor,
+                       loss_weight, grad_out, grad_pred);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

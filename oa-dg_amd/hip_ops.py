@@ -190,6 +190,54 @@ def rpn_loss(ys, num_anchors, targets, avg_factor, w_cls, lambda_jsd, w_box):
     return _RpnLoss.apply(int(num_anchors), tuple(targets), avg_factor, w_cls, lambda_jsd, w_box, *ys)
 
 
+# --------------------------------------------------------------------------------------- RoI head: box loss + accuracy
+class _RoiRegAcc(torch.autograd.Function):
+    """(loss_bbox, acc) of BBoxHead.loss on the head's raw outputs (csrc/cls_loss.hip oadg_roi_reg_acc_fwd / _bwd): the
+    positives' class-specific deltas against their targets (L1 / SmoothL1, rows below ``reg_limit``) and the top-1
+    accuracy, one launch forward, one backward (the whole [K, 4 C] gradient in bbox_pred's dtype)."""
+
+    @staticmethod
+    def forward(ctx, bbox_pred, cls_score, labels, targets, weights, num_classes, reg_limit, beta, avg_factor, loss_weight):
+        require_cuda(bbox_pred, labels, targets, weights)
+        dts = {torch.float32: 0, torch.bfloat16: 1}
+        bp = bbox_pred.contiguous()
+        cs = cls_score.detach().contiguous() if cls_score is not None else None
+        K, n_reg = bp.shape
+        out = torch.empty(2, dtype=torch.float32, device=bp.device)
+        labels, targets, weights = labels.contiguous(), targets.float().contiguous(), weights.float().contiguous()
+        check(_lib.lib().oadg_roi_reg_acc_fwd(ptr(bp), dts[bp.dtype], ptr(cs), dts[cs.dtype] if cs is not None else 0,
+                                              ptr(labels), ptr(targets), ptr(weights), K, int(num_classes), n_reg,
+                                              cs.shape[1] if cs is not None else 0, int(reg_limit), float(beta),
+                                              float(avg_factor), float(loss_weight), ptr(out), stream_ptr()),
+              'oadg_roi_reg_acc_fwd')
+        ctx.save_for_backward(bp, labels, targets, weights)
+        ctx.cfg = (int(num_classes), int(reg_limit), float(beta), float(avg_factor), float(loss_weight), dts[bp.dtype])
+        loss, acc = out[0], out[1:2]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, g, _gacc):
+        bp, labels, targets, weights = ctx.saved_tensors
+        C, reg_limit, beta, avg, lw, dt = ctx.cfg
+        K, n_reg = bp.shape
+        grad = torch.empty_like(bp)
+        g = g.contiguous().float().view(1)
+        check(_lib.lib().oadg_roi_reg_bwd(ptr(bp), dt, ptr(labels), ptr(targets), ptr(weights), K, C, n_reg, reg_limit, beta,
+                                          avg, lw, ptr(g), ptr(grad), stream_ptr()), 'oadg_roi_reg_bwd')
+        return grad, None, None, None, None, None, None, None, None, None
+
+
+def roi_reg_acc(bbox_pred, cls_score, labels, bbox_targets, bbox_weights, num_classes, reg_limit, beta, avg_factor,
+                loss_weight):
+    """see :class:`_RoiRegAcc`; ``beta`` 0 = L1"""
+    return _RoiRegAcc.apply(bbox_pred, cls_score, labels, bbox_targets, bbox_weights, num_classes, reg_limit, beta,
+                            avg_factor, loss_weight)
+
+
+FUSED_ROI_LOSS = os.environ.get('OADG_FUSED_ROI_LOSS', '1') == '1'
+
+
 # --------------------------------------------------------------------------------------- FC weight on NHWC features
 class _FcWeightPermute(torch.autograd.Function):
     """W fp32 [O, C*P] (column c*P + p, the reference's NCHW flatten) -> bf16 [O, P*C] (column p*C + c, the order of

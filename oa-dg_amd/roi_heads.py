@@ -244,11 +244,20 @@ class BBoxHead(nn.Module):
 
     def _cls_reg_losses(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
                         avg_factor, reduction_override=None, pos_rows=None):
+        """``cls_score`` / ``bbox_pred`` as the head produced them (bf16 under autocast): the classification loss and the
+        tensor path cast to fp32 like the reference's ``loss`` does, the fused box loss reads them as they are."""
         losses = dict()
-        if cls_score is not None and cls_score.numel() > 0:
-            losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor,
+        cls_f = cls_score.float() if cls_score is not None else None
+        if cls_f is not None and cls_f.numel() > 0:
+            losses['loss_cls'] = self.loss_cls(cls_f, labels, label_weights, avg_factor=avg_factor,
                                                reduction_override=reduction_override)
-            losses['acc'] = accuracy(cls_score, labels)
+        fused = self._fused_reg_acc(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows)
+        if fused is not None:
+            losses['acc'], losses['loss_bbox'] = fused[1], fused[0]         # (the reference's key order: loss_cls, acc, loss_bbox)
+            return losses
+        if cls_f is not None and cls_f.numel() > 0:
+            losses['acc'] = accuracy(cls_f, labels)
+        bbox_pred = bbox_pred.float() if bbox_pred is not None else None
         if bbox_pred is not None and pos_rows is not None:
             # positives are the leading rows of every image block: their indices are known on the host
             if pos_rows.numel() > 0:
@@ -278,6 +287,28 @@ class BBoxHead(nn.Module):
                 losses['loss_bbox'] = bbox_pred[pos].sum()
         return losses
 
+    def _fused_reg_acc(self, cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows):
+        """(loss_bbox, acc) from one launch of csrc/cls_loss.hip (hip_ops.roi_reg_acc) - or None: the tensor path runs.
+        ``pos_rows`` (host tensor, ascending) tells which rows are positives without a device read; the fork's
+        ...LossPlus takes the leading chunk of them (view 1, smooth_l1_loss_plus.py: torch.chunk(pos_pred, num_views)[0])."""
+        from .losses import L1Loss, L1LossPlus, SmoothL1Loss, SmoothL1LossPlus
+        lb = self.loss_bbox
+        if not (hip_ops.FUSED_ROI_LOSS and pos_rows is not None and reduction_override is None and cls_score is not None
+                and bbox_pred is not None and bbox_pred.is_cuda and cls_score.numel() > 0 and bbox_pred.dim() == 2
+                and type(lb) in (L1Loss, L1LossPlus, SmoothL1Loss, SmoothL1LossPlus) and lb.reduction == 'mean'
+                and bbox_pred.dtype in (torch.float32, torch.bfloat16) and cls_score.dtype in (torch.float32, torch.bfloat16)
+                and labels.dtype == torch.long and bbox_pred.shape[1] == (4 if self.reg_class_agnostic else 4 * self.num_classes)):
+            return None
+        K, P = bbox_pred.shape[0], int(pos_rows.numel())
+        if isinstance(lb, (L1LossPlus, SmoothL1LossPlus)):
+            n1 = -(-P // lb.num_views)                          # rows of torch.chunk(pos_pred, num_views)[0]
+            reg_limit = int(pos_rows[n1 - 1]) + 1 if n1 > 0 else 0
+        else:
+            reg_limit = K
+        beta = float(getattr(lb, 'beta', 0.0))
+        return hip_ops.roi_reg_acc(bbox_pred, cls_score, labels, bbox_targets, bbox_weights, self.num_classes, reg_limit,
+                                   beta, float(max(bbox_targets.size(0), 1)), float(lb.loss_weight))
+
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
              reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):
         """bbox_head.py:397-...: avg_factor = #(label_weights > 0)."""
@@ -285,10 +316,8 @@ class BBoxHead(nn.Module):
         if cls_score is not None:
             avg = max(float(num_sampled), 1.) if num_sampled is not None else \
                 max(torch.sum(label_weights > 0).float().item(), 1.)
-        return self._cls_reg_losses(cls_score.float() if cls_score is not None else None,
-                                    bbox_pred.float() if bbox_pred is not None else None, labels,
-                                    label_weights, bbox_targets, bbox_weights, avg, reduction_override,
-                                    pos_rows=pos_rows)
+        return self._cls_reg_losses(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, avg,
+                                    reduction_override, pos_rows=pos_rows)
 
 
 class ConvFCBBoxHead(BBoxHead):
@@ -408,10 +437,8 @@ class Shared2FCContrastiveHead(ConvFCBBoxHead):
         if cls_score is not None:
             avg = max(float(num_sampled), 1.) if num_sampled is not None else \
                 max(torch.sum(label_weights > 0).float().item(), 1.)
-        losses = self._cls_reg_losses(cls_score.float() if cls_score is not None else None,
-                                      bbox_pred.float() if bbox_pred is not None else None, labels,
-                                      label_weights, bbox_targets, bbox_weights, avg, reduction_override,
-                                      pos_rows=pos_rows)
+        losses = self._cls_reg_losses(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, avg,
+                                      reduction_override, pos_rows=pos_rows)
         labels = labels.contiguous().view(-1, 1)
         if cont_feats is not None and cont_feats.numel() > 0:
             # The reference adds the key only when #foreground > min_samples (a host-side branch on device

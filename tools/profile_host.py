@@ -248,6 +248,20 @@ def main():
         print('ATen / library kernels >= 15 us on the main stream, per step:')
         for (sec, nm), (c, t) in sorted(big.items(), key=lambda kv: -kv[1][1])[:40]:
             print(f'  {c / 2:5.1f} x {t / 2e3:6.3f} ms  [{sec}]  {nm}')
+        if '--window' in sys.argv:      # the host-bound stretch: every main-stream kernel from the RoI targets to the first
+            # backward convolution of the LAST profiled step, in time order (gap before, duration, name)
+            starts = [i for i, m in enumerate(main) if 'roi_targets_kernel' in m[2]]
+            if starts:
+                i0 = starts[-1]
+                print('main-stream kernels from roi_targets_kernel on (gap before us, duration us, name):')
+                seen_bwd = 0
+                for i in range(i0 - 3, len(main)):
+                    gap = main[i][0] - main[i - 1][1]
+                    print(f'  {gap:7.1f} {main[i][1] - main[i][0]:7.1f}  {main[i][2][:110]}')
+                    if 'conv_wgrad' in main[i][2]:
+                        seen_bwd += 1
+                        if seen_bwd >= 3:
+                            break
         print('idle (gaps > 5 us) by the section that launched the kernel after the gap, ms per step:')
         for nm, g in sorted(per_sec.items(), key=lambda kv: -kv[1]):
             print(f'  {nm:28s} {g / 2e3:7.2f}')
