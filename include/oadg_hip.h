@@ -507,6 +507,17 @@ int oadg_sgd_step_multi(const oadg_sgd_tensor* table_dev, int n, long long total
  * C % 64 == 0, P <= 256, O <= 65535. */
 int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, int P, int mode, void* stream);
 
+/* BaseDetector._parse_losses for scalar loss values in one launch
+ *   serves mmdet/models/detectors/base.py:234-277: log_vars[name] = value.mean() or sum(v.mean() for v in list),
+ *          loss = sum of the variables whose name contains 'loss'
+ * values_host [n]: HOST array of device pointers to ONE float each; name_of_host [n]: the index of the variable each
+ * value belongs to (ascending; a per-level list has several entries); bit i of is_loss_mask: variable i is part of the
+ * total.  packed [n_names + 1] = the variables in order, then the total (also written to total_out [1] when not NULL).
+ * The sums are python's: 0 + v0 + v1 + ... */
+#define OADG_PARSE_LOSSES_MAX 32
+int oadg_parse_losses(const float* const* values_host, const int* name_of_host, int n, int n_names, unsigned is_loss_mask,
+                      float* packed, float* total_out, void* stream);
+
 /* RoI head: the regression term of BBoxHead.loss and the logged accuracy in one forward and one backward launch
  *   serves BBoxHead.loss   mmdet/models/roi_heads/bbox_heads/bbox_head.py:397-460 (pos_inds = labels in [0, C),
  *          bbox_pred.view(K, -1, 4)[pos, labels[pos]], loss_bbox(pos_pred, targets[pos], weights[pos], avg_factor=K)),

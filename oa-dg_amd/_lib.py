@@ -114,6 +114,7 @@ SIGNATURES = {
     'oadg_sgd_blocks': (ctypes.c_longlong, [ctypes.c_longlong]),
     'oadg_sgd_step_multi': (ci, [vp, ci, ctypes.c_longlong, cf, cf, cf, vp]),
     'oadg_fc_weight_permute': (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    'oadg_parse_losses': (ci, [vp, vp, ci, ci, ctypes.c_uint, vp, vp, vp]),
     'oadg_roi_reg_acc_fwd': (ci, [vp, ci, vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, cf, cf, cf, vp, vp]),
     'oadg_roi_reg_bwd': (ci, [vp, ci, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp]),
     'oadg_roi_assign_add_gt': (ci, [vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t,

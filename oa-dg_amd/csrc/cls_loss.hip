@@ -19,6 +19,7 @@
 // HBM-bound streaming kernels: one pass to reduce (per-block fp64 partials, fixed order => run-to-run
 // deterministic), one pass to write d(logits).  Algorithmic traffic RPN: 2 x (4 B logit) + 8 B label +
 // 4 B weight per pair forward, + 8 B of gradient backward.
+#include <cstring>
 #include "common.h"
 #include "../../include/oadg_hip.h"
 
@@ -539,6 +540,38 @@ __global__ __launch_bounds__(256) void roi_reg_bwd_kernel(const void* __restrict
     }
 }
 
+
+// ================================================================================================ _parse_losses
+// BaseDetector._parse_losses (mmdet/models/detectors/base.py:234-277) for scalar loss values: log_vars[name] = the sum of
+// its entries (a value or a per-level list, python's left-to-right float adds starting from 0), loss = the sum of the
+// variables whose name contains 'loss', in dictionary order; packed = [log_vars..., loss].  One thread: ~10 numbers.
+struct ParseLossArgs {
+    const float* v[OADG_PARSE_LOSSES_MAX];
+    int name_of[OADG_PARSE_LOSSES_MAX];
+    int n, n_names;
+    unsigned is_loss;          // bit i: name i takes part in the total
+};
+
+__global__ void parse_losses_kernel(const ParseLossArgs a, float* __restrict__ out, float* __restrict__ total_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    for (int name = 0; name < a.n_names; ++name) {
+        float s = 0.f;
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < OADG_PARSE_LOSSES_MAX; ++i)
+            if (i < a.n && a.name_of[i] == name) {
+                // a single tensor is its own mean; a list is python's sum(): 0 + v0 + v1 + ...
+                s = first ? (0.f + a.v[i][0]) : (s + a.v[i][0]);
+                first = false;
+            }
+        out[name] = s;
+        if ((a.is_loss >> name) & 1u) total = total + s;
+    }
+    out[a.n_names] = total;
+    if (total_out) total_out[0] = total;
+}
+
 }  // namespace
 
 extern "C" {
@@ -687,6 +720,23 @@ int oadg_roi_reg_bwd(const void* bbox_pred, int pred_dtype, const int64_t* label
     hipLaunchKernelGGL(roi_reg_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bbox_pred,
                        pred_dtype, labels, bbox_targets, bbox_weights, K, num_classes, n_reg, reg_limit, beta, avg_factor,
                        loss_weight, grad_out, grad_pred);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+int oadg_parse_losses(const float* const* values_host, const int* name_of_host, int n, int n_names, unsigned is_loss_mask,
+                      float* packed, float* total_out, void* stream) {
+    if (!values_host || !name_of_host || !packed || n < 1 || n > OADG_PARSE_LOSSES_MAX || n_names < 1 || n_names > 31)
+        return OADG_EARG;
+    ParseLossArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int i = 0; i < n; ++i) {
+        if (!values_host[i] || name_of_host[i] < 0 || name_of_host[i] >= n_names) return OADG_EARG;
+        a.v[i] = values_host[i];
+        a.name_of[i] = name_of_host[i];
+    }
+    a.n = n; a.n_names = n_names; a.is_loss = is_loss_mask;
+    hipLaunchKernelGGL(parse_losses_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, packed, total_out);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -112,18 +112,22 @@ class BaseDetector(nn.Module):
     def _parse_losses(self, losses):
         """base.py:234-277.  Same keys and values; the per-variable all-reduces + .item() of the reference
         become one packed all-reduce and one host read."""
-        log_vars = OrderedDict()
-        for name, value in losses.items():
-            if isinstance(value, torch.Tensor):
-                log_vars[name] = value.mean()
-            elif isinstance(value, list):
-                log_vars[name] = sum(v.mean() for v in value)
-            else:
-                raise TypeError(f'{name} is not a tensor or list of tensors')
-        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
-        log_vars['loss'] = loss
-        names = list(log_vars.keys())
-        packed = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
+        fused = self._parse_losses_fused(losses)
+        if fused is not None:
+            loss, packed, names = fused
+        else:
+            log_vars = OrderedDict()
+            for name, value in losses.items():
+                if isinstance(value, torch.Tensor):
+                    log_vars[name] = value.mean()
+                elif isinstance(value, list):
+                    log_vars[name] = sum(v.mean() for v in value)
+                else:
+                    raise TypeError(f'{name} is not a tensor or list of tensors')
+            loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+            log_vars['loss'] = loss
+            names = list(log_vars.keys())
+            packed = torch.stack([log_vars[k].detach().float().reshape(()) for k in names])
         distributed = dist.is_available() and dist.is_initialized() and not getattr(self, 'local_log_vars', False)
         if distributed:
             # base.py:258-265 checks that every rank logs the same variables; the count rides in the same
@@ -145,6 +149,31 @@ class BaseDetector(nn.Module):
                 self._check_log_count(count, expect, names)
             log_vars = OrderedDict(zip(names, packed.unbind(0)))
         return loss, log_vars
+
+    @staticmethod
+    def _parse_losses_fused(losses):
+        """(loss, packed log vector, names) from one launch (hip_ops.parse_losses) when every value is a one-element fp32
+        CUDA tensor (a mean of one element is the element; the sums are python's left-to-right adds) - else None"""
+        from . import hip_ops
+        if not hip_ops.FUSED_PARSE_LOSSES or 'loss' in losses:
+            return None
+        vals, name_of, names, mask = [], [], [], 0
+        for name, value in losses.items():
+            items = [value] if isinstance(value, torch.Tensor) else value
+            if not isinstance(items, list) or not items:
+                return None
+            for v in items:
+                if not (isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 and v.numel() == 1):
+                    return None
+                vals.append(v)
+                name_of.append(len(names))
+            if 'loss' in name:
+                mask |= 1 << len(names)
+            names.append(name)
+        if not vals or len(vals) > 32 or len(names) > 30:
+            return None
+        loss, packed = hip_ops.parse_losses(vals, name_of, len(names), mask)
+        return loss, packed, names + ['loss']
 
     def _check_log_count(self, count, expect, names):
         """Deferred form of the reference's cross-rank assertion: this step's all-reduced count is copied to a
