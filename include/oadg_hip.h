@@ -81,6 +81,10 @@ int oadg_roi_align_bwd(float* const* dfeats_host, const int* heights_host, const
  * in argsort(keys) order keeps the feature rows / gradient lines of neighbouring RoIs in L2. */
 int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float finest_scale, long long* keys,
                         void* stream);
+/* the same order without a sort call: order [K] = stable argsort of those keys (int32), range [levels * n_img + 1] = the
+ * first position in `order` of every (level, image) group - what oadg_roi_align_bwd_tiles takes; K <= 8192 */
+int oadg_roi_order(const float* rois, int K, int n_img, int levels, float finest_scale, int* order, int* range,
+                   void* stream);
 /* The bf16 backward organised by OUTPUT tiles (8 x 8 pixels of one image on one level per workgroup): every element of
  * the bf16 gradient maps dmaps[l] [N,H_l,W_l,C] is WRITTEN (no zero fill, no fp32 maps, no atomics, no cast pass) and the
  * summation order is fixed by `order` (deterministic).  order [K] = RoI indices sorted by the oadg_roi_order_keys keys,

@@ -68,6 +68,7 @@ SIGNATURES = {
     'oadg_roi_align_bwd': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, ci, cf,
                                 vp, ci, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_roi_order_keys': (ci, [vp, ci, ci, ci, cf, vp, vp]),
+    'oadg_roi_order': (ci, [vp, ci, ci, ci, cf, vp, vp, vp]),
     'oadg_roi_align_bwd_tiles': (ci, [POINTER(vp), POINTER(ci), POINTER(ci), POINTER(cf), ci, ci, ci, cf, vp, ci, ci, ci,
                                       ci, ci, vp, vp, vp, vp, vp]),
     'oadg_rpn_loss_workspace_bytes': (cs, []),

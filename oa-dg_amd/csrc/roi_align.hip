@@ -571,10 +571,8 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
 // sort key of a RoI for the processing order of the two kernels above: (pyramid level, image, 16-feature-pixel cell
 // of the RoI centre, row-major).  Proposals cluster around objects: workgroups that run together then read the same
 // feature rows and - backward - add into the same gradient lines while those are still in L2.
-__global__ void roi_order_key_kernel(const float* __restrict__ rois, int K, int n_img, int levels, float finest_scale,
-                                     long long* __restrict__ keys) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= K) return;
+__device__ __forceinline__ long long roi_order_key(const float* __restrict__ rois, int k, int n_img, int levels,
+                                                   float finest_scale) {
     const float* r = rois + (size_t)k * 5;
     const float w = fmaxf(r[3] - r[1], 0.f), h = fmaxf(r[4] - r[2], 0.f);
     float l = floorf(log2f(sqrtf(w * h) / finest_scale + 1e-6f));
@@ -586,7 +584,41 @@ __global__ void roi_order_key_kernel(const float* __restrict__ rois, int K, int 
     qy = qy < 0 ? 0 : (qy > 1023 ? 1023 : qy);
     int b = (int)r[0];
     b = b < 0 ? 0 : (b >= n_img ? n_img - 1 : b);
-    keys[k] = (((long long)lvl * n_img + b) * 1024 + qy) * 1024 + qx;
+    return (((long long)lvl * n_img + b) * 1024 + qy) * 1024 + qx;
+}
+
+__global__ void roi_order_key_kernel(const float* __restrict__ rois, int K, int n_img, int levels, float finest_scale,
+                                     long long* __restrict__ keys) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) keys[k] = roi_order_key(rois, k, n_img, levels, finest_scale);
+}
+
+// argsort of the keys (ties by index: a stable sort) + the first position of every (level, image) group in ONE launch,
+// by counting: every workgroup holds all K composite keys (key << 16 | index) in LDS and thread i counts the smaller ones
+// - K reads of one LDS address per step (a broadcast), K <= 8192.  torch: key kernel + sort (6 rocPRIM launches) +
+// int cast + searchsorted, in the stretch of the step where the device waits for the host.
+__global__ __launch_bounds__(256) void roi_order_rank_kernel(const float* __restrict__ rois, int K, int n_img, int levels,
+                                                             float finest_scale, int* __restrict__ order,
+                                                             int* __restrict__ range) {
+    extern __shared__ unsigned long long rk_keys[];
+    for (int j = threadIdx.x; j < K; j += 256)
+        rk_keys[j] = ((unsigned long long)roi_order_key(rois, j, n_img, levels, finest_scale) << 16) | (unsigned)j;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K) {
+        const unsigned long long mine = rk_keys[i];
+        int rank = 0;
+        for (int j = 0; j < K; ++j) rank += rk_keys[j] < mine ? 1 : 0;
+        order[rank] = i;
+    }
+    const int groups = levels * n_img;
+    if (blockIdx.x == gridDim.x - 1)                        // (the last workgroup is the least loaded one)
+        for (int g = threadIdx.x; g <= groups; g += 256) {
+            const unsigned long long bound = (unsigned long long)g << 36;       // group g's smallest key: g << 20, then << 16
+            int cnt = 0;
+            for (int j = 0; j < K; ++j) cnt += rk_keys[j] < bound ? 1 : 0;
+            range[g] = cnt;
+        }
 }
 
 int fill_pyramid(Pyramid& p, const void* const* feats, float* const* dfeats, const int* heights,
@@ -636,6 +668,17 @@ int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float f
     if (K == 0) return OADG_OK;
     hipLaunchKernelGGL(roi_order_key_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, rois, K, n_img,
                        levels, finest_scale, keys);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+// order [K] = argsort(keys) (stable) as int32 and range [levels * n_img + 1] = the first position in `order` of every
+// (level, image) group, in one launch; K <= 8192 (OADG_EARG above: sort the keys of oadg_roi_order_keys instead)
+int oadg_roi_order(const float* rois, int K, int n_img, int levels, float finest_scale, int* order, int* range,
+                   void* stream) {
+    if (!rois || !order || !range || K < 1 || K > 8192 || n_img < 1 || levels < 1 || levels > OADG_MAX_LEVELS) return OADG_EARG;
+    hipLaunchKernelGGL(roi_order_rank_kernel, dim3((K + 255) / 256), dim3(256), (size_t)K * sizeof(unsigned long long),
+                       (hipStream_t)stream, rois, K, n_img, levels, finest_scale, order, range);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -330,6 +330,7 @@ ROI_LOCALITY_ORDER = os.environ.get('OADG_ROI_ORDER', '1') == '1'
 # fp32 atomic scatter (OADG_ROI_BWD_TILES=0; fp32 atomics retire at ~1.2 TB/s of 4-byte adds on this chip whatever their
 # scope - tools/probe/atomic_lab.hip - so 236 M of them cannot take less than 0.8 ms) stays for fp32 maps and PH, PW > 8.
 BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '1') == '1'
+ROI_ORDER_ONE_LAUNCH = os.environ.get('OADG_ROI_ORDER_ONE_LAUNCH', '1') == '1'
 _GROUP_KEYS = {}
 
 
@@ -365,10 +366,22 @@ class _RoIAlignFPN(torch.autograd.Function):
         if ROI_LOCALITY_ORDER and (K >= 512 or tiles):
             # process the RoIs level by level, image by image, cell by cell (the result does not depend on the order):
             # neighbouring RoIs share feature rows and - backward - gradient lines while those are still in L2
-            keys = torch.empty((K,), dtype=torch.int64, device=rois.device)
-            check(L.oadg_roi_order_keys(ptr(rois), K, N, len(feats), float(finest_scale), ptr(keys), stream_ptr()),
-                  'oadg_roi_order_keys')
-            if tiles:       # the tile-gather backward walks the RoIs of one (level, image) group: group boundaries
+            if K <= 8192 and ROI_ORDER_ONE_LAUNCH:
+                # stable argsort of the keys + the (level, image) group boundaries by counting, one launch (csrc oadg_roi_order)
+                order = torch.empty((K,), dtype=torch.int32, device=rois.device)
+                rng_ = torch.empty((len(feats) * N + 1,), dtype=torch.int32, device=rois.device)
+                check(L.oadg_roi_order(ptr(rois), K, N, len(feats), float(finest_scale), ptr(order), ptr(rng_),
+                                       stream_ptr()), 'oadg_roi_order')
+                if not tiles:
+                    rng_ = None
+                keys = None
+            else:
+                keys = torch.empty((K,), dtype=torch.int64, device=rois.device)
+                check(L.oadg_roi_order_keys(ptr(rois), K, N, len(feats), float(finest_scale), ptr(keys), stream_ptr()),
+                      'oadg_roi_order_keys')
+            if keys is None:
+                pass
+            elif tiles:     # the tile-gather backward walks the RoIs of one (level, image) group: group boundaries
                 skeys, order = keys.sort()
                 order = order.int()
                 rng_ = torch.searchsorted(skeys, _group_keys(len(feats), N, rois.device), out_int32=True)

@@ -208,3 +208,28 @@ def test_bbox_head_on_nhwc_features_matches_the_flatten_path(dev):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item() + 1e-6
         assert (a - b).abs().mean().item() <= 4e-3 * b.abs().mean().item() + 1e-7
+
+
+@pytest.mark.parametrize('K', [1, 300, 4198, 8192])
+def test_roi_order_one_launch_equals_stable_sort_of_the_keys(dev, K):
+    """oadg_roi_order: order = stable argsort of oadg_roi_order_keys' keys, range = first position of every (level, image)
+    group (searchsorted of the group's smallest key) - exact; many RoIs share a cell, so ties are exercised."""
+    import ctypes
+    from oadg_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(K)
+    n_img, levels = 8, 4
+    wh = torch.rand(K, 2, device=dev, generator=g) ** 2 * 600 + 4
+    xy = torch.rand(K, 2, device=dev, generator=g) * torch.tensor([2048., 1024.], device=dev)
+    rois = torch.cat([torch.randint(0, n_img, (K, 1), device=dev, generator=g).float(), xy, xy + wh], 1).contiguous()
+    keys = torch.empty(K, dtype=torch.int64, device=dev)
+    _lib.check(L.oadg_roi_order_keys(_lib.ptr(rois), K, n_img, levels, 56.0, _lib.ptr(keys), _lib.stream_ptr()), 'keys')
+    order = torch.empty(K, dtype=torch.int32, device=dev)
+    rng = torch.empty(n_img * levels + 1, dtype=torch.int32, device=dev)
+    _lib.check(L.oadg_roi_order(_lib.ptr(rois), K, n_img, levels, 56.0, _lib.ptr(order), _lib.ptr(rng), _lib.stream_ptr()),
+               'order')
+    skeys, ref = torch.sort(keys, stable=True)
+    assert torch.equal(order.long(), ref)
+    bounds = torch.arange(n_img * levels + 1, device=dev, dtype=torch.int64) << 20
+    assert torch.equal(rng.long(), torch.searchsorted(skeys, bounds))
+    assert int(rng[-1]) == K and (K < 100 or int((skeys[1:] == skeys[:-1]).sum()) > 0)
