@@ -113,19 +113,19 @@ class FusedSGD(torch.optim.SGD):
         for gi, (group, ps) in enumerate(zip(self.param_groups, lists)):
             if not ps:
                 continue
-            key = (gi, tuple(id(p) for p in ps))
+            key = (gi, tuple((id(p), p.numel()) for p in ps))
             ent = self._tables.get(gi)
             if ent is None or ent['key'] != key:
                 tab = np.zeros(len(ps), dtype=_SGD_TENSOR)
                 blocks = 0
                 for i, p in enumerate(ps):
-                    tab[i]['param'], tab[i]['numel'], tab[i]['first_block'] = p.data_ptr(), p.numel(), blocks
+                    tab[i]['numel'], tab[i]['first_block'] = p.numel(), blocks
                     blocks += int(L.oadg_sgd_blocks(p.numel()))
                 dev = ps[0].device
                 ent = self._tables[gi] = dict(
                     key=key, tab=tab, blocks=blocks,
                     pinned=[torch.empty(tab.nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)],
-                    dev=torch.empty(tab.nbytes, dtype=torch.uint8, device=dev))
+                    events=[None, None], dev=torch.empty(tab.nbytes, dtype=torch.uint8, device=dev))
             tab = ent['tab']
             bufs, first = [], []
             for p in ps:
@@ -135,13 +135,18 @@ class FusedSGD(torch.optim.SGD):
                 if b is None:
                     b = st['momentum_buffer'] = torch.empty_like(p.grad)       # (receives g' in the kernel: clone(grad))
                 bufs.append(b)
+            tab['param'] = [p.data_ptr() for p in ps]          # (every step: ``p.data`` may have been re-pointed)
             tab['grad'] = [p.grad.data_ptr() for p in ps]
             tab['momentum'] = [b.data_ptr() for b in bufs]
             tab['first_step'] = first
             self._slot ^= 1
             pin = ent['pinned'][self._slot]
+            if ent['events'][self._slot] is not None:
+                ent['events'][self._slot].synchronize()        # the copy out of this staging slot two steps ago is done
             pin.numpy()[:] = tab.view(np.uint8)
             ent['dev'].copy_(pin, non_blocking=True)
+            ev = ent['events'][self._slot] = ent['events'][self._slot] or torch.cuda.Event()
+            ev.record()
             _lib.check(L.oadg_sgd_step_multi(_lib.ptr(ent['dev']), len(ps), ent['blocks'], float(group['lr']),
                                              float(group['momentum']), float(group['weight_decay']), _lib.stream_ptr()),
                        'oadg_sgd_step_multi')

@@ -159,11 +159,15 @@ def flush_colsums():
     if st is None or st[0][0].numel() < tab.nbytes:
         n = max(tab.nbytes, 256 * _CS_JOB.itemsize)
         st = _CS_STAGE[dev] = ([torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(4)],
-                               [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(4)], [0])
-    st[2][0] = (st[2][0] + 1) % 4          # a few flushes per step at most (one per gradient bucket): four slots
-    pin, tdev = st[0][st[2][0]], st[1][st[2][0]]
+                               [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(4)], [0], [None] * 4)
+    k = st[2][0] = (st[2][0] + 1) % 4      # a few flushes per step at most (one per gradient bucket): four slots
+    pin, tdev = st[0][k], st[1][k]
+    if st[3][k] is not None:
+        st[3][k].synchronize()             # the copy out of this staging slot four flushes ago is done
     pin.numpy()[:tab.nbytes] = tab.view(np.uint8)
     tdev[:tab.nbytes].copy_(pin[:tab.nbytes], non_blocking=True)
+    st[3][k] = st[3][k] or torch.cuda.Event()
+    st[3][k].record()
     check(_lib.lib().oadg_colsum_reduce_multi(ptr(tdev), len(pend), blocks, stream_ptr()), 'oadg_colsum_reduce_multi')
     for e in pend:
         for prm, alias in e.targets:
