@@ -272,6 +272,36 @@ def parse_losses(values, name_of, n_names, mask):
 FUSED_PARSE_LOSSES = os.environ.get('OADG_FUSED_PARSE_LOSSES', '1') == '1'
 
 
+# --------------------------------------------------------------------------------------- one cast pass for a head's parameters
+class _CastAll(torch.autograd.Function):
+    """fp32 parameters -> bf16 copies in ONE multi-tensor pass, their gradients back to fp32 in one pass: what autocast
+    does per ``F.linear`` call (a weight cast and a bias cast forward, two gradient casts backward: 24 tiny launches for
+    the RoI head's five remaining linears, in the stretch of the step where the device waits for the host)."""
+
+    @staticmethod
+    def forward(ctx, *params):
+        outs = [torch.empty_like(p, dtype=torch.bfloat16) for p in params]
+        torch._foreach_copy_(outs, [p.detach() for p in params])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g for g in grads if g is not None]
+        outs = [torch.empty_like(g, dtype=torch.float32) for g in live]
+        if live:
+            torch._foreach_copy_(outs, live)
+        it = iter(outs)
+        return tuple(next(it) if g is not None else None for g in grads)
+
+
+def cast_all_bf16(params):
+    """bf16 copies of ``params`` (a list of fp32 CUDA tensors), differentiable - see :class:`_CastAll`"""
+    return _CastAll.apply(*params)
+
+
+FC_CAST_ONCE = os.environ.get('OADG_FC_CAST_ONCE', '1') == '1'
+
+
 # --------------------------------------------------------------------------------------- FC weight on NHWC features
 class _FcWeightPermute(torch.autograd.Function):
     """W fp32 [O, C*P] (column c*P + p, the reference's NCHW flatten) -> bf16 [O, P*C] (column p*C + c, the order of

@@ -355,6 +355,37 @@ class ConvFCBBoxHead(BBoxHead):
             for m in ml:
                 xavier_init(m, distribution='uniform')
 
+    _cast = {}
+
+    def _cast_params(self, x, skip_weight_of=None):
+        """{parameter: bf16 copy} for every Linear of the head, made in one multi-tensor pass (hip_ops.cast_all_bf16) when
+        the head runs under bf16 autocast on the device - else {} and every layer casts for itself as autocast does"""
+        self._cast = {}
+        if not (hip_ops.FC_CAST_ONCE and x.is_cuda and torch.is_autocast_enabled() and torch.is_grad_enabled()
+                and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+            return
+        ps = []
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                for t in (m.weight, m.bias):
+                    if t is not None and t is not skip_weight_of and t.dtype == torch.float32 and t.is_cuda:
+                        ps.append(t)
+        if ps:
+            self._cast = dict(zip(ps, hip_ops.cast_all_bf16(ps)))
+
+    def _lin(self, fc, x):
+        """``fc(x)`` on the pre-cast parameters when :meth:`_cast_params` made them"""
+        c = self._cast
+        w = c.get(fc.weight) if c else None
+        if w is None:
+            return fc(x)
+        return F.linear(x, w, c.get(fc.bias) if fc.bias is not None else None)
+
+    def _seq(self, seq, x):
+        for m in seq:
+            x = self._lin(m, x) if isinstance(m, nn.Linear) else m(x)
+        return x
+
     def _trunk(self, x):
         fcs = list(self.shared_fcs)
         if hip_ops.FC_PERMUTE and x.dim() == 4 and x.is_cuda and x.dtype == torch.bfloat16 and \
@@ -366,23 +397,27 @@ class ConvFCBBoxHead(BBoxHead):
             # the reference's NCHW flatten, summed in another order
             fc = fcs.pop(0)
             K, C, PH, PW = x.shape
+            self._cast_params(x, skip_weight_of=fc.weight)
             w = hip_ops.fc_weight_permuted(fc.weight, C, PH * PW)
-            x = self.relu(F.linear(x.permute(0, 2, 3, 1).reshape(K, PH * PW * C), w, fc.bias))
+            x = self.relu(F.linear(x.permute(0, 2, 3, 1).reshape(K, PH * PW * C), w, self._cast.get(fc.bias, fc.bias)))
         else:
+            self._cast_params(x)
             x = x.flatten(1)        # (c, ph, pw) order, as the reference's NCHW flatten
         for fc in fcs:
-            x = self.relu(fc(x))
+            x = self.relu(self._lin(fc, x))
         x_cls, x_reg = x, x
         for fc in self.cls_fcs:
-            x_cls = self.relu(fc(x_cls))
+            x_cls = self.relu(self._lin(fc, x_cls))
         for fc in self.reg_fcs:
-            x_reg = self.relu(fc(x_reg))
+            x_reg = self.relu(self._lin(fc, x_reg))
         return x, x_cls, x_reg
 
     def forward(self, x):
         _, x_cls, x_reg = self._trunk(x)
-        return (self.fc_cls(x_cls) if self.with_cls else None,
-                self.fc_reg(x_reg) if self.with_reg else None)
+        out = (self._lin(self.fc_cls, x_cls) if self.with_cls else None,
+               self._lin(self.fc_reg, x_reg) if self.with_reg else None)
+        self._cast = {}
+        return out
 
 
 @HEADS.register_module()
@@ -425,9 +460,11 @@ class Shared2FCContrastiveHead(ConvFCBBoxHead):
     def forward(self, x):
         x, x_cls, x_reg = self._trunk(x)
         self.cls_feats = x_cls
-        return (self.fc_cls(x_cls) if self.with_cls else None,
-                self.fc_reg(x_reg) if self.with_reg else None,
-                self.fc_cont(x) if self.with_cont else None)
+        out = (self._lin(self.fc_cls, x_cls) if self.with_cls else None,
+               self._lin(self.fc_reg, x_reg) if self.with_reg else None,
+               self._seq(self.fc_cont, x) if self.with_cont else None)
+        self._cast = {}
+        return out
 
     def loss(self, cls_score, bbox_pred, cont_feats, rois, labels, label_weights, bbox_targets, bbox_weights,
              bbox_absolute_targets=None, reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):

@@ -233,3 +233,31 @@ def test_roi_order_one_launch_equals_stable_sort_of_the_keys(dev, K):
     bounds = torch.arange(n_img * levels + 1, device=dev, dtype=torch.int64) << 20
     assert torch.equal(rng.long(), torch.searchsorted(skeys, bounds))
     assert int(rng[-1]) == K and (K < 100 or int((skeys[1:] == skeys[:-1]).sum()) > 0)
+
+
+def test_head_parameters_cast_in_one_pass_give_identical_results(dev):
+    """hip_ops.cast_all_bf16 (one multi-tensor cast of the contrastive head's Linear parameters forward, one for their
+    gradients backward) against autocast's per-layer casts: the same bf16 values enter the same GEMMs - outputs and
+    every parameter gradient bit-identical."""
+    from oadg_amd import hip_ops
+    from oadg_amd.roi_heads import Shared2FCContrastiveHead
+    torch.manual_seed(0)
+    head = Shared2FCContrastiveHead(in_channels=64, fc_out_channels=128, roi_feat_size=7, num_classes=8).to(dev)
+    x0 = torch.randn(96, 64, 7, 7, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = []
+    for on in (True, False):
+        hip_ops.FC_CAST_ONCE = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            head.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                cls, reg, cont = head(x)
+            (cls.float().square().sum() + reg.float().square().sum() + cont.float().abs().sum()).backward()
+            res.append(([cls, reg, cont, x.grad], {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None}))
+        finally:
+            hip_ops.FC_CAST_ONCE = True
+    for a, b in zip(res[0][0], res[1][0]):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) >= 12
+    for n in res[0][1]:
+        assert res[0][1][n].dtype == torch.float32 and torch.equal(res[0][1][n], res[1][1][n]), n
