@@ -222,3 +222,45 @@ def test_fused_roi_assign_add_gt_equals_tensor_path(dev, match_low_quality):
             assert u.shape == v.shape and u.dtype == v.dtype and torch.equal(u, v), (i, name)
     # proposal lists of different lengths are outside the kernels' domain: the caller is told to loop
     assert B.roi_assign_sample_begin(asg, smp, [props[0], props[1][:200]], gts[:2], labels[:2]) is None
+
+
+def test_fused_roi_path_without_any_gt(dev):
+    """A batch whose images have no gt boxes at all (Gmax = 0): the fused assignment / targets take the same route as the
+    tensor path - every valid proposal is background, no positives, targets all zero, labels = num_classes."""
+    from oadg_amd.config import ConfigDict
+    from oadg_amd.core import bbox as B
+    from oadg_amd.roi_heads import Shared2FCBBoxHead
+    gen = torch.Generator(device=dev).manual_seed(9)
+    asg = B.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False)
+    smp = B.RandomSampler(num=64, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+    props = []
+    for _ in range(2):
+        p = _boxes(gen, 100, dev)
+        s = torch.rand(100, 1, generator=gen, device=dev)
+        s[90:] = -1.
+        props.append(torch.cat([p, s], 1))
+    gts = [torch.zeros(0, 4, device=dev) for _ in range(2)]
+    labels = [torch.zeros(0, dtype=torch.long, device=dev) for _ in range(2)]
+    out = {}
+    for mode in ('tensor', 'fused'):
+        torch.manual_seed(4)
+        if mode == 'fused':
+            pend = B.roi_assign_sample_begin(asg, smp, props, gts, labels)
+            assert pend is not None
+        else:
+            ars, counts = asg.assign_many(props, [p[:, 4] >= 0 for p in props], gts, labels) or (None, None)
+            if ars is None:          # (the batch kernel declines Gmax = 0 inputs it cannot stack: per-image assignment)
+                ars = [asg.assign_masked(p[:, :4], p[:, 4] >= 0, g, l) for p, g, l in zip(props, gts, labels)]
+            pend = B.sample_many_begin(smp, ars, props, gts, labels, counts=counts)
+        res = pend.finish()
+        out[mode] = [(r.pos_inds.clone(), r.neg_inds.clone(), r.bboxes.clone()) for r in res]
+    for x, y in zip(out['tensor'], out['fused']):
+        assert x[0].numel() == 0 and y[0].numel() == 0
+        assert torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) and x[1].numel() == 64
+    head = Shared2FCBBoxHead(in_channels=8, fc_out_channels=16, roi_feat_size=7, num_classes=8).to(dev)
+    fused = head.rois_and_targets(res, ConfigDict(pos_weight=-1))
+    assert fused is not None
+    rois, K, t = fused
+    assert K == 128 and torch.equal(rois, B.bbox2roi([r.bboxes for r in res]))
+    assert int((t[0] != 8).sum()) == 0 and float(t[2].abs().sum()) == 0 and float(t[3].abs().sum()) == 0
+    assert torch.equal(t[1], torch.ones(128, device=dev))
