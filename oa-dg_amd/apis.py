@@ -154,7 +154,11 @@ class FusedSGD(torch.optim.SGD):
             # torch.optim.SGD would, so that everything keyed on them sees the update (hip_conv's bank of prepared
             # convolution weights, autograd's saved-tensor checks); the momentum buffers likewise
             both = ps + bufs
-            torch._C._autograd._unsafe_set_version_counter(both, [t._version + 1 for t in both])
+            bump = getattr(torch._C._autograd, '_unsafe_set_version_counter', None)
+            if bump is not None:
+                bump(both, [t._version + 1 for t in both])
+            else:                               # (a torch without the hook: an in-place no-op per tensor does the same)
+                torch._foreach_add_(both, 0.0)
         return None
 
 

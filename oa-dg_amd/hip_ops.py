@@ -273,6 +273,15 @@ FUSED_PARSE_LOSSES = os.environ.get('OADG_FUSED_PARSE_LOSSES', '1') == '1'
 
 
 # --------------------------------------------------------------------------------------- one cast pass for a head's parameters
+def _foreach_copy(dst, src):
+    f = getattr(torch, '_foreach_copy_', None)
+    if f is not None:
+        f(dst, src)
+    else:
+        for d, s_ in zip(dst, src):
+            d.copy_(s_)
+
+
 class _CastAll(torch.autograd.Function):
     """fp32 parameters -> bf16 copies in ONE multi-tensor pass, their gradients back to fp32 in one pass: what autocast
     does per ``F.linear`` call (a weight cast and a bias cast forward, two gradient casts backward: 24 tiny launches for
@@ -281,7 +290,7 @@ class _CastAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *params):
         outs = [torch.empty_like(p, dtype=torch.bfloat16) for p in params]
-        torch._foreach_copy_(outs, [p.detach() for p in params])
+        _foreach_copy(outs, [p.detach() for p in params])
         return tuple(outs)
 
     @staticmethod
@@ -289,7 +298,7 @@ class _CastAll(torch.autograd.Function):
         live = [g for g in grads if g is not None]
         outs = [torch.empty_like(g, dtype=torch.float32) for g in live]
         if live:
-            torch._foreach_copy_(outs, live)
+            _foreach_copy(outs, live)
         it = iter(outs)
         return tuple(next(it) if g is not None else None for g in grads)
 
