@@ -367,6 +367,33 @@ int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float*
                                      const float* scale, const float* mean, const float* var, float eps, int K, int C,
                                      int R, int S, float* dw, float* dgamma, int w_krsc, void* stream);
 
+/* The weight gradients of SEVERAL layers in one launch (round 4): the small maps of the backbone / neck cannot fill the
+ * chip with long workgroups one layer at a time, so a trainer defers them and issues groups.  Host: fill x, dy, N, H, W,
+ * C, K, R, S, stride, pad, dil of every job (K % 256 == 0, C % 256 == 0), call oadg_conv2d_wgrad_multi_plan - it fills
+ * the remaining fields and returns the length of the workgroup list (<= target_blocks when the group's weight tiles fit;
+ * negative = -OADG_E*) -, point part at splits * K * R * S * C floats per job, copy the table to the device, launch.
+ * part has the layout of oadg_conv2d_wgrad_parts_nhwc_bf16's workspace; oadg_prep_conv_weights_bwd_parts_multi is the
+ * matching consumer (one launch for the group: splits summed in fp32 in a fixed order, BN-fold chain rule, layout
+ * change; w_krsc bits as in oadg_prep_conv_weights_bwd_parts; first_block = sum of K over the jobs before). */
+typedef struct oadg_wgrad_job {
+    const void* x;             /* bf16 [N,H,W,C] */
+    const void* dy;            /* bf16 [N,Ho,Wo,K] */
+    void* part;                /* fp32 [splits][K][R*S][C] */
+    long P;                    /* plan: N*Ho*Wo */
+    int N, H, W, C, K, R, S, stride, pad, dil;
+    int Ho, Wo, splits, chunks_per_split, first_block, blocks;      /* plan */
+} oadg_wgrad_job;
+long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs_host, int n, int target_blocks);
+int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const void* zeros16, void* stream);
+typedef struct oadg_prep_bwd_job {
+    const float *part, *gbias, *w, *scale, *mean, *var;
+    float *dw, *dgamma;
+    float eps;
+    int splits, K, C, R, S, w_krsc, first_block;
+} oadg_prep_bwd_job;
+int oadg_prep_conv_weights_bwd_parts_multi(const oadg_prep_bwd_job* jobs_dev, int n, int total_blocks, int max_crs,
+                                           void* stream);
+
 /* one parity class of a strided data gradient: a stride-1 convolution over x (= dy) whose out_h x out_w output pixels
  * per image are stored on the strided grid row = ((n*OH + ho*osh + oph)*OW + wo*osw + opw) of y [N,OH,OW,K]; residual and
  * mask are read at the same rows; input positions past the extent of x read zeros.  Replaces the stride-2 branch of

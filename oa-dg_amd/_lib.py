@@ -112,6 +112,9 @@ SIGNATURES = {
     'oadg_sample_select': (ci, [vp, ci, cl, ci, vp, vp, vp, ctypes.c_size_t, vp]),
     'oadg_anchor_targets': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_colsum_reduce_multi': (ci, [vp, ci, ci, vp]),
+    'oadg_conv2d_wgrad_multi_plan': (ctypes.c_long, [vp, ci, ci]),
+    'oadg_conv2d_wgrad_multi': (ci, [vp, ci, ci, vp, vp]),
+    'oadg_prep_conv_weights_bwd_parts_multi': (ci, [vp, ci, ci, ci, vp]),
     'oadg_sgd_blocks': (ctypes.c_longlong, [ctypes.c_longlong]),
     'oadg_sgd_step_multi': (ci, [vp, ci, ctypes.c_longlong, cf, cf, cf, vp]),
     'oadg_fc_weight_permute': (ci, [vp, vp, ci, ci, ci, ci, vp]),

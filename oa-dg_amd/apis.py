@@ -155,10 +155,12 @@ class FusedSGD(torch.optim.SGD):
             # convolution weights, autograd's saved-tensor checks); the momentum buffers likewise
             both = ps + bufs
             bump = getattr(torch._C._autograd, '_unsafe_set_version_counter', None)
-            if bump is not None:
+            try:
+                if bump is None:
+                    raise TypeError
                 bump(both, [t._version + 1 for t in both])
-            else:                               # (a torch without the hook: an in-place no-op per tensor does the same)
-                torch._foreach_add_(both, 0.0)
+            except TypeError:                   # a torch without the hook, or with its older (Tensor, int) signature:
+                torch._foreach_add_(both, 0.0)  # an in-place no-op per tensor bumps the counters the same way
         return None
 
 
@@ -292,7 +294,7 @@ class FlatGradReducer:
 
     def _launch(self, b):
         from . import hip_conv
-        hip_conv.flush_colsums()          # bias gradients whose reduction was deferred (hip_conv.DEFER_COLSUM) are read now
+        hip_conv.flush_deferred()         # weight / bias gradients whose launches were deferred (hip_conv.DEFER_*) are read now
         flat = self.flat[b['start']:b['end']]
         if all(p.grad is not None for p in b['params']):
             torch.cat([self._memory_order(p.grad, p) for p in b['params']], out=flat)     # ONE packing launch
@@ -328,10 +330,14 @@ class TrainEngine:
     SURVEY.md 3.1): OptimizerHook semantics = zero_grad, loss.backward(), (no grad clip), step."""
 
     def __init__(self, model, optimizer, distributed=False, amp_dtype=None, bucket_cap_mb=50,
-                 find_unused_parameters=False):
+                 find_unused_parameters=False, grad_clip=None):
         self.module = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
+        # OptimizerHook.clip_grads (mmcv/runner/hooks/optimizer.py): clip_grad_norm_(**grad_clip) over the parameters that
+        # received a gradient, after the gradient average and before optimizer.step(); None (the reference's schedules) = off
+        self.grad_clip = dict(grad_clip) if grad_clip else None
+        self.last_grad_norm = None
         self.ddp = self.reducer = None
         # Opt-in (OADG_STEP_PRIO=-1|0|1): run the train step on its own HIP stream of that priority
         # (hipDeviceGetStreamPriorityRange: -1 high .. 1 low on MI355X) so its kernels are dispatched ahead of the data
@@ -394,12 +400,42 @@ class TrainEngine:
             if self.reducer is not None:
                 self.reducer.finish()
         with _rf('sec:optimizer'):
+            if self.grad_clip is not None:
+                params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
+                if params:
+                    self.last_grad_norm = torch.nn.utils.clip_grad_norm_(params, **self.grad_clip)
             self.optimizer.step()
             if self.amp_dtype is torch.bfloat16:
                 # the parameters just changed: re-prepare every convolution's weights (BN fold, bf16 layouts) in one launch,
                 # so that the next forward pass prepares nothing (hip_conv.refresh_prepared)
                 hip_conv.refresh_prepared()
         return dict(loss=loss.detach(), log_vars=log_vars, num_samples=n)
+
+
+def parse_optimizer_config(cfg):
+    """``optimizer_config`` / ``fp16`` of a reference config (apis/train.py:153-161) -> the keyword arguments of
+    TrainEngine.  ``grad_clip`` is honoured (mmcv OptimizerHook); everything this build cannot honour is REJECTED with
+    its name instead of being dropped: a custom hook ``type``, unknown keys, and ``fp16`` (mmcv's Fp16OptimizerHook =
+    fp16 autocast with loss scaling - this build trains in bf16 autocast, which has fp32's exponent range and no loss
+    scale; ``--amp bf16`` is the supported mixed-precision mode)."""
+    if cfg.get('fp16', None) is not None:
+        raise NotImplementedError(
+            f"config key fp16={dict(cfg.get('fp16'))!r}: fp16 loss-scaled training (mmcv Fp16OptimizerHook) is not built; "
+            "this build's mixed precision is bf16 autocast (--amp bf16, the default) - remove the fp16 key")
+    oc = cfg.get('optimizer_config', None)
+    oc = dict(oc) if oc else {}
+    if 'type' in oc:
+        raise NotImplementedError(f"optimizer_config.type={oc['type']!r}: only mmcv's plain OptimizerHook semantics "
+                                  "(zero_grad, backward, optional grad_clip, step) are built")
+    clip = oc.pop('grad_clip', None)
+    oc.pop('detect_anomalous_params', None)          # a debugging aid of mmcv's hook, no effect on training
+    if oc:
+        raise NotImplementedError(f'optimizer_config keys not supported: {sorted(oc)}')
+    if clip is not None:
+        clip = dict(clip)
+        if 'max_norm' not in clip:
+            raise ValueError(f'optimizer_config.grad_clip={clip!r} needs max_norm (torch.nn.utils.clip_grad_norm_)')
+    return dict(grad_clip=clip)
 
 
 def train_detector(model, data_iter, cfg, distributed=False, max_iters=None, logger=print, amp_dtype=None,
@@ -410,7 +446,7 @@ def train_detector(model, data_iter, cfg, distributed=False, max_iters=None, log
     optimizer = build_optimizer(model, cfg.optimizer)
     sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
     engine = TrainEngine(model, optimizer, distributed, amp_dtype,
-                         find_unused_parameters=cfg.get('find_unused_parameters', False))
+                         find_unused_parameters=cfg.get('find_unused_parameters', False), **parse_optimizer_config(cfg))
     interval = cfg.get('log_config', {}).get('interval', 50)
     rank, _ = get_dist_info()
     if iters_per_epoch is None and hasattr(data_iter, '__len__'):

@@ -1306,29 +1306,12 @@ struct PixState {
     long xoff[2];         // element offset of input pixel (n, ho * stride, wo * stride)
 };
 
-__global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// one workgroup's share of a weight gradient: tile `combo` = (tap, k tile, c tile) of pixel range `split`
+__device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int split, const int combo, unsigned char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int kt_n = a.K / 256, ct_n = a.C / 256, RS = a.R * a.S;
-    const int combos = kt_n * ct_n * RS;
-    const long bid = blockIdx.x;
-    int split, combo;
-    if (a.splits % 8 == 0) {
-        const long xcd = bid & 7, j = bid >> 3;
-        combo = (int)(j % combos);
-        split = (int)((j / combos) * 8 + xcd);
-    } else {
-        // workgroup b runs on XCD b % 8: XCD x takes the CONTIGUOUS slice [x * per, (x + 1) * per) of the split-major
-        // workgroup list, so the taps / tiles of a pixel range share an XCD's L2 except where a slice boundary cuts a
-        // split (28 splits x 9 taps = 252 workgroups use 252 CUs; 24 aligned splits only 216)
-        const long total = (long)a.splits * combos, per = (total + 7) >> 3;
-        const long xcd = bid & 7, slot = bid >> 3, w = xcd * per + slot;
-        if (slot >= per || w >= total) return;
-        combo = (int)(w % combos);
-        split = (int)(w / combos);
-    }
     const int ct = combo % ct_n;
     const int kt = (combo / ct_n) % kt_n;
     const int rs = combo / (ct_n * kt_n);
@@ -1545,6 +1528,60 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
         }
 }
 
+__global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int combos = (a.K / 256) * (a.C / 256) * a.R * a.S;
+    const long bid = blockIdx.x;
+    int split, combo;
+    if (a.splits % 8 == 0) {
+        const long xcd = bid & 7, j = bid >> 3;
+        combo = (int)(j % combos);
+        split = (int)((j / combos) * 8 + xcd);
+    } else {
+        // workgroup b runs on XCD b % 8: XCD x takes the CONTIGUOUS slice [x * per, (x + 1) * per) of the split-major
+        // workgroup list, so the taps / tiles of a pixel range share an XCD's L2 except where a slice boundary cuts a
+        // split (28 splits x 9 taps = 252 workgroups use 252 CUs; 24 aligned splits only 216)
+        const long total = (long)a.splits * combos, per = (total + 7) >> 3;
+        const long xcd = bid & 7, slot = bid >> 3, w = xcd * per + slot;
+        if (slot >= per || w >= total) return;
+        combo = (int)(w % combos);
+        split = (int)(w / combos);
+    }
+    wgrad256_tile(a, split, combo, smem);
+}
+
+// ---- several layers' weight gradients in ONE launch (round 4) -----------------------------------------------------
+// The small maps of the backbone / neck (layer3, layer4, P3-P5 laterals and output convolutions: 1024 or 256 K-tiles of
+// 64 pixels each) cannot fill 256 compute units with long workgroups on their own: one round of 256 workgroups gives each
+// 8-37 K-tiles between a ~4 us prologue and a 16 us partial-tile epilogue, and leaves 28-64 fp32 partial tiles per
+// weight tile to be written, re-read and summed.  Their launches are independent, so a trainer defers them and issues a
+// GROUP as one launch: job j owns the workgroups [first_block_j, first_block_j + tiles_j * splits_j) of one list,
+// splits_j chosen by oadg_conv2d_wgrad_multi_plan so that the list has <= 256 entries of about equal length (>= 64
+// K-tiles each when the group is large enough) - fewer, longer splits: 4-8 partials per weight tile instead of 28-64.
+// XCD x takes the contiguous slice x of the list (as in the single-layer kernel), so the tiles of a pixel range meet in
+// one L2.  The job table lives in device memory; a workgroup finds its job by binary search on first_block (uniform).
+__global__ __launch_bounds__(512) void conv_wgrad256_multi_kernel(const oadg_wgrad_job* __restrict__ jobs, int n_jobs,
+                                                                  int total, const unsigned short* zeros) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int per = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, w = xcd * per + slot;
+    if (slot >= per || w >= total) return;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= w) lo = mid; else hi = mid - 1;
+    }
+    const oadg_wgrad_job& jb = jobs[__builtin_amdgcn_readfirstlane(lo)];
+    WgradArgs a;
+    a.x = (const unsigned short*)jb.x; a.dy = (const unsigned short*)jb.dy; a.part = (float*)jb.part; a.zeros = zeros;
+    a.N = jb.N; a.H = jb.H; a.W = jb.W; a.C = jb.C; a.K = jb.K; a.R = jb.R; a.S = jb.S; a.Ho = jb.Ho; a.Wo = jb.Wo;
+    a.stride = jb.stride; a.pad = jb.pad; a.dil = jb.dil; a.splits = jb.splits; a.chunks_per_split = jb.chunks_per_split;
+    a.P = jb.P;
+    const int local = w - jb.first_block;
+    const int combos = (a.K / 256) * (a.C / 256) * a.R * a.S;
+    wgrad256_tile(a, local / combos, local % combos, smem);
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, long n, float* __restrict__ dw) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1675,6 +1712,84 @@ extern "C" int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, 
     if (!splits) return OADG_EARG;
     return wgrad_launch(x, dy, nullptr, zeros16, workspace, workspace_bytes, N, H, W, C, K, R, S, stride, pad, dil,
                         splits, stream);
+}
+
+// ---- grouped launch (see conv_wgrad256_multi_kernel).  Plan on the host: jobs_host[i] carries the problem (x, dy, N, H,
+// W, C, K, R, S, stride, pad, dil); this fills Ho, Wo, P, splits, chunks_per_split, first_block, blocks and returns the
+// length of the workgroup list (<= target_blocks whenever the group's weight tiles fit, else one workgroup per tile), or
+// a negative OADG_E* code.  The caller then points part at splits * K * R * S * C floats per job, copies the table to the
+// device and launches.  Every job must be a shape the 256-tile kernel covers (K % 256 == 0, C % 256 == 0).
+extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int target_blocks) {
+    if (!jobs || n < 1 || target_blocks < 1) return -(long)OADG_EARG;
+    double work = 0.0;
+    for (int i = 0; i < n; ++i) {
+        oadg_wgrad_job& j = jobs[i];
+        if (j.N < 1 || j.H < 1 || j.W < 1 || j.R < 1 || j.S < 1 || j.stride < 1 || j.dil < 1 || j.pad < 0) return -(long)OADG_EARG;
+        if (j.K % 256 != 0 || j.C % 256 != 0 || j.K < 256 || j.C < 256) return -(long)OADG_EARG;
+        if ((double)j.N * j.H * j.W * j.C >= 4294967296.0) return -(long)OADG_EARG;
+        j.Ho = (j.H + 2 * j.pad - j.dil * (j.R - 1) - 1) / j.stride + 1;
+        j.Wo = (j.W + 2 * j.pad - j.dil * (j.S - 1) - 1) / j.stride + 1;
+        if (j.Ho < 1 || j.Wo < 1) return -(long)OADG_EARG;
+        j.P = (long)j.N * j.Ho * j.Wo;
+        const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
+        work += (double)tiles * (double)nchunks;
+    }
+    // K-tiles per workgroup if the list had exactly target_blocks entries; every job starts with the split count that
+    // stays at or above it, then the job with the longest workgroups takes one more split while the list has room
+    const double per = work / target_blocks;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        oadg_wgrad_job& j = jobs[i];
+        const long nchunks = (j.P + WP - 1) / WP;
+        long sp = per > 0.0 ? (long)((double)nchunks / per) : 1;
+        if (sp < 1) sp = 1;
+        if (sp > nchunks) sp = nchunks;
+        j.splits = (int)sp;
+        total += (long)(j.K / 256) * (j.C / 256) * j.R * j.S * sp;
+    }
+    for (;;) {
+        int best = -1;
+        double longest = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const oadg_wgrad_job& j = jobs[i];
+            const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
+            if (j.splits >= nchunks || total + tiles > target_blocks) continue;
+            const double len = (double)nchunks / j.splits;
+            if (len > longest) { longest = len; best = i; }
+        }
+        if (best < 0) break;
+        jobs[best].splits += 1;
+        total += (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
+    }
+    long first = 0;
+    for (int i = 0; i < n; ++i) {
+        oadg_wgrad_job& j = jobs[i];
+        const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
+        j.chunks_per_split = (int)((nchunks + j.splits - 1) / j.splits);
+        j.splits = (int)((nchunks + j.chunks_per_split - 1) / j.chunks_per_split);      // no empty pixel range
+        j.first_block = (int)first;
+        j.blocks = (int)(tiles * j.splits);
+        first += j.blocks;
+        if (first > 0x3fffffffL) return -(long)OADG_EARG;
+    }
+    return first;
+}
+
+extern "C" int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const void* zeros16,
+                                       void* stream) {
+    if (!jobs_dev || n < 1 || total_blocks < 1 || !zeros16) return OADG_EARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad256_multi_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)(((total_blocks + 7) / 8) * 8);         // eight equal XCD slices
+    hipLaunchKernelGGL(conv_wgrad256_multi_kernel, dim3(blocks), dim3(512), 2 * BUF_BYTES, (hipStream_t)stream, jobs_dev, n,
+                       total_blocks, (const unsigned short*)zeros16);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
 }
 
 // ================================================================================================ weight preparation
@@ -1950,6 +2065,78 @@ extern "C" int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, c
     if (lds > 5 * 12000) return OADG_EARG;    // callers fall back to the reduced form
     hipLaunchKernelGGL(prep_weights_bwd_parts_kernel, dim3(K), dim3(1024), lds, (hipStream_t)stream, part, splits, gbias,
                        w, scale, mean, var, eps, K, C, R, S, dw, dgamma, w_krsc);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+namespace {
+// prep_weights_bwd_parts_kernel for the jobs of a grouped weight-gradient launch: few splits (1-8), so one pass of 512
+// threads with eight independent accumulators per element (fixed order: deterministic) and ONE fp32 copy of the filter
+// in LDS ([R*S][C], <= 18 KiB for 512 x 3 x 3) instead of five; block b belongs to the job with first_block <= b <
+// first_block + K (binary search over the device table), one output channel per block.
+__global__ __launch_bounds__(512) void prep_weights_bwd_parts_multi_kernel(const oadg_prep_bwd_job* __restrict__ jobs,
+                                                                           int n_jobs) {
+    extern __shared__ float gsum[];            // [R*S][C] of the widest job
+    __shared__ float red[16];
+    int lo = 0, hi = n_jobs - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+    }
+    const oadg_prep_bwd_job& d = jobs[__builtin_amdgcn_readfirstlane(lo)];
+    const int k = b - d.first_block;
+    const int K = d.K, C = d.C, RS = d.R * d.S, n = C * RS, splits = d.splits;
+    const int w_krsc = d.w_krsc & 1;
+    const size_t stride = (size_t)K * n;
+    const float* p0 = d.part + (size_t)k * n;
+    for (int j = threadIdx.x; j < n; j += 512) {
+        float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= splits; sp += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc8[u] += p0[(size_t)(sp + u) * stride + j];
+        }
+        for (int u = 0; sp < splits; ++sp, ++u) acc8[u] += p0[(size_t)sp * stride + j];
+        gsum[j] = ((acc8[0] + acc8[1]) + (acc8[2] + acc8[3])) + ((acc8[4] + acc8[5]) + (acc8[6] + acc8[7]));
+    }
+    __syncthreads();
+    const float sc = d.scale ? d.scale[k] : 1.f;
+    const float* wk = d.w + (size_t)k * n;
+    float* dw = d.dw + (size_t)k * n;
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < n; i += 512) {
+        const int rs = i % RS, c = i / RS;
+        const float g = gsum[w_krsc ? i : rs * C + c];
+        dw[i] = g * sc;
+        dot += g * wk[i];
+    }
+    if (d.dgamma) {
+        const float tot = block_sum(dot, red);
+        if (threadIdx.x == 0)
+            d.dgamma[k] = (d.w_krsc & 2) ? tot : (tot - (d.gbias ? d.gbias[k] : 0.f) * d.mean[k]) * rsqrtf(d.var[k] + d.eps);
+    }
+}
+}  // namespace
+
+// jobs_dev [n] on the DEVICE in ascending first_block order (first_block = sum of K over the jobs before); total_blocks =
+// sum of K; max_crs = the largest C * R * S of the group (<= 36000: LDS).  Per job the arithmetic of
+// oadg_prep_conv_weights_bwd_parts with the splits summed in one fixed order.
+extern "C" int oadg_prep_conv_weights_bwd_parts_multi(const oadg_prep_bwd_job* jobs_dev, int n, int total_blocks,
+                                                      int max_crs, void* stream) {
+    if (!jobs_dev || n < 1 || total_blocks < 1 || max_crs < 1 || max_crs > 36000) return OADG_EARG;
+    const size_t lds = (size_t)max_crs * sizeof(float);
+    if (lds > 48 * 1024) {
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)prep_weights_bwd_parts_multi_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 36000 * sizeof(float));
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+    }
+    hipLaunchKernelGGL(prep_weights_bwd_parts_multi_kernel, dim3((unsigned)total_blocks), dim3(512), lds,
+                       (hipStream_t)stream, jobs_dev, n);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -429,6 +429,18 @@ extern "C" int oadg_fc_weight_permute(const void* src, void* dst, int O, int C, 
     if (!src || !dst || O < 1 || C < FCP_TC || (C % FCP_TC) || P < 1 || P > 256 || (mode != 0 && mode != 1) || O > 65535)
         return OADG_EARG;
     const size_t smem = (size_t)FCP_TC * (P + 1) * sizeof(float);
+    if (smem > 48 * 1024) {          // 14 x 14 bins and more: above the default dynamic-LDS limit (P = 256: 65,792 bytes)
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)fc_weight_permute_kernel<0>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, FCP_TC * 257 * sizeof(float));
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)fc_weight_permute_kernel<1>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, FCP_TC * 257 * sizeof(float));
+            if (e != hipSuccess) return (int)e;
+            attr = true;
+        }
+    }
     const dim3 grid(C / FCP_TC, O);
     if (mode == 0)
         hipLaunchKernelGGL(fc_weight_permute_kernel<0>, grid, dim3(256), smem, (hipStream_t)stream, src, dst, C, P);

@@ -80,17 +80,27 @@ _STEP = 0                   # training-step counter: a bank entry counts the for
 
 
 def begin_step(defer):
-    """TrainEngine: a new step starts; ``defer``: collect the column-sum reductions of its backward pass"""
-    global _STEP, DEFER_COLSUM
+    """TrainEngine: a new step starts; ``defer``: collect the column-sum reductions and the small layers' weight
+    gradients of its backward pass"""
+    global _STEP, DEFER_COLSUM, DEFER_WGRAD
     _STEP += 1
     DEFER_COLSUM = bool(defer) and os.environ.get('OADG_DEFER_COLSUM', '1') == '1'
+    DEFER_WGRAD = bool(defer) and os.environ.get('OADG_DEFER_WGRAD', '1') == '1'
 
 
 def end_backward():
     """TrainEngine: the backward pass has been enqueued - run what was deferred, stop deferring"""
-    global DEFER_COLSUM
-    DEFER_COLSUM = False
-    return flush_colsums()
+    global DEFER_COLSUM, DEFER_WGRAD
+    DEFER_COLSUM = DEFER_WGRAD = False
+    return flush_deferred()
+
+
+def flush_deferred():
+    """everything a backward pass has deferred so far, on the current stream: the grouped weight gradients first (their
+    consumer leaves raw BN-scale dot products that the column-sum launch finishes), then the column sums.  Called at the
+    end of the backward pass and before a data-parallel gradient bucket is packed."""
+    n = flush_wgrads()
+    return n + flush_colsums()
 
 
 _CS_JOB = np.dtype([('part', np.uint64), ('out', np.uint64), ('dgamma', np.uint64), ('mean', np.uint64),
@@ -178,6 +188,154 @@ def flush_colsums():
                 g.copy_(alias)
         e.done, e.part, e.fix, e.targets = True, None, None, []
     return len(pend)
+
+
+# ---- deferred, grouped weight gradients ---------------------------------------------------------------------------------
+# The weight gradient of a layer is consumed by nobody but AccumulateGrad (through _PrepWeights.backward).  The small maps
+# of the backbone / neck cannot fill the chip with long workgroups on their own (csrc conv_wgrad256_multi_kernel), so
+# inside TrainEngine's backward their launches are collected and issued in groups: one weight-gradient launch + one
+# launch of the partial-sum / BN-fold consumer per group.  dW / dgamma travel up the graph as tensors that the group's
+# launches fill later - the same arrangement, with the same aliasing rules, as the deferred column sums above.
+DEFER_WGRAD = False
+WGRAD_SMALL = int(os.environ.get('OADG_WGRAD_SMALL', 40000))        # weight tiles x K-tiles below which a layer is deferred
+WGRAD_GROUP = int(os.environ.get('OADG_WGRAD_GROUP', 65536))        # ... and the sum at which a group is launched
+_WQ = []
+_WQ_WORK = 0
+_WG_JOB = np.dtype([('x', 'u8'), ('dy', 'u8'), ('part', 'u8'), ('P', 'i8'), ('N', 'i4'), ('H', 'i4'), ('W', 'i4'),
+                    ('C', 'i4'), ('K', 'i4'), ('R', 'i4'), ('S', 'i4'), ('stride', 'i4'), ('pad', 'i4'), ('dil', 'i4'),
+                    ('Ho', 'i4'), ('Wo', 'i4'), ('splits', 'i4'), ('cps', 'i4'), ('first_block', 'i4'),
+                    ('blocks', 'i4')], align=True)                                                  # oadg_wgrad_job
+_PB_JOB = np.dtype([('part', 'u8'), ('gbias', 'u8'), ('w', 'u8'), ('scale', 'u8'), ('mean', 'u8'), ('var', 'u8'),
+                    ('dw', 'u8'), ('dgamma', 'u8'), ('eps', 'f4'), ('splits', 'i4'), ('K', 'i4'), ('C', 'i4'),
+                    ('R', 'i4'), ('S', 'i4'), ('w_krsc', 'i4'), ('first_block', 'i4')], align=True)  # oadg_prep_bwd_job
+assert _WG_JOB.itemsize == 96 and _PB_JOB.itemsize == 96
+
+
+class _TableStage:
+    """host table -> device memory without a blocking copy: a ring of pinned + device buffers per device; a slot is
+    reused only after the copy issued from it ``SLOTS`` uploads ago has completed (event)"""
+    SLOTS = 16
+
+    def __init__(self):
+        self.dev = {}
+
+    def upload(self, tab, device):
+        raw = tab.view(np.uint8).reshape(-1)
+        st = self.dev.get(device)
+        if st is None or st[0][0].numel() < raw.nbytes:
+            n = max(raw.nbytes, 64 * 96)
+            st = self.dev[device] = ([torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)],
+                                     [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.SLOTS)], [0],
+                                     [None] * self.SLOTS)
+        k = st[2][0] = (st[2][0] + 1) % self.SLOTS
+        pin, tdev = st[0][k], st[1][k]
+        if st[3][k] is not None:
+            st[3][k].synchronize()
+        pin.numpy()[:raw.nbytes] = raw
+        tdev[:raw.nbytes].copy_(pin[:raw.nbytes], non_blocking=True)
+        st[3][k] = st[3][k] or torch.cuda.Event()
+        st[3][k].record()
+        return tdev
+
+
+_TABLES = _TableStage()
+
+
+def wgrad_work(N, Ho, Wo, C, K, R, S):
+    """weight tiles x K-tiles of a weight-gradient problem on the 256-tile kernel (0: not that kernel's shape)"""
+    if K % 256 or C % 256:
+        return 0
+    return (K // 256) * (C // 256) * R * S * ((N * Ho * Wo + 63) // 64)
+
+
+class _WgradJob:
+    """one deferred weight gradient: the operands (kept alive), its geometry and - once _PrepWeights.backward has run -
+    the consumer's operands and the aliases of the tensors that went up the graph"""
+    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets')
+
+    def __init__(self, x16, gy16, K, R, S, stride, pad, dil):
+        N, C, H, W = x16.shape
+        self.x, self.gy = x16, gy16
+        self.geo = (N, H, W, C, K, R, S, stride, pad, dil)
+        self.work = wgrad_work(N, gy16.shape[2], gy16.shape[3], C, K, R, S)
+        self.prep, self.targets = None, []
+
+
+def wgrad_multi(jobs, target_blocks=256):
+    """[(x16, gy16, K, R, S, stride, pad, dil)] -> (workspace, [(part pointer, splits)] per job): the weight gradients of
+    several layers as fp32 split partials from ONE launch (csrc oadg_conv2d_wgrad_multi)"""
+    L = _lib.lib()
+    tab = np.zeros(len(jobs), dtype=_WG_JOB)
+    dev = jobs[0][0].device
+    for r, (x16, gy16, K, R, S, stride, pad, dil) in zip(tab, jobs):
+        N, C, H, W = x16.shape
+        r['x'], r['dy'] = x16.data_ptr(), gy16.data_ptr()
+        r['N'], r['H'], r['W'], r['C'], r['K'], r['R'], r['S'] = N, H, W, C, K, R, S
+        r['stride'], r['pad'], r['dil'] = stride, pad, dil
+    total = L.oadg_conv2d_wgrad_multi_plan(tab.ctypes.data_as(ctypes.c_void_p), len(jobs), int(target_blocks))
+    if total <= 0:
+        raise RuntimeError(f'oadg_conv2d_wgrad_multi_plan failed (code {-total})')
+    sizes = [int(r['splits']) * int(r['K']) * int(r['R']) * int(r['S']) * int(r['C']) * 4 for r in tab]
+    ws = torch.empty(sum(sizes), dtype=torch.uint8, device=dev)
+    off, parts = 0, []
+    for r, (x16, gy16, *_), sz in zip(tab, jobs, sizes):
+        assert gy16.shape[2] == r['Ho'] and gy16.shape[3] == r['Wo'], 'dy does not have the convolution\'s output extent'
+        r['part'] = ws.data_ptr() + off
+        parts.append((ws.data_ptr() + off, int(r['splits'])))
+        off += sz
+    name = 'conv_wgrad256_multi_kernel' if (TIMERS is not None and _timed('wgrad256')) else None
+    if name:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    tdev = _TABLES.upload(tab, dev)
+    check(L.oadg_conv2d_wgrad_multi(ptr(tdev), len(jobs), int(total), ptr(_zeros(dev)), stream_ptr()),
+          'oadg_conv2d_wgrad_multi')
+    if name:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        fl = by = 0.0
+        for x16, gy16, K, R, S, stride, pad, dil in jobs:
+            N, C, H, W = x16.shape
+            P = N * gy16.shape[2] * gy16.shape[3]
+            fl += 2.0 * P * K * C * R * S
+            by += 2.0 * (N * H * W * C + P * K) + 4.0 * K * C * R * S
+        TIMERS.append((e0, e1, fl, by, name, (len(jobs), 0, 0, 0, 0, 0, 0, False, False)))
+    return ws, parts
+
+
+def flush_wgrads():
+    """launch the deferred weight gradients collected so far as ONE group (+ one launch of their consumer)"""
+    global _WQ, _WQ_WORK
+    jobs, _WQ, _WQ_WORK = _WQ, [], 0
+    if not jobs:
+        return 0
+    L = _lib.lib()
+    dev = jobs[0].x.device
+    ws, parts = wgrad_multi([(j.x, j.gy) + j.geo[4:] for j in jobs])
+    tab = np.zeros(len(jobs), dtype=_PB_JOB)
+    first, max_crs = 0, 0
+    p_ = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    for r, j, (pp, splits) in zip(tab, jobs, parts):
+        gb, w, scale, mean, var, eps, flags, dw, dgamma = j.prep
+        K, C, R, S = j.geo[4], j.geo[3], j.geo[5], j.geo[6]
+        r['part'], r['gbias'], r['w'], r['scale'], r['mean'], r['var'] = pp, p_(gb), p_(w), p_(scale), p_(mean), p_(var)
+        r['dw'], r['dgamma'], r['eps'], r['splits'] = p_(dw), p_(dgamma), eps, splits
+        r['K'], r['C'], r['R'], r['S'], r['w_krsc'], r['first_block'] = K, C, R, S, flags, first
+        first += K
+        max_crs = max(max_crs, C * R * S)
+    tdev = _TABLES.upload(tab, dev)
+    check(L.oadg_prep_conv_weights_bwd_parts_multi(ptr(tdev), len(jobs), first, max_crs, stream_ptr()),
+          'oadg_prep_conv_weights_bwd_parts_multi')
+    for j in jobs:
+        for prm, alias in j.targets:
+            # AccumulateGrad adopts a gradient it holds the last reference to - then .grad IS the tensor just filled; had
+            # it copied instead (a tensor hook, an extra reference), the copy was taken before the launch: refresh it
+            g = prm.grad
+            if g is not None and g.data_ptr() != alias.data_ptr() and g.shape == alias.shape:
+                g.copy_(alias)
+        j.x = j.gy = j.prep = None
+        j.targets = []
+    return len(jobs)
 
 
 def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False, mask_bits=None,
@@ -312,10 +470,11 @@ class WeightGradToken:
     """Hand-off of a weight gradient from the convolution's backward to the backward of its weight preparation
     (one prepared weight <-> one convolution call; weights used by several calls, e.g. the RPN conv shared by the
     pyramid levels, take the reduced path because autograd has to add their gradients)."""
-    __slots__ = ('uses', 'parts')
+    __slots__ = ('uses', 'parts', 'deferrable')
 
     def __init__(self):
         self.uses, self.parts = 0, None
+        self.deferrable = False      # the gradients of this preparation go straight to AccumulateGrad of bank parameters
 
 
 _ZERO_SCALARS = {}
@@ -436,7 +595,25 @@ class _PrepWeights(torch.autograd.Function):
         parts = None
         if tok is not None and tok.parts is not None:
             parts, tok.parts = tok.parts, None
-        if gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
+        if gwf is not None and isinstance(parts, _WgradJob):
+            # a small layer inside TrainEngine's backward: its weight gradient joins the current group
+            dw = torch.empty_like(w)
+            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            job = parts
+            defer = ctx.leaf_inputs and ent is not None and ent.step == _STEP and ent.count == 1 and \
+                all(t.grad is None for t in ent.src) and DEFER_WGRAD
+            job.prep = (gb_now, w, scale, mean, var, eps, int(krsc) | raw, dw.detach(),
+                        dgamma.detach() if dgamma is not None else None)
+            if defer:
+                job.targets.append((ent.src[0], job.prep[7]))
+                if dgamma is not None:
+                    job.targets.append((ent.src[1], job.prep[8]))
+            global _WQ_WORK
+            _WQ.append(job)
+            _WQ_WORK += job.work
+            if not defer or _WQ_WORK >= WGRAD_GROUP:
+                flush_wgrads()       # (not deferrable after all: the gradient is summed on arrival - run the group now)
+        elif gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
             dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
             check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb_now), ptr(w), ptr(scale), ptr(mean),
@@ -530,7 +707,19 @@ class _Bank:
         """re-prepare every registered layer whose parameters changed, in ONE launch; returns the number of layers"""
         import numpy as np
         import weakref
-        ents = [e for e in self.entries if e.args is not None and e.args[0].is_cuda]
+        ents = []
+        for e in self.entries:
+            if e.args is None or not e.args[0].is_cuda:
+                continue
+            # the table holds RAW pointers of the source tensors: an entry whose parameter / buffer storage was re-pointed
+            # since it was filled (p.data = ..., module.to(), load_state_dict(assign=True), parameter flattening) is
+            # dropped here - never launched on the stale pointer, never re-stamped valid - and prepared again by its
+            # next forward call (ADVICE r3)
+            if e.versions is None or any(v[1] != t.data_ptr() for v, t in zip(e.versions, e.src)):
+                e.args = e.versions = None
+                self.dirty = True
+                continue
+            ents.append(e)
         if not ents:
             self.table = None
             return 0
@@ -598,6 +787,8 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
                 ([bias_in] if bias_in is not None else [])
             entry = _BankEntry(src, want_wt)
             cache_on._oadg_prep_entry = entry
+    if tok is not None:
+        tok.deferrable = entry is not None
     if bn is not None:
         out = _PrepWeights.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None,
                                  want_wt, tok, entry)
@@ -754,7 +945,11 @@ class _Conv2dMFMA(torch.autograd.Function):
         gw = None
         if need_w and x16.numel() < 2 ** 32 and _hip_wgrad(K, C, R, gy.shape[0] * gy.shape[2] * gy.shape[3]):
             wtok = ctx.wtoken
-            if wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
+            work = wgrad_work(gy.shape[0], gy.shape[2], gy.shape[3], C, K, R, S) if DEFER_WGRAD else 0
+            if wtok is not None and wtok.uses == 1 and wtok.deferrable and 0 < work < WGRAD_SMALL and C * R * S <= 36000:
+                wtok.parts = _WgradJob(x16, gy, K, R, S, stride, pad, dil)     # launched with its group (flush_wgrads)
+                gw = _dummy_grad(wf)
+            elif wtok is not None and wtok.uses == 1 and C * R * S * 4 <= 12000:
                 wtok.parts = conv_wgrad_parts(x16, gy, K, R, S, stride, pad, dil)
                 gw = _dummy_grad(wf)          # the real gradient rides on the token (fp32 partials)
             else:

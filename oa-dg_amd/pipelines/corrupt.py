@@ -129,14 +129,15 @@ def defocus_blur(x, severity=1):
 
 
 def _clipped_zoom(img, zoom_factor):
-    """imagecorruptions.clipped_zoom for h x w images: centre crop of ceil(side / zoom), bilinear zoom back, centre trim"""
+    """imagecorruptions.clipped_zoom for h x w images: centre crop of ceil(side / zoom), bilinear zoom back; the zoomed
+    layer (a few pixels larger than the image) is trimmed from the TOP-LEFT, as zoom_blur of the package does
+    (``zoom_layer[:h, :w]``), not around its centre"""
     from scipy.ndimage import zoom as scizoom
     h, w = img.shape[:2]
     ch, cw = int(np.ceil(h / float(zoom_factor))), int(np.ceil(w / float(zoom_factor)))
     top, left = (h - ch) // 2, (w - cw) // 2
     img = scizoom(img[top:top + ch, left:left + cw], (zoom_factor, zoom_factor, 1), order=1)
-    t2, l2 = (img.shape[0] - h) // 2, (img.shape[1] - w) // 2
-    return img[t2:t2 + h, l2:l2 + w]
+    return img[:h, :w]
 
 
 def zoom_blur(x, severity=1):
@@ -230,7 +231,7 @@ def pixelate(x, severity=1):
     h, w = np.asarray(x).shape[:2]
     im = Image.fromarray(np.asarray(x, np.uint8))
     im = im.resize((int(w * c), int(h * c)), Image.BOX)
-    return np.asarray(im.resize((w, h), Image.BOX))
+    return np.asarray(im.resize((w, h), Image.NEAREST))      # the package: BOX down, NEAREST up
 
 
 _FUNCS = dict(gaussian_noise=gaussian_noise, shot_noise=shot_noise, impulse_noise=impulse_noise, defocus_blur=defocus_blur,

@@ -344,7 +344,9 @@ def _oamix_parallel(self, states, views, na, pad_shape):
     def task(k):
         h = self._helpers[k]
         om = h['om']
-        om.stats = self.oamix.stats
+        # counters: a private dict per helper, merged by the caller once the futures are done (the shared dict's
+        # read-modify-write updates raced between helper threads)
+        om.stats = {} if self.oamix.stats is not None else None
         with torch.cuda.stream(h['stream']):
             h['stream'].wait_event(ready)
             for i in range(k, len(states), K):
@@ -358,6 +360,10 @@ def _oamix_parallel(self, states, views, na, pad_shape):
     futs = [self._helpers[k]['pool'].submit(task, k) for k in range(K)]
     for f in futs:
         cur.wait_event(f.result())
+    if self.oamix.stats is not None:
+        for k in range(K):
+            for key, n in (self._helpers[k]['om'].stats or {}).items():
+                self.oamix.stats[key] = self.oamix.stats.get(key, 0) + n
     return [r[0] for r in results], [r[1] for r in results]
 
 

@@ -21,6 +21,12 @@ from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_
                        build_loss, build_roi_extractor, build_sampler)
 
 
+def _autocast_dtype():
+    """the CUDA autocast dtype (torch >= 2.4: get_autocast_dtype; older builds: get_autocast_gpu_dtype)"""
+    f = getattr(torch, 'get_autocast_dtype', None)
+    return f('cuda') if f is not None else torch.get_autocast_gpu_dtype()
+
+
 def _pair(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
@@ -362,7 +368,7 @@ class ConvFCBBoxHead(BBoxHead):
         the head runs under bf16 autocast on the device - else {} and every layer casts for itself as autocast does"""
         self._cast = {}
         if not (hip_ops.FC_CAST_ONCE and x.is_cuda and torch.is_autocast_enabled() and torch.is_grad_enabled()
-                and torch.get_autocast_dtype('cuda') == torch.bfloat16):
+                and _autocast_dtype() == torch.bfloat16):
             return
         ps = []
         for m in self.modules():

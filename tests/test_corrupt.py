@@ -55,7 +55,8 @@ def test_pixelate_and_jpeg_are_pillow_round_trips():
     img = _img(4, 90, 150)[:-1, :-3]                            # 87 x 141: sides that the scale factors do not divide
     h, w = img.shape[:2]
     for sev, c in zip(range(1, 6), [0.6, 0.5, 0.4, 0.3, 0.25]):
-        im = Image.fromarray(img).resize((int(w * c), int(h * c)), Image.BOX).resize((w, h), Image.BOX)
+        im = Image.fromarray(img).resize((int(w * c), int(h * c)), Image.BOX).resize((w, h), Image.NEAREST)   # BOX down, NEAREST up
+        assert len(np.unique(np.asarray(im).reshape(-1, 3), axis=0)) <= int(w * c) * int(h * c)       # blocks of constant colour
         assert np.array_equal(corrupt(img, 'pixelate', sev), np.asarray(im))
     for sev, q in zip(range(1, 6), [25, 18, 15, 10, 7]):
         buf = io.BytesIO()

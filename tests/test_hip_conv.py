@@ -874,6 +874,7 @@ def test_deferred_column_sums_give_the_same_gradients_bit_for_bit(dev):
             net.zero_grad(set_to_none=True)
             hip_conv.begin_step(defer=mode != 'immediate')
             assert hip_conv.DEFER_COLSUM == (mode != 'immediate')
+            hip_conv.DEFER_WGRAD = False       # (grouped weight gradients re-split their sums: tested below, not bit-equal)
             try:
                 with torch.autocast('cuda', dtype=torch.bfloat16):
                     cls, reg = head(neck(bb(x)))
@@ -894,3 +895,109 @@ def test_deferred_column_sums_give_the_same_gradients_bit_for_bit(dev):
     finally:
         hip_conv.enable(False)
         hip_conv.DEFER_COLSUM = False
+
+
+_WG_SHAPES = [(2, 256, 16, 24, 256, 3, 1, 1, 1), (2, 1024, 16, 24, 256, 1, 1, 0, 1), (2, 256, 16, 24, 1024, 1, 1, 0, 1),
+              (2, 512, 8, 12, 512, 3, 1, 1, 1), (2, 512, 16, 24, 1024, 1, 2, 0, 1), (2, 256, 32, 48, 256, 3, 2, 1, 1),
+              (1, 512, 9, 13, 256, 3, 1, 2, 2), (3, 256, 5, 7, 256, 3, 1, 1, 1)]
+
+
+@pytest.mark.parametrize('target', [256, 64, 7])
+def test_grouped_weight_gradient_launch_matches_single_layer_launches(dev, target):
+    """oadg_conv2d_wgrad_multi: the weight gradients of several layers (3x3 / 1x1, stride 2, dilation, maps smaller than
+    one 64-pixel K-tile chunk row, a ragged last chunk) from ONE launch, every job with its own split count from
+    oadg_conv2d_wgrad_multi_plan.  The summed partials equal the single-layer kernel's result to fp32 rounding and the
+    fp32 reference (same bf16 operands) to 2e-3; ``target`` = the length of the workgroup list the plan aims at (7: fewer
+    than the group's weight tiles - one workgroup per tile)."""
+    from oadg_amd import hip_conv
+    g = torch.Generator(device=dev).manual_seed(5)
+    jobs, refs, singles = [], [], []
+    for N, C, H, W, K, R, stride, pad, dil in _WG_SHAPES:
+        x = torch.randn(N, C, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        Ho = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (R - 1) - 1) // stride + 1
+        gy = torch.randn(N, K, Ho, Wo, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        jobs.append((x, gy, K, R, R, stride, pad, dil))
+        refs.append(torch.nn.grad.conv2d_weight(x.float(), (K, C, R, R), gy.float(), stride=stride, padding=pad, dilation=dil))
+        singles.append(hip_conv.conv_wgrad(x, gy, K, R, R, stride, pad, dil).float())
+    ws, parts = hip_conv.wgrad_multi(jobs, target_blocks=target)
+    torch.cuda.synchronize()
+    base = ws.data_ptr()
+    total = sum((K // 256) * (C // 256) * R * R * sp for (N, C, H, W, K, R, *_), (_, sp) in zip(_WG_SHAPES, parts))
+    tiles = sum((K // 256) * (C // 256) * R * R for (N, C, H, W, K, R, *_) in _WG_SHAPES)
+    assert total <= max(target, tiles)
+    if target >= 256:
+        assert max(sp for _, sp in parts) > 1
+    for (N, C, H, W, K, R, *_), (pp, sp), ref, single in zip(_WG_SHAPES, parts, refs, singles):
+        n = sp * K * R * R * C
+        part = ws[pp - base: pp - base + 4 * n].view(torch.float32).view(sp, K, R, R, C)
+        dw = part.sum(0).permute(0, 3, 1, 2)
+        scale = ref.abs().max().item()
+        assert (dw - ref).abs().max().item() <= 2e-3 * scale, (C, K, R)
+        assert (dw - single).abs().max().item() <= 2e-5 * scale, (C, K, R)
+
+
+def test_deferred_grouped_weight_gradients_in_a_backward_pass(dev, monkeypatch):
+    """hip_conv.DEFER_WGRAD (TrainEngine's backward): the weight gradients of the layers with small maps are collected
+    and launched in groups (csrc conv_wgrad256_multi_kernel + prep_weights_bwd_parts_multi_kernel); dW, dgamma and the
+    deferred column sums / raw BN-scale dot products they interact with arrive in the parameters' .grad.  Against the
+    immediate form: equal to fp32 rounding (other split counts, other summation order); run to run: bit-identical."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import ResNet
+    from oadg_amd.necks import FPN
+    hip_conv.enable(True)
+    calls = []
+    orig = hip_conv.wgrad_multi
+    monkeypatch.setattr(hip_conv, 'wgrad_multi', lambda jobs, **k: (calls.append(len(jobs)), orig(jobs, **k))[1])
+    monkeypatch.setattr(hip_conv, 'WGRAD_GROUP', 600)           # tiny maps here: a group every few layers
+    try:
+        torch.manual_seed(0)
+        bb = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                    norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch')
+        neck = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)
+        neck.init_weights()
+        net = torch.nn.ModuleList([bb, neck]).to(dev).to(memory_format=torch.channels_last)
+        net.train()
+        for m in bb.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+                torch.nn.init.normal_(m.bias, 0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.2)
+        g = torch.Generator(device=dev).manual_seed(1)
+        x = torch.randn(2, 3, 256, 384, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+        res, groups = {}, {}
+        for mode in ('immediate', 'deferred', 'deferred_again'):
+            net.zero_grad(set_to_none=True)
+            calls.clear()
+            hip_conv.begin_step(defer=mode != 'immediate')
+            assert hip_conv.DEFER_WGRAD == (mode != 'immediate')
+            try:
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    outs = neck(bb(x))
+                loss = sum((o.float() ** 2).mean() for o in outs)
+                loss.backward()
+            finally:
+                hip_conv.end_backward()
+            assert not hip_conv._WQ and not hip_conv._PENDING and not hip_conv.DEFER_WGRAD
+            torch.cuda.synchronize()
+            groups[mode] = list(calls)
+            res[mode] = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        assert groups['immediate'] == [] and len(groups['deferred']) >= 3 and sum(groups['deferred']) >= 30, groups
+        assert max(groups['deferred']) >= 4
+        assert set(res['immediate']) == set(res['deferred']) and len(res['immediate']) > 100
+        worst = 0.0
+        for n, a in res['immediate'].items():
+            b = res['deferred'][n]
+            assert torch.isfinite(b).all(), n
+            err = (a - b).abs().max().item() / (a.abs().max().item() + 1e-12)
+            worst = max(worst, err)
+            # (filters with C * R * S > 3000 - layer4's 3x3: the immediate form hands the weight gradient over in bf16,
+            #  oadg_prep_conv_weights_bwd; the grouped form keeps fp32 partials)
+            wide = a.dim() == 4 and a.shape[1] * a.shape[2] * a.shape[3] > 3000
+            assert err <= (5e-3 if wide else 1e-4), (n, err)
+            assert torch.equal(b, res['deferred_again'][n]), n
+        assert worst > 0.0          # (the groups really took other split counts)
+    finally:
+        hip_conv.enable(False)
+        hip_conv.DEFER_COLSUM = hip_conv.DEFER_WGRAD = False

@@ -83,11 +83,12 @@ def main():
     import oadg_amd
     from oadg_amd import Config, build_detector
     from oadg_amd.apis import (TrainEngine, StepLrSchedule, build_optimizer, get_dist_info, init_dist,
-                               init_random_seed, set_random_seed)
+                               init_random_seed, parse_optimizer_config, set_random_seed)
     from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
     cfg = Config.fromfile(a.config)
     if a.cfg_options:
         cfg.merge_from_dict(a.cfg_options)
+    opt_hook = parse_optimizer_config(cfg)       # grad_clip honoured; fp16 / custom hooks rejected by name, before any work
     work_dir = a.work_dir or cfg.get('work_dir') or os.path.join('./work_dirs',
                                                                  os.path.splitext(os.path.basename(a.config))[0])
     distributed = a.launcher != 'none'
@@ -138,7 +139,9 @@ def main():
                 print(f'[oadg] WARNING load_from: {e} -> continuing WITHOUT it (--allow-missing-pretrained)', flush=True)
     amp = torch.bfloat16 if a.amp == 'bf16' else None
     engine = TrainEngine(model, optimizer, distributed=distributed, amp_dtype=amp,
-                         find_unused_parameters=cfg.get('find_unused_parameters', False))
+                         find_unused_parameters=cfg.get('find_unused_parameters', False), **opt_hook)
+    if rank == 0 and opt_hook['grad_clip']:
+        print(f"optimizer_config.grad_clip: clip_grad_norm_({opt_hook['grad_clip']})", flush=True)
     sched = StepLrSchedule(optimizer, **cfg.get('lr_config', dict(policy='step', step=[1 << 30])))
     from oadg_amd.datasets import build_dataset
     ds = build_dataset(cfg.data.train, default_args=dict(seed=seed + rank, device=dev), synthetic_fallback=True)
