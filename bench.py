@@ -32,26 +32,44 @@ CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_o
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
-PROFILE_TAGS = ('r03', 'r02', 'r01')
+
+
+def newest_profile_tag():
+    """the newest round tag that has committed PMC summaries (profiles/rNN_pmc_FETCH_SIZE.json + _WRITE_SIZE.json)"""
+    import glob
+    import re
+    tags = set()
+    for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_FETCH_SIZE.json')):
+        m = re.match(r'(r\d+)_pmc_FETCH_SIZE\.json$', os.path.basename(f))
+        if m and os.path.exists(os.path.join(ROOT, 'profiles', f'{m.group(1)}_pmc_WRITE_SIZE.json')):
+            tags.add(m.group(1))
+    return max(tags, key=lambda t: int(t[1:])) if tags else None
+
+
+def rocprof_name(timer_name):
+    """kernel name as rocprofv3 prints it from a timer name of hip_conv (which may carry a '+reduce' / ' xN (...)' note)"""
+    return timer_name.split(' x')[0].replace('+reduce', '')
 
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of this same command
     (profiles/<tag>_pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter).  Counters are in
     KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide coalesced reads; WRITE_SIZE is
-    taken as reported (uncalibrated).  PMC counters cannot be collected from inside the timed run, so the value
-    is the latest committed measurement, with its source named; null when no summary is present."""
-    for tag in PROFILE_TAGS:                     # newest committed measurement first
-        try:
-            tot = 0.0
-            for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
-                rows = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_{c}.json')))
-                tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
-            return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
-                    'traffic_source': f'profiles/{tag}_pmc_FETCH_SIZE.json x2 + {tag}_pmc_WRITE_SIZE.json'}
-        except (OSError, StopIteration, KeyError, ValueError):
-            continue
-    return {'traffic': None}
+    taken as reported (uncalibrated).  PMC counters cannot be collected from inside the timed run, so the value is the
+    committed measurement of the NEWEST round only (a kernel that is not in it - renamed, new - reports null rather than
+    an older round's figure), with its source named."""
+    tag = newest_profile_tag()
+    if tag is None:
+        return {'traffic': None}
+    try:
+        tot = 0.0
+        for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
+            rows = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_{c}.json')))
+            tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
+        return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
+                'traffic_source': f'profiles/{tag}_pmc_FETCH_SIZE.json x2 + {tag}_pmc_WRITE_SIZE.json'}
+    except (OSError, StopIteration, KeyError, ValueError):
+        return {'traffic': None, 'traffic_note': f'{kernel} is not in profiles/{tag}_pmc_*.json'}
 
 
 def parse():
@@ -86,6 +104,13 @@ def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56, fwd=False):
     return float((49 * C * elem + 2 * 4 * C * foot).sum().item())
 
 
+def roi_tile_bwd_bytes(n_rois, n_imgs, height, width, strides, C, elem):
+    """what roi_align_bwd_tiles_kernel moves: every element of the dense gradient maps of the RoI levels written ONCE
+    (no fp32 maps, no read-modify-write) + each RoI's 7 x 7 x C gradient slab read once"""
+    maps = sum(n_imgs * (-(-height // s_)) * (-(-width // s_)) * C * elem for s_ in strides)
+    return float(maps + n_rois * 49 * C * elem)
+
+
 def family_of(kernel_name):
     """hip_conv.TIMERS_ONLY_VARIANT key of a kernel name recorded by hip_conv"""
     if kernel_name.startswith('conv_wgrad256'):
@@ -100,14 +125,15 @@ def family_of(kernel_name):
 
 
 FAMILIES = (('conv256 forward / data gradient', ('conv_igemm256_kernel',), 'mfma'),
-            ('weight gradient 256-tile', ('conv_wgrad256_kernel',), 'mfma'),
+            ('weight gradient 256-tile (single-layer launches + grouped multi-layer launches)',
+             ('conv_wgrad256_kernel', 'conv_wgrad256_multi_kernel'), 'mfma'),
             ('weight gradient 128-tile', ('conv_wgrad_kernel',), 'hbm'),
             ('pointwise streaming (1x1, C <= 256)', ('conv_pw_stream_kernel',), 'hbm'),
             ('128-tile convolution', ('conv_igemm_kernel',), 'mfma'))
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (xf32-free) MFMA peak
 
 
-def families_table(conv_timers, op_timers, roi_sets, steps, elem):
+def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
     """roofline.families: achieved rate of every hand-written kernel family the north star names, from HIP events
     recorded on the launch stream during ``steps`` extra steps after the timed region; PMC traffic (bytes per launch)
     from the committed rocprofv3 counter passes of this same command."""
@@ -127,11 +153,11 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem):
         else:
             e.update(achieved=round(by / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                      frac=round(by / ms / 1e6 / HBM_PEAK_GBS, 4), tflops=round(fl / ms / 1e9, 1))
-        tr = [pmc_traffic(n_.replace('+reduce', '')) for n_ in names]
-        tr = [t_ for t_ in tr if t_.get('traffic')]
+        tr = {rocprof_name(n_): pmc_traffic(rocprof_name(n_)) for n_ in names}
+        tr = {n_: t_ for n_, t_ in tr.items() if t_.get('traffic')}
         if tr:
-            e['traffic'] = {n_: t_['traffic'] for n_, t_ in zip(names, tr)}
-            e['traffic_source'] = tr[0]['traffic_source']
+            e['traffic'] = {n_: t_['traffic'] for n_, t_ in tr.items()}
+            e['traffic_source'] = next(iter(tr.values()))['traffic_source']
         out.append(e)
 
     def ms_of(key):
@@ -147,10 +173,17 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem):
         # forward: read the unique footprint in the map dtype, write 49 C elements
         rois_bytes['roi_align_fwd'].append(roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem, fwd=True))
     from oadg_amd import hip_ops as _ho
-    bwd_kernel = 'roi_align_bwd_tiles_kernel' if (_ho.BWD_TILES and elem == 2) else 'roi_align_bwd_kernel'
+    tiles = bool(_ho.BWD_TILES and elem == 2)
+    bwd_kernel = 'roi_align_bwd_tiles_kernel' if tiles else 'roi_align_bwd_kernel'
+    if tiles and geom is not None:
+        # the default bf16 backward organises the gradient by OUTPUT tiles: its algorithmic bytes are the dense maps written
+        # once + the slabs read once, NOT the SURVEY 8d scatter model (49 C read + fp32 read-modify-write of the footprint)
+        survey = list(rois_bytes['roi_align_bwd'])
+        rois_bytes['roi_align_bwd'] = [roi_tile_bwd_bytes(sum(r_.shape[0] for r_ in rs_), geom['n_imgs'], geom['height'],
+                                                          geom['width'], [4, 8, 16, 32], 256, elem)
+                                       for rs_ in roi_sets if rs_ is not None]
     for key, title in (('roi_align_fwd', 'RoIAlign forward'),
-                       ('roi_align_bwd', 'RoIAlign backward (%s; model bytes = SURVEY 8d: 49 C read + fp32 read-modify-write of '
-                                         'the footprint, which the tile kernel does not do)' % bwd_kernel)):
+                       ('roi_align_bwd', 'RoIAlign backward (%s)' % bwd_kernel)):
         rows = ms_of(key)
         if rows and rois_bytes[key]:
             ms = sum(r[0] for r in rows)
@@ -160,6 +193,9 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem):
                  'ms_per_step': round(ms / steps, 3), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
                  'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
                  'algorithmic_bytes_per_launch': int(by / len(rows))}
+            if key == 'roi_align_bwd' and tiles and geom is not None:
+                e['bytes_model'] = 'dense bf16 gradient maps of P2-P5 written once + 49 C bf16 per RoI read once'
+                e['survey_8d_scatter_model_bytes_per_launch'] = int(sum(survey) / len(survey))
             e.update({k: v for k, v in pmc_traffic(kname).items() if v})
             out.append(e)
     for key, title in (('supcon_fwd', 'OA-Loss supcon forward'), ('supcon_bwd', 'OA-Loss supcon backward')):
@@ -367,30 +403,33 @@ def main():
     for i in range(priming):
         step(i)
     mfma = a.conv == 'mfma' and amp is not None
-    probe = min(2, a.warmup) if mfma else 0
-    for i in range(a.warmup - probe):
+    for i in range(a.warmup):
         out = step(i)
-    # the last warm-up steps time EVERY convolution / weight-gradient launch (HIP events on the launch stream) to find the
-    # dominant hand-written kernel family of this run; the timed region then carries event pairs around that family only
-    # (all ~350 pairs per step cost ~1.5 ms per step), and the per-family table is measured on extra steps AFTER the
-    # timed region (same process, same data stream, not part of `value`)
-    dominant = None
-    if probe:
-        torch.cuda.synchronize()
-        hip_conv.TIMERS, hip_conv.TIMERS_ONLY_VARIANT = [], None
-        for i in range(a.warmup - probe, a.warmup):
-            out = step(i)
-        torch.cuda.synchronize()
-        tot = {}
-        for t in hip_conv.TIMERS:
-            tot[t[4]] = tot.get(t[4], 0.0) + t[0].elapsed_time(t[1])
-        dominant = max(tot.items(), key=lambda kv: kv[1])[0]
-        hip_conv.TIMERS = []
-        hip_conv.TIMERS_ONLY_VARIANT = family_of(dominant)
-        if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':
-            hip_conv.TIMERS_ONLY_VARIANT = None
+    # Live HIP events (on the launch stream) inside the timed region, arranged so that `roofline.kernel` is the same on every
+    # run: every SAMPLE_EVERY-th timed step carries event pairs around ALL launches of the two kernel families that can be
+    # the largest single kernel of the step - the 256-tile forward / data-gradient kernel and the 256-tile weight-gradient
+    # kernels (~90 pairs, ~0.4 ms on such a step, ~0.1 ms per step on average) - and the kernel with the largest total
+    # over those steps is reported (round 3 chose the family from a 2-step warm-up probe: two kernels within 5 % of each
+    # other swapped places from run to run).  The other families are measured on extra steps AFTER the timed region.
+    sample_every = int(os.environ.get('OADG_BENCH_SAMPLE_EVERY', 4))
+    sampled_steps = [0]
+    live = [] if mfma else None
     hip_ops.TIMERS = None
+    hip_conv.TIMERS = None
+    hip_conv.TIMERS_ONLY_VARIANT = None if os.environ.get('OADG_BENCH_DIAG_CONV') == '1' else (2, 'wgrad256')
+    plain_step = step
+
+    def step(i):                                # noqa: F811 (the timed region's step: the sampler around the plain one)
+        on = live is not None and (i - a.warmup) % sample_every == 0
+        hip_conv.TIMERS = live if on else None
+        sampled_steps[0] += int(on)
+        try:
+            return plain_step(i)
+        finally:
+            hip_conv.TIMERS = None
     dt, out = timed_region(step, a, distributed, dev, torch.cuda.synchronize)
+    step = plain_step
+    hip_conv.TIMERS = live
     conv_timers, hip_conv.TIMERS = hip_conv.TIMERS, None
     loss = float(out['loss'])
     assert np.isfinite(loss), 'training diverged'
@@ -419,10 +458,11 @@ def main():
     #      takes the most time per step.  Algorithmic FLOPs per launch = 2*M*K*R*S*C summed over the launches / number of
     #      launches, divided by the mean launch duration.
     elem = 2 if amp is not None else 4
+    n_s = max(sampled_steps[0], 1)
     if conv_timers:
         per_kernel = {}
         for t in conv_timers:
-            per_kernel.setdefault(t[4], []).append((t[0].elapsed_time(t[1]), t[2], t[3]))
+            per_kernel.setdefault(rocprof_name(t[4]), []).append((t[0].elapsed_time(t[1]), t[2], t[3]))
         name, rows = max(per_kernel.items(), key=lambda kv: sum(r[0] for r in kv[1]))   # the dominant one
         ms = [r[0] for r in rows]
         avg_ms, per_launch = sum(ms) / len(ms), sum(r[1] for r in rows) / len(rows)
@@ -432,30 +472,32 @@ def main():
                 'traffic': None, 'avg_launch_ms': round(avg_ms, 4), 'launches': len(ms),
                 'algorithmic_flops_per_launch': int(per_launch),
                 'algorithmic_bytes_per_launch': int(sum(r[2] for r in rows) / len(rows)),
-                'launches_per_step': round(len(ms) / a.steps, 1),
-                'kernel_ms_per_step': round(sum(ms) / a.steps, 2),
-                'other_conv_kernels': {k: {'launches_per_step': round(len(v) / a.steps, 1),
-                                           'ms_per_step': round(sum(r[0] for r in v) / a.steps, 2),
+                'launches_per_step': round(len(ms) / n_s, 1),
+                'kernel_ms_per_step': round(sum(ms) / n_s, 2),
+                'timed_steps': f'{n_s} of the {a.steps} steps of the timed region (every {sample_every}th)',
+                'other_conv_kernels': {k: {'launches_per_step': round(len(v) / n_s, 1),
+                                           'ms_per_step': round(sum(r[0] for r in v) / n_s, 2),
                                            'achieved': round(sum(r[1] for r in v) / sum(r[0] for r in v) / 1e9, 1)}
                                        for k, v in per_kernel.items() if k != name}}
         # the family mixes shapes (3x3 at P2 ... P4 / layer3 and a few HBM-bound 1x1 launches): its heaviest shape alone
         shp_ = {}
         for t in conv_timers:
-            if t[4] == name:
+            if rocprof_name(t[4]) == name:
                 e = shp_.setdefault(t[5], [0, 0.0, 0.0])
                 e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]
         if shp_:
             k_, e = max(shp_.items(), key=lambda kv: kv[1][1])
-            roof['heaviest_shape'] = {'N,H,W,C,K,R,stride': list(k_[:7]), 'launches_per_step': round(e[0] / a.steps, 1),
+            roof['heaviest_shape'] = {'N,H,W,C,K,R,stride': list(k_[:7]), 'launches_per_step': round(e[0] / n_s, 1),
                                       'avg_launch_ms': round(e[1] / e[0], 4),
                                       'achieved': round(e[2] / e[1] / 1e9, 1),
                                       'frac': round(e[2] / e[1] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
-        roof.update(pmc_traffic(name.replace('+reduce', '')))
+        roof.update(pmc_traffic(name))
     else:
         roof = {'kernel': None, 'bound': 'mfma', 'achieved': None, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': None, 'traffic': None, 'note': 'library convolutions (--conv miopen / fp32): no own conv kernel timed'}
     if diag_steps:
-        roof['families'] = families_table(diag_conv, diag_ops, roi_sets, diag_steps, elem)
+        roof['families'] = families_table(diag_conv, diag_ops, roi_sets, diag_steps, elem,
+                                          geom=dict(n_imgs=2 * a.batch, height=a.height, width=a.width))
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':      # per-shape table of the conv launches (stderr)
             shp = {}
             for t in diag_conv:

@@ -27,6 +27,19 @@ def _adjacent_views(views):
     return parent
 
 
+_LOG_PAD = {}
+
+
+def _log_pad(like, n_names, slots=31):
+    """[zeros(max(0, slots - n_names)), float(n_names)] on ``like``'s device (cached constants: no fill launch per step)"""
+    key = (like.device, like.dtype, n_names)
+    t = _LOG_PAD.get(key)
+    if t is None:
+        t = _LOG_PAD[key] = torch.cat([torch.zeros(max(0, slots - n_names), dtype=like.dtype),
+                                       torch.full((1,), float(n_names), dtype=like.dtype)]).to(like.device)
+    return t
+
+
 def integrate_data(data, train_cfg):
     """base.py:22-48: concatenate the views along the batch axis (all originals first, then all OA-Mix
     images) and extend/duplicate the per-image lists to match; inject ``num_views`` / ``batch_size``."""
@@ -132,10 +145,13 @@ class BaseDetector(nn.Module):
         if distributed:
             # base.py:258-265 checks that every rank logs the same variables; the count rides in the same
             # all-reduce and is verified without a per-step host synchronisation (see _check_log_count)
-            packed = torch.cat([packed, packed.new_full((1,), float(len(names)))])
+            # The vector has a FIXED length (values, zero padding to 31 slots, count): should the ranks ever disagree on
+            # their keys, the collective still matches in size and the assertion below reports it - the reference
+            # reduces the count in a collective of its own first for the same reason (base.py:258-265)
+            packed = torch.cat([packed, _log_pad(packed, len(names))])
             dist.all_reduce(packed)
             expect = len(names) * dist.get_world_size()
-            count, packed = packed[-1], packed[:-1] / dist.get_world_size()
+            count, packed = packed[-1], packed[:len(names)] / dist.get_world_size()
         if getattr(self, 'log_vars_on_host', True):
             if distributed:
                 vals = torch.cat([packed, count.view(1)]).tolist()          # one host read

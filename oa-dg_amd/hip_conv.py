@@ -374,13 +374,25 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
                        2.0 * (N * H * W * C + K * C * R * S +
                               N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None)) +
                               N * Ho * Wo * K / 16.0 * ((mask_bits is not None) + (bits_out is not None))),
-                       ('conv_igemm256_kernel<%s>' if v == 2 else 'conv_pw_stream_kernel<%s>' if v == 4 else
-                        ('conv_igemm_kernel<%d, %%s, %d>' % (128 if K % 128 == 0 else 64, 1 if v == 3 else 2)))
-                       % ('true' if (residual is not None or mask is not None or mask_bits is not None) else 'false'),
+                       kernel_name(v, C, K, R, S, stride, pad, residual is not None, mask is not None, mask_bits is not None,
+                                   bits_out is not None),
                        (N, H, W, C, K, R, stride, residual is not None, mask is not None)))
     if want_colsum:
         return y, _colsum(part, K)
     return y
+
+
+def kernel_name(v, C, K, R, S, stride, pad, res, mask, bits_in, bits_out, scatter=False):
+    """the instantiation csrc conv_launch runs for variant ``v`` with these operands, spelt as rocprofv3 prints it (minus
+    namespace and argument list): bench.py keys its live timers and the committed PMC summaries on this string"""
+    b = lambda f: 'true' if f else 'false'  # noqa: E731
+    post = res or mask or bits_in
+    if v == 2:
+        return 'conv_igemm256_kernel<%s>' % b(post)
+    if v == 4:
+        return 'conv_pw_stream_kernel<%d, %s, %s, %s>' % (C, b(res), b(bits_in), b(bits_out))
+    pw = v == 3 and R == 1 and S == 1 and stride == 1 and pad == 0 and not scatter
+    return 'conv_igemm_kernel<%d, %s, %d, %s>' % (128 if K % 128 == 0 else 64, b(post), 1 if v == 3 else 2, b(pw))
 
 
 _S2_CLASSES = ((0, 0, 1, 1, 0), (0, 1, 1, 2, 1), (1, 0, 2, 1, 3), (1, 1, 2, 2, 5))    # ph, pw, taps_h, taps_w, block offset
@@ -412,6 +424,10 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
             geo.append((ph, pw, th, tw, off, ha, wa, (N * ha * wa + 127) // 128))
     part = torch.empty((sum(g[-1] for g in geo), C), dtype=torch.float32, device=gy.device) if want_colsum else None
     row = 0
+    timed = _timed(3)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     for ph, pw, th, tw, off, ha, wa, tiles in geo:
         wptr = ctypes.c_void_p(wt.data_ptr() + off * C * K * 2)
         pptr = ctypes.c_void_p(part.data_ptr() + row * C * 4) if part is not None else None
@@ -419,6 +435,17 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
                                               th, tw, 0, 1, 0, ha, wa, H, W, 2, 2, ph, pw, ptr(mask), pptr,
                                               ptr(mask_bits), stream_ptr()), 'oadg_conv2d_nhwc_bf16_scatter')
         row += tiles
+    if timed:
+        # the class launches of one stride-2 data gradient as ONE entry: 2 * (output pixels of the forward conv) * K * C
+        # * R * S FLOP (no zero-inserted dy), dy + the class filters read, dx (+ residual / mask) touched once
+        e1.record()
+        post = accumulate is not None or mask is not None or mask_bits is not None
+        TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * R,
+                       2.0 * (N * Ho * Wo * K + K * C * R * R + N * H * W * C * (1 + (accumulate is not None) + (mask is not None)))
+                       + N * H * W * C / 8.0 * (mask_bits is not None),
+                       kernel_name(3, K, C, 2, 2, 1, 0, accumulate is not None, mask is not None, mask_bits is not None, False,
+                                   scatter=True) + ' x%d (stride-2 dgrad classes)' % len(geo),
+                       (N, Ho, Wo, K, C, R, 2, accumulate is not None, mask is not None)))
     if want_colsum:
         return gx, _colsum(part, C)
     return gx

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q, torch_ddp=False):
+def _worker(rank, world, port, q, torch_ddp=False, sparse_rank1=False):
     os.environ['OADG_USE_TORCH_DDP'] = '1' if torch_ddp else '0'
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -32,6 +32,15 @@ def _worker(rank, world, port, q, torch_ddp=False):
     det.train()
     eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=True)
     b = model_batch(10 + rank, 1, 192, 320, n_gt=6)          # different data on each rank
+    if sparse_rank1 and rank == 1:
+        # ONE small object: a handful of foreground RoIs (the gt itself per view) <= ContrastiveLossPlus.min_samples = 10,
+        # the state in which the reference skips the contrastive branch (contrastive_head.py:123-129)
+        b['gt_bboxes'] = [np.array([[40., 30., 52., 44.]], np.float32)]
+        b['gt_labels'] = [np.array([2], np.int64)]
+    order = []
+    if eng.reducer is not None:
+        orig = eng.reducer._launch
+        eng.reducer._launch = lambda bk: (order.append([x is bk for x in eng.reducer.buckets].index(True)), orig(bk))[1]
     shape = b['img'].shape[2:] + (3,)
     t = torch.tensor
     data = dict(img=t(b['img']), img2=t(b['img2']), gt_bboxes=[t(x) for x in b['gt_bboxes']],
@@ -45,8 +54,14 @@ def _worker(rank, world, port, q, torch_ddp=False):
     p = torch.cat([q_.detach().flatten()[:64] for q_ in det.parameters() if q_.requires_grad])
     g = det.roi_head.bbox_head.fc_cls.weight.grad.detach().flatten()[:256].clone()
     lv = out['log_vars']
+    extra = None
+    if sparse_rank1:
+        fc = det.roi_head.bbox_head.fc_cont[0]
+        lab = det.roi_head.bbox_head.roi_targets[0]
+        extra = (order, int((lab != lab.max()).sum()),
+                 fc.weight.grad.detach().flatten()[:512].clone().numpy(), len(eng.reducer.buckets))
     q.put((rank, p.numpy(), g.numpy(), dict(lv), float(out['loss']),
-           bool((det.roi_head.bbox_head.fc_cls.weight.detach() != w0).any())))
+           bool((det.roi_head.bbox_head.fc_cls.weight.detach() != w0).any()), extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -147,7 +162,7 @@ def test_two_rank_data_parallel_step(torch_ddp):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, p0, g0, lv0, l0, ch0), (_, p1, g1, lv1, l1, ch1) = res
+    (_, p0, g0, lv0, l0, ch0, _x0), (_, p1, g1, lv1, l1, ch1, _x1) = res
     assert ch0 and ch1, 'the optimizer step changed nothing'
     assert np.array_equal(g0, g1), 'gradients were not all-reduced to the same mean'
     assert np.array_equal(p0, p1), 'parameters diverged across ranks'
@@ -186,3 +201,63 @@ def test_flat_reducer_layout_helpers_and_tail_bucket(monkeypatch):
     assert sizes[-1] * 4 <= (1 << 20) and red.buckets[-1]['params'][-1] is list(net.parameters())[0]
     for q in net.parameters():
         assert red.views[q].shape == q.shape and red.views[q].stride() == q.stride()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_step_when_one_rank_has_no_foreground_for_the_contrastive_loss():
+    """rank 1's image holds one small object, so its sampled RoIs carry fewer foreground rows than
+    ContrastiveLossPlus.min_samples - the state in which the reference drops ``loss_cont`` from the dict
+    (contrastive_head.py:123-129; its ranks would then fail the key-count assertion of base.py:258-265).  Here the
+    key stays (value 0 on that rank, the rule is applied inside the loss kernel), so both ranks build the same graph:
+    the gradient buckets are all-reduced in the SAME order on both ranks, the contrastive branch's parameters
+    receive the mean of rank 0's gradient and zero, and the replicas stay identical."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, False, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, 540)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, p0, g0, lv0, l0, ch0, x0), (_, p1, g1, lv1, l1, ch1, x1) = res
+    (order0, fg0, cont0, nb0), (order1, fg1, cont1, nb1) = x0, x1
+    assert nb0 == nb1 == 4
+    assert fg1 <= 10 < fg0, (fg0, fg1)      # rank 1 is below min_samples (contrastive_head.py:125), rank 0 above
+    assert order0 == order1 == list(range(nb0)), (order0, order1)
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1) and np.array_equal(cont0, cont1)
+    assert lv0.keys() == lv1.keys() and 'loss_cont' in lv0
+    assert np.abs(cont0).max() > 0          # rank 0's contrastive gradient arrived on both ranks (halved by the mean)
+
+
+def test_bucket_plan_on_the_real_parameter_sets(monkeypatch):
+    """FlatGradReducer on the parameters of the two benchmarked detectors (no process group needed
+    for the plan).  R50-FPN OA-DG, 64 MiB buckets: 68.9 / 67.2 / 24.4 / 5.4 MB (= 65.7 / 64.1 / 23.3 / 5.2 MiB), the
+    RoI head + neck first, the 5.4 MB tail = the first trainable backbone stage (ready last).  R101-DC5 OA-DG with
+    OADG_BUCKET_MB=128: FIVE buckets - the 100352 x 1024 FC weight is one 411 MB tensor and cannot be split, so the first
+    bucket (RoI head) is 416.7 MB and is the first collective of the backward pass."""
+    import oadg_amd  # noqa: F401
+    from oadg_amd import Config, apis, build_detector
+    monkeypatch.setattr(apis.dist, 'get_world_size', lambda g=None: 1)
+    monkeypatch.setattr(apis.dist, 'broadcast', lambda *a, **k: None)
+    plans = {}
+    for name, cfgf, mb in (('r50', 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py', 64),
+                           ('dc5', 'configs/oadg/faster_rcnn_r101_dc5_1x_dwd_oadg.py', 128)):
+        det = build_detector(Config.fromfile(os.path.join(ROOT, cfgf)).model)
+        red = apis.FlatGradReducer(det, bucket_mb=mb)
+        names = {p: n for n, p in det.named_parameters()}
+        plans[name] = ([round((b['end'] - b['start']) * 4 / 1e6, 1) for b in red.buckets],
+                       [(names[b['params'][0]], names[b['params'][-1]]) for b in red.buckets])
+        trainable = [p for p in det.parameters() if p.requires_grad]
+        assert sum(b['end'] - b['start'] for b in red.buckets) == sum(p.numel() for p in trainable) == red.flat.numel()
+        assert [p for b in red.buckets for p in b['params']] == trainable[::-1]      # reverse registration order
+        for p in trainable:
+            assert red.views[p].shape == p.shape and red.views[p].stride() == p.stride()
+        del det, red
+    sizes, ends = plans['r50']
+    assert sizes == [68.9, 67.2, 24.4, 5.4], sizes
+    assert ends[0][0].startswith('roi_head.bbox_head.fc_cont') and ends[-1][1] == 'backbone.layer2.0.conv1.weight'
+    sizes, ends = plans['dc5']
+    assert sizes == [416.7, 151.6, 134.5, 28.8, 5.4], sizes
+    assert ends[0][1] == 'roi_head.bbox_head.shared_fcs.0.weight' and ends[-1][1] == 'backbone.layer2.0.conv1.weight'
