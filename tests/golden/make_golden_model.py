@@ -156,10 +156,50 @@ def main_test(h=256, w=512, n_img=2, seed=0):
           [[len(a) for a in r] for r in results])
 
 
+def aug_inputs(seed=0, h=256, w=512):
+    """the four test-time augmentations of ONE seeded image, as MultiScaleFlipAug(img_scale=[(w, h), (1.25 w, 1.25 h)],
+    flip=True) orders them: (scale 1, no flip), (scale 1, horizontal flip), (scale 1.25, no flip), (scale 1.25, flip).
+    The larger view is torch's bilinear interpolation of the first (deterministic on the CPU) - aug_test's arithmetic does
+    not care how the views were made, the fixture pins what it does with them."""
+    import torch.nn.functional as F
+    img = torch.tensor(model_batch(seed, 1, h, w)['img'])
+    big = F.interpolate(img, size=(int(h * 1.25), int(w * 1.25)), mode='bilinear', align_corners=False)
+    imgs, metas = [], []
+    for t, sf in ((img, 1.0), (big, 1.25)):
+        for flip in (False, True):
+            imgs.append(t.flip(3) if flip else t)
+            metas.append([dict(img_shape=tuple(t.shape[2:]) + (3,), pad_shape=tuple(t.shape[2:]) + (3,),
+                               ori_shape=(h, w, 3), scale_factor=np.full(4, sf, dtype=np.float32), flip=flip,
+                               flip_direction='horizontal' if flip else None, ori_filename='0.png')])
+    return imgs, metas
+
+
+def main_aug_test(h=256, w=512, seed=0):
+    """Test-time augmentation: reference ``TwoStageDetector.aug_test`` (two_stage.py:268-277) -> ``aug_test_rpn`` +
+    ``merge_aug_proposals`` (dense_test_mixins.py:135-167, merge_augs.py:13-83) -> ``aug_test_bboxes`` +
+    ``merge_aug_bboxes`` (test_mixins.py:139-177, merge_augs.py:86-112) -> ``multiclass_nms`` -> ``bbox2result`` on four
+    augmentations of one seeded image, name-seeded weights, eval mode, rescale=True."""
+    det = build_reference_detector()
+    load_named(det)
+    det.eval()
+    imgs, metas = aug_inputs(seed, h, w)
+    with torch.no_grad():
+        feats = det.extract_feats(imgs)
+        props = det.rpn_head.aug_test_rpn(feats, metas)
+        results = det.aug_test(imgs, metas, rescale=True)
+    out = dict(h=np.int64(h), w=np.int64(w), seed=np.int64(seed), merged_proposals=props[0].numpy().copy())
+    for c, arr in enumerate(results[0]):
+        out[f'det_c{c}'] = np.asarray(arr, dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, f'model_aug_test_{h}x{w}.npz'), **out)
+    print('wrote', f'model_aug_test_{h}x{w}.npz', props[0].shape, [len(a) for a in results[0]])
+
+
 if __name__ == '__main__':
     mode = sys.argv[1] if len(sys.argv) > 1 else 'step'
     if mode == 'test':
         main_test()
+    elif mode == 'aug':
+        main_aug_test()
     elif mode == 'full':       # SURVEY 8c G7 at BASELINE config 1's real shape (N=2, 1024x2048): ~2 min, 13.5 GB here
         main(1024, 2048, samples=False)
     elif mode == 'dc5':        # BASELINE configs[3] (R101-DC5 OA-DG): 17,280 anchors > nms_pre 12,000 > split_thr 10,000
