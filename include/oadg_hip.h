@@ -267,6 +267,22 @@ int oadg_oamix_bbox_plan(int kind, double severity, const long long* ib, const i
 int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* steps_dev, const int* tile_prefix_dev,
                           const int* level_first_host, int n_levels, const int* tile_prefix_host, const float* My,
                           const float* Mx, uint8_t* scratch, void* stream);
+/* the chains of several images advanced in lockstep: level l of every chain in ONE launch pair (the images of a batch
+ * are independent; launches per batch = 2 x the deepest chain).  One descriptor per image with the operands of
+ * oadg_oamix_bbox_chain; images and scratch buffers pairwise distinct.  Byte-identical to n calls of
+ * oadg_oamix_bbox_chain. */
+typedef struct {
+    uint8_t* img;
+    const oadg_bbox_step* steps_dev;
+    const int* tile_prefix_dev;
+    const int* level_first_host;
+    const int* tile_prefix_host;
+    const float* My;
+    const float* Mx;
+    uint8_t* scratch;
+    int H, W, n_levels, pad_;
+} oadg_bbox_chain;
+int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void* stream);
 int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
                        const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,
                        const uint8_t* union_u8, float* acc, float acc_w, int acc_mode, void* stream);

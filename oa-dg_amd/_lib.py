@@ -137,6 +137,7 @@ SIGNATURES = {
     'oadg_oamix_bbox_plan_bytes': (cs, [ci]),
     'oadg_oamix_bbox_plan': (ci, [ci, cd, vp, vp, ci, vp, ci, ci, ci, vp, cs, vp, vp, vp]),
     'oadg_oamix_bbox_chain': (ci, [vp, ci, ci, vp, vp, POINTER(ci), ci, POINTER(ci), vp, vp, vp, vp]),
+    'oadg_oamix_bbox_chain_multi': (ci, [vp, ci, vp]),
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
                               ci, vp]),

@@ -364,9 +364,16 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
 // Epilogue per wave: accumulators + bias -> bf16 rows [pixel][64 channels] in a private staging area (padded rows) ->
 // 16-byte pieces -> finish_piece (residual, ReLU, mask bits, column sums, bits out) -> 128-byte row segments to HBM.
 // Results equal the 128-tile kernel's bit for bit (same products, same fp32 summation order per output).
+// Round 4, the READ-HEAVY mirror (C = 512: ResNet conv1 of stage 2 / 3 / 4 inputs, the data gradient of their conv3, the P3
+// lateral): the register budget of a wave holds the weights of 32 output channels x 512 (128 VGPRs, as 64 x 256 does), so
+// a workgroup covers 128 output channels and K / 128 workgroup columns share a pixel range; the pixel ring is 16 pixels x
+// 1 KiB wide.  Same schedule, same epilogue (four lanes per pixel instead of eight), bit-identical to the tile kernel.
 template <int C>
 struct PwGeo {
-    static constexpr int KPW = 64, SP = (C >= 256 ? 16 : 32), NS = (C >= 256 ? 8 : 4), NP = SP / 8, SLOTS = C / 8;
+    static constexpr int KPW = (C >= 512 ? 32 : 64);          // output channels per wave (weights stationary in registers)
+    static constexpr int SP = (C >= 256 ? 16 : 32), NS = (C == 256 ? 8 : 4), SLOTS = C / 8;
+    static constexpr int LPP = KPW / 8;                        // lanes (16-byte pieces) per pixel row of a wave's staging area
+    static constexpr int PPP = 64 / LPP, NP = SP / PPP;        // pixels per epilogue pass, passes per sub-tile
     static constexpr int SUB_BYTES = SP * C * 2, G = SUB_BYTES / 4096;
     static constexpr int RT = KPW / 16, CT = SP / 16, KS = C / 32, STG_STRIDE = KPW * 2 + 16, STG_BYTES = SP * STG_STRIDE;
     static constexpr int LDS = NS * SUB_BYTES + 4 * STG_BYTES + 4 * KPW * 4;
@@ -379,6 +386,7 @@ template <int C, bool RES, bool BIN, bool BOUT>
 __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int ncol) {
     using Geo = PwGeo<C>;
     constexpr int KPW = Geo::KPW, SP = Geo::SP, NS = Geo::NS, NP = Geo::NP, SLOTS = Geo::SLOTS, SUB_BYTES = Geo::SUB_BYTES;
+    constexpr int LPP = Geo::LPP, PPP = Geo::PPP;
     constexpr int G = Geo::G, RT = Geo::RT, CT = Geo::CT, KS = Geo::KS, STG_STRIDE = Geo::STG_STRIDE, STG_BYTES = Geo::STG_BYTES;
     // vector-memory operations per sub-tile and wave: G LDS-DMA loads, R operand loads, S stores
     constexpr int R = (RES ? NP : 0) + (BIN ? NP : 0), S = NP + (BOUT ? NP : 0);
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 wf[rt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)(kcol + rt * 16 + fr) * C + ks * 32 + fq * 8);
-        sbias[lane] = a.bias ? a.bias[kcol + lane] : 0.f;
+        if (lane < KPW) sbias[lane] = a.bias ? a.bias[kcol + lane] : 0.f;
 
         // ---- loader geometry (constant over sub-tiles).  The LDS image of an LDS-DMA instruction is lane-linear, so the
         // bank-conflict swizzle (16-byte slot ^ f(pixel)) is applied on the global source address
@@ -435,11 +443,11 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
             bbase[ct] = px * (C * 2);
             bsw[ct] = (fq ^ (C == 64 ? ((px >> 1) & 7) : (px & 15))) << 4;
         }
-        // epilogue pieces of this lane: pixel lane / 8 + 8 * jj, 16-byte slot lane % 8 of the wave's 64 channels
-        const int ppx = lane >> 3, psl = lane & 7;
+        // epilogue pieces of this lane: pixel lane / LPP + PPP * jj, 16-byte slot lane % LPP of the wave's KPW channels
+        const int ppx = lane / LPP, psl = lane % LPP;
         // element offset of a piece = (uniform) sub-tile and piece-row terms + this lane's term: no vector multiplies
         const size_t lane_off = (size_t)ppx * a.K + kcol + psl * 8;
-        const size_t sub_stride = (size_t)SP * a.K, row8 = (size_t)8 * a.K;
+        const size_t sub_stride = (size_t)SP * a.K, row8 = (size_t)PPP * a.K;
         bf16x8 rv[2][NP];
         unsigned mb[2][NP];
         auto request = [&](long sub, int set) {     // residual / mask bits of sub-tile `sub` -> register set `set`
@@ -462,8 +470,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
         auto body = [&](int i, auto set_c) {
             constexpr int set = decltype(set_c)::value;
             const long sub = range + i * ranges;
-            // sub-tile i landed: everything issued after its DMA may stay in flight (pipeline fill: drain)
-            if (i < NS - 1) OADG_VMCNT(0); else OADG_VMCNT((NS - 2) * G + (NS - 1) * (R + S));
+            // sub-tile i landed: everything issued after its DMA may stay in flight (the pipeline fill was drained before
+            // the loop, so the same count holds from the first iteration on)
+            OADG_VMCNT((NS - 2) * G + (NS - 1) * (R + S));
             asm volatile("s_barrier" ::: "memory");     // ... for every wave; and slot (i - 1) % NS has been read by all
             stage(sub + (NS - 1) * ranges, (i + NS - 1) % NS);
             request(sub + ranges, set ^ 1);
@@ -501,6 +510,9 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
                     *reinterpret_cast<bf16x4*>(stg + (ct * 16 + fr) * STG_STRIDE + (rt * 16 + fq * 4) * 2) = o;
                 }
             }
+            // the wave re-reads its staging rows as 16-byte pieces: order the compiler's view of the two access shapes
+            // (LDS executes a wave's operations in issue order)
+            asm volatile("" ::: "memory");
             if (POST) {
                 // the operands of THIS sub-tile (requested one sub-tile ago); what was issued since stays in flight
                 OADG_VMCNT(S + G + R);
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
             }
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
-                const int px = ppx + 8 * jj;
+                const int px = ppx + PPP * jj;
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + px * STG_STRIDE + psl * 16);
                 const size_t off = (size_t)sub * sub_stride + jj * row8 + lane_off;
                 v = finish_piece<POST>(a, v, RES ? rv[set][jj] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, bf16x8{0, 0, 0, 0, 0, 0, 0, 0},
@@ -520,19 +532,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
                 asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(a.y + off), "v"(v) : "memory");
             }
         };
+        OADG_VMCNT(0);                              // the first NS - 1 sub-tiles and the first operands have landed
         for (int i = 0; i < n_it; i += 2) {         // two bodies per trip: the register set index is a constant
             body(i, std::integral_constant<int, 0>{});
             if (i + 1 < n_it) body(i + 1, std::integral_constant<int, 1>{});
         }
     }
-    if (a.colsum) {     // one row of partial column sums per pixel range: lanes l, l + 8, ... share a channel slot
+    if (a.colsum) {     // one row of partial column sums per pixel range: lanes l, l + LPP, ... share a channel slot
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float t = csum[e];
-            t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+#pragma unroll
+            for (int sh = LPP; sh < 64; sh <<= 1) t += __shfl_xor(t, sh, 64);
             csum[e] = t;
         }
-        if (lane < 8) {
+        if (lane < LPP) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) a.colsum[(size_t)range * a.K + kcol + lane * 8 + e] = csum[e];
         }
@@ -541,8 +555,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
 
 // geometry test of the streaming pointwise kernel (the operands are tested by the launcher): pixel ranges, or 0
 long pw_stream_ranges(long M, int C, int K, int R, int S, int stride, int pad) {
-    if (R != 1 || S != 1 || stride != 1 || pad != 0 || (C != 64 && C != 128 && C != 256) || K % 256 != 0) return 0;
-    const int ncol = K / 256, sp = C >= 256 ? 16 : 32;
+    if (R != 1 || S != 1 || stride != 1 || pad != 0 || (C != 64 && C != 128 && C != 256 && C != 512)) return 0;
+    const int kwg = C >= 512 ? 128 : 256;                       // output channels per workgroup (4 waves x KPW)
+    if (K % kwg != 0) return 0;
+    const int ncol = K / kwg, sp = C >= 256 ? 16 : 32;
     if (ncol > 64 || (64 % ncol) != 0 || M % sp != 0) return 0;
     const long ranges = 512 / ncol;
     return (M / sp) >= 8 * ranges ? ranges : 0;                 // at least 8 sub-tiles per workgroup
@@ -551,7 +567,7 @@ long pw_stream_ranges(long M, int C, int K, int R, int S, int stride, int pad) {
 template <int C>
 int launch_pw_stream(const ConvArgs& a, hipStream_t st) {
     using Geo = PwGeo<C>;
-    const int ncol = a.K / 256;
+    const int ncol = a.K / (4 * Geo::KPW);
     const bool res = a.res != nullptr, bin = a.bits_in != nullptr, bout = a.bits_out != nullptr;
 #define OADG_PWS(RE, BI, BO)                                                                                       \
     do {                                                                                                           \
@@ -930,6 +946,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
         if (C == 64) rc = launch_pw_stream<64>(a, (hipStream_t)stream);
         else if (C == 128) rc = launch_pw_stream<128>(a, (hipStream_t)stream);
         else if (C == 256) rc = launch_pw_stream<256>(a, (hipStream_t)stream);
+        else if (C == 512) rc = launch_pw_stream<512>(a, (hipStream_t)stream);
         if (rc != OADG_OK) return rc;
         OADG_LAUNCH_CHECK();
         return OADG_OK;

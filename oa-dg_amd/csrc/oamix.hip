@@ -421,6 +421,44 @@ __global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restric
     copy_tile(img, W, steps, tile_prefix, first, count, tile_base + (blockIdx.x >> 2), blockIdx.x & 3, scratch);
 }
 
+// ---- the chains of SEVERAL images in lockstep (round 4) -----------------------------------------------------------------
+// The images of a batch are augmented independently (own work image, own mask profiles, own scratch), and a
+// bboxes_only_* chain needs its launch pair per dependency level only because of the dependencies INSIDE its image.  The
+// pipeline therefore advances the chains of all images of the batch together: level l of every chain in ONE launch pair -
+// launches per batch = 2 x the deepest chain instead of 2 x the sum over the images.  Up to 8 images per launch; their
+// descriptors travel by value in the launch arguments and are selected with compile-time indices only (a dynamically
+// indexed argument block would be copied to scratch memory per thread).
+struct ChainImg {
+    uint8_t* img;
+    const oadg_bbox_step* steps;
+    const int* tile_prefix;
+    const float* My;
+    const float* Mx;
+    uint8_t* scratch;
+    int H, W, first, count, tile_base, block0;        // block0: first workgroup of this image in the launch (blend tiles)
+};
+struct ChainLevel {
+    ChainImg im[8];
+    int n;
+};
+__device__ __forceinline__ ChainImg pick_image(const ChainLevel& a, int tile) {
+    ChainImg s = a.im[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+        if (k < a.n && tile >= a.im[k].block0) s = a.im[k];
+    return s;
+}
+__global__ __launch_bounds__(256) void bbox_blend_imgs_kernel(ChainLevel a) {
+    const ChainImg s = pick_image(a, blockIdx.x);
+    blend_tile(s.img, s.H, s.W, s.steps, s.tile_prefix, s.first, s.count, s.tile_base + (blockIdx.x - s.block0), s.My, s.Mx,
+               s.scratch);
+}
+__global__ __launch_bounds__(256) void rect_copy_imgs_kernel(ChainLevel a) {
+    const int tile = blockIdx.x >> 2;
+    const ChainImg s = pick_image(a, tile);
+    copy_tile(s.img, s.W, s.steps, s.tile_prefix, s.first, s.count, s.tile_base + (tile - s.block0), blockIdx.x & 3, s.scratch);
+}
+
 // (Round 3 experiment, removed: the whole level chain of an op as ONE persistent launch - a fixed set of workgroups on one
 // XCD walking the levels with grid barriers in between.  It is bit-exact, but slower than the launch pair per level:
 // `buffer_inv sc0` does not drop a compute unit's L1 lines outside threadgroup-split mode (14 of 16 bit-exactness cases
@@ -987,6 +1025,52 @@ int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* step
         hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles * 4), dim3(256), 0, st, img, W, steps_dev,
                            tile_prefix_dev, first, count, tile_base, (const uint8_t*)scratch);
         OADG_LAUNCH_CHECK();
+    }
+    return OADG_OK;
+}
+
+// n chains (one per image, each with the operands of oadg_oamix_bbox_chain) advanced level by level together: level l of
+// all chains that have one = one launch pair.  Per image the same kernels' arithmetic in the same order as
+// oadg_oamix_bbox_chain: byte-identical images.  The images, scratch buffers and tables must be pairwise distinct.
+int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void* stream) {
+    if (!chains_host || n < 1) return OADG_EARG;
+    int deepest = 0;
+    for (int i = 0; i < n; ++i) {
+        const oadg_bbox_chain& c = chains_host[i];
+        if (!c.img || !c.steps_dev || !c.tile_prefix_dev || !c.level_first_host || !c.tile_prefix_host || !c.My || !c.Mx ||
+            !c.scratch || c.n_levels < 0)
+            return OADG_EARG;
+        for (int j = 0; j < i; ++j)
+            if (chains_host[j].img == c.img || chains_host[j].scratch == c.scratch) return OADG_EARG;
+        if (c.n_levels > deepest) deepest = c.n_levels;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < deepest; ++l) {
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            ChainLevel a;
+            a.n = 0;
+            int blocks = 0;
+            for (int i = i0; i < n && i < i0 + 8; ++i) {
+                const oadg_bbox_chain& c = chains_host[i];
+                if (l >= c.n_levels) continue;
+                const int first = c.level_first_host[l], count = c.level_first_host[l + 1] - first;
+                if (count <= 0) continue;
+                const int tile_base = c.tile_prefix_host[first];
+                const int tiles = c.tile_prefix_host[first + count] - tile_base;
+                if (tiles <= 0) continue;
+                ChainImg& m = a.im[a.n++];
+                m.img = c.img; m.steps = c.steps_dev; m.tile_prefix = c.tile_prefix_dev; m.My = c.My; m.Mx = c.Mx;
+                m.scratch = c.scratch; m.H = c.H; m.W = c.W; m.first = first; m.count = count; m.tile_base = tile_base;
+                m.block0 = blocks;
+                blocks += tiles;
+            }
+            if (a.n == 0) continue;
+            for (int k = a.n; k < 8; ++k) a.im[k] = a.im[0];
+            hipLaunchKernelGGL(bbox_blend_imgs_kernel, dim3(blocks), dim3(256), 0, st, a);
+            OADG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(rect_copy_imgs_kernel, dim3(blocks * 4), dim3(256), 0, st, a);
+            OADG_LAUNCH_CHECK();
+        }
     }
     return OADG_OK;
 }

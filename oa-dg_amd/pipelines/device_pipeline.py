@@ -18,6 +18,7 @@ from .._lib import check, ptr, stream_ptr
 from ..registry import DATASETS, PIPELINES, build_from_cfg
 from .corrupt import Corrupt
 from .geometric import RandomFlip, Resize
+from . import oa_mix as _oa_mix
 from .oa_mix import OAMix, _ImageState
 
 
@@ -296,6 +297,11 @@ class DevicePipeline:
             views = [ctypes.c_void_p(img2.data_ptr() + i * img2.stride(0) * img2.element_size()) for i in range(N)]
             if self.oamix_workers > 1 and N > 1:
                 ml, oa = self._oamix_parallel(states, views, na, (Hp, Wp))
+            elif N > 1 and _oa_mix.LOCKSTEP:
+                # the per-box chains of the batch's images advance level by level TOGETHER (OAMix.oamix_many)
+                hist = om.oamix_many(states, [_PtrView(v, self.dtype) for v in views], na, (Hp, Wp))
+                ml = [torch.from_numpy(np.asarray(h['random_box_list'])) for h in hist]
+                oa = [torch.from_numpy(np.stack(h['oa_random_box_list'], axis=0)) for h in hist]
             else:
                 ml, oa = [], []
                 for i, st in enumerate(states):

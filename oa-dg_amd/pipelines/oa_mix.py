@@ -53,6 +53,10 @@ AUG_LISTS = {   # oa_mix.py:15-29
 MIX_TARGET_DTYPE = np.dtype([('fg_index', '<i4'), ('rect', '<i4', (4,)), ('m_oa', '<f4')])   # oadg_mix_target
 BBOX_STEP_DTYPE = np.dtype([('minv', '<f8', (6,)), ('rect', '<i4', (4,)), ('row', '<i4'), ('pad_', '<i4'),
                             ('scratch_off', '<i8')])                                          # oadg_bbox_step
+BBOX_CHAIN_DTYPE = np.dtype([('img', '<u8'), ('steps_dev', '<u8'), ('tile_prefix_dev', '<u8'), ('level_first_host', '<u8'),
+                             ('tile_prefix_host', '<u8'), ('My', '<u8'), ('Mx', '<u8'), ('scratch', '<u8'), ('H', '<i4'),
+                             ('W', '<i4'), ('n_levels', '<i4'), ('pad_', '<i4')])                        # oadg_bbox_chain
+LOCKSTEP = os.environ.get('OADG_OAMIX_LOCKSTEP', '1') == '1'    # the images of a batch advance their per-box chains together
 BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
 PLAN_IN_C = os.environ.get('OADG_OAMIX_PLAN_C', '1') == '1'     # the op's host arithmetic in one C call (else numpy)
 
@@ -314,12 +318,67 @@ class OAMix:
         self._history = {}
         self.kwargs = kwargs            # unknown kwargs are swallowed like the reference (oa_mix.py:72)
         self._bufs = {}
+        self._rec = None                # a list while oamix_many() records an image's device commands
         self.trace = None               # set to [] to record the op sequence (tests)
         self.stats = None               # set to {} to count compose steps / bbox-step pixels (tools/bench_oamix.py)
 
+    # ------------------------------------------------------------------------------------------ lockstep
+    def _do(self, fn):
+        """a device command of the current image: now, or - inside oamix_many() - appended to the image's command list"""
+        if self._rec is None:
+            fn()
+        else:
+            self._rec.append(('call', fn))
+
+    def oamix_many(self, states, out_norms, norm, pad_shape):
+        """``oamix`` for the images of a batch with their ``bboxes_only_*`` chains advanced in LOCKSTEP.  The host side runs
+        image by image exactly as before (same draws from the same stream in the same order; uploads are issued right
+        away), but the kernels that touch an image's work buffers are recorded per image and then issued round by round:
+        every image runs up to its next per-box chain, then level l of all those chains goes out as ONE launch pair
+        (csrc oadg_oamix_bbox_chain_multi).  The images own disjoint buffers (``_buffers`` slots) and every image's own
+        command order is kept, so the views are byte-identical to the sequential pass; launches per batch drop from
+        2 x (sum of the chain depths) to 2 x (sum over rounds of the deepest chain).  Returns the per-image histories."""
+        L = _lib.lib()
+        recs, hist = [], []
+        for i, st in enumerate(states):
+            st.slot = i
+            self._history, self._rec = {}, []
+            try:
+                self.oamix(st, out_u8=None, out_norm=out_norms[i], norm=norm, pad_shape=pad_shape)
+            finally:
+                rec, self._rec = self._rec, None
+            recs.append(rec)
+            hist.append(self._history)
+        at = [0] * len(recs)
+        from .. import hip_ops
+        while True:
+            for i, rec in enumerate(recs):
+                while at[i] < len(rec) and rec[at[i]][0] == 'call':
+                    rec[at[i]][1]()
+                    at[i] += 1
+            ready = [i for i, rec in enumerate(recs) if at[i] < len(rec)]
+            if not ready:
+                break
+            tab = np.zeros((len(ready),), BBOX_CHAIN_DTYPE)
+            work = 0.0
+            for r, i in zip(tab, ready):
+                c = recs[i][at[i]][1]
+                r['img'], r['steps_dev'], r['tile_prefix_dev'] = c['img'], c['steps_dev'], c['tile_prefix_dev']
+                r['level_first_host'], r['tile_prefix_host'] = c['level_first'].ctypes.data, c['tile_prefix'].ctypes.data
+                r['My'], r['Mx'], r['scratch'], r['H'], r['W'], r['n_levels'] = c['My'], c['Mx'], c['scratch'], c['H'], c['W'], c['n_levels']
+                work += c['work']
+            check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain_multi, tab.ctypes.data_as(ctypes.c_void_p),
+                                 len(ready), stream_ptr(), work=work), 'oadg_oamix_bbox_chain_multi')
+            if self.stats is not None:
+                self.stats['lockstep_rounds'] = self.stats.get('lockstep_rounds', 0) + 1
+                self.stats['lockstep_levels'] = self.stats.get('lockstep_levels', 0) + int(tab['n_levels'].max())
+            for i in ready:
+                at[i] += 1
+        return hist
+
     # ------------------------------------------------------------------------------------------ buffers
     def _buffers(self, st):
-        key = (st.H, st.W, str(st.img.device))
+        key = (st.H, st.W, str(st.img.device), getattr(st, 'slot', 0))
         b = self._bufs.get(key)
         if b is None:
             dev, H, W = st.img.device, st.H, st.W
@@ -330,7 +389,7 @@ class OAMix:
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
                      luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
                      gray=torch.empty((1,), dtype=torch.int64, device=dev))
-            while len(self._bufs) >= 3:          # per-sample multi-scale: a new shape per image; keep the latest few
+            while len(self._bufs) >= 16:         # per-sample multi-scale: a new shape per image; keep the latest few
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[key] = b
         return b
@@ -369,8 +428,11 @@ class OAMix:
         if step.get('luts_for') is not src:
             L = _lib.lib()
             b = self._buffers(st)
-            check(L.oadg_oamix_hist(ptr(src), st.H * st.W, ptr(b['hist']), stream_ptr()), 'oadg_oamix_hist')
-            check(L.oadg_oamix_luts(ptr(b['hist']), ptr(b['luts']), stream_ptr()), 'oadg_oamix_luts')
+
+            def run(src=src, b=b, n=st.H * st.W):
+                check(L.oadg_oamix_hist(ptr(src), n, ptr(b['hist']), stream_ptr()), 'oadg_oamix_hist')
+                check(L.oadg_oamix_luts(ptr(b['hist']), ptr(b['luts']), stream_ptr()), 'oadg_oamix_luts')
+            self._do(run)
             step['luts_for'] = src
 
     def _aug(self, st, src, step):
@@ -401,8 +463,8 @@ class OAMix:
             if name == 'contrast':
                 if step.get('gray_for') is not src:
                     b = self._buffers(st)
-                    check(_lib.lib().oadg_oamix_gray_sum(ptr(src), st.H * st.W, ptr(b['gray']), stream_ptr()),
-                          'oadg_oamix_gray_sum')
+                    self._do(lambda src=src, b=b, n=st.H * st.W: check(
+                        _lib.lib().oadg_oamix_gray_sum(ptr(src), n, ptr(b['gray']), stream_ptr()), 'oadg_oamix_gray_sum'))
                     step['gray_for'] = src
                 op.image = self._buffers(st)['gray'].data_ptr()
         else:
@@ -424,7 +486,7 @@ class OAMix:
         b = self._buffers(st)
         T = b['tmp'][step['n_tmp']]
         step['n_tmp'] += 1
-        T.copy_(src)
+        self._do(lambda T=T, src=src: T.copy_(src))
         H, W = st.H, st.W
         if BATCH_BOXES and PLAN_IN_C:
             self._bbox_chain_c(st, T, kind, step)
@@ -443,10 +505,11 @@ class OAMix:
                 if sup is None or sup[2] <= 0 or sup[3] <= 0:
                     continue                                     # mask identically zero: image unchanged
                 minv = (ctypes.c_double * 6)(*invert_affine(M))
-                check(L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
-                                             ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
-                                             ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
-                                             stream_ptr()), 'oadg_oamix_bbox_step')
+                self._do(lambda minv=minv, sup=sup, i=i: check(
+                    L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
+                                           ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
+                                           ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
+                                           stream_ptr()), 'oadg_oamix_bbox_step'))
         if self.stats is not None:
             self.stats['bbox_ops'] = self.stats.get('bbox_ops', 0) + 1
             sup_ = st.plan_arrays()[1].astype(np.int64)
@@ -497,6 +560,15 @@ class OAMix:
         tiles_off = n_live * BBOX_STEP_DTYPE.itemsize
         from .. import hip_ops
         work = float(9 * area.value)
+        if self._rec is not None:
+            # lockstep: this chain waits for the other images of the batch (oamix_many).  The plan's host tables live in
+            # buffers the next plan reuses (thread-local level list, pinned staging slot): private copies travel along
+            self._rec.append(('chain', dict(
+                img=T.data_ptr(), H=H, W=W, steps_dev=dst.data_ptr(), tile_prefix_dev=dst.data_ptr() + tiles_off,
+                level_first=lf[:n_levels + 1].copy(),
+                tile_prefix=buf[tiles_off:tiles_off + (n_live + 1) * 4].numpy().view(np.int32).copy(), n_levels=n_levels,
+                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=work, keep=(T, dst, st))))
+            return
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, dst.data_ptr(),
                              dst.data_ptr() + tiles_off, lf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
                              ctypes.cast(buf.data_ptr() + tiles_off, ctypes.POINTER(ctypes.c_int)), ptr(st.My),
@@ -601,6 +673,12 @@ class OAMix:
         # model bytes of the chain (SURVEY 8d's sum 3 w h term, per blend: the rect is read, its warped source is read,
         # the result is written) + the two mask profiles of every step
         work = float(9 * area.sum() + 4 * (steps['rect'][:, 2].sum() + steps['rect'][:, 3].sum()))
+        if self._rec is not None:
+            self._rec.append(('chain', dict(
+                img=T.data_ptr(), H=H, W=W, steps_dev=steps_dev.data_ptr(), tile_prefix_dev=tiles_dev.data_ptr(),
+                level_first=first, tile_prefix=tiles, n_levels=n_levels, My=st.My.data_ptr(), Mx=st.Mx.data_ptr(),
+                scratch=b['scratch'].data_ptr(), work=work, keep=(T, steps_dev, tiles_dev, st))))
+            return
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
                              first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
                              tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(st.My), ptr(st.Mx),
@@ -628,10 +706,10 @@ class OAMix:
                 ops[2] = self._aug(st, cur, step)
                 dst = b['ping'][d & 1]
                 last = d == depth - 1
-                check(L.oadg_oamix_compose(ptr(cur), ptr(dst), H, W, ops, rects, len(rboxes), ptr(b['luts']),
-                                           ptr(st.union_f), ptr(st.union_u8), ptr(b['acc']), float(ws[i]),
-                                           (1 if i == 0 else 2) if last else 0, stream_ptr()),
-                      'oadg_oamix_compose')
+                self._do(lambda cur=cur, dst=dst, ops=ops, w=float(ws[i]), mode=(1 if i == 0 else 2) if last else 0: check(
+                    L.oadg_oamix_compose(ptr(cur), ptr(dst), H, W, ops, rects, len(rboxes), ptr(b['luts']),
+                                         ptr(st.union_f), ptr(st.union_u8), ptr(b['acc']), w, mode, stream_ptr()),
+                    'oadg_oamix_compose'))
                 cur = dst
                 if self.stats is not None:
                     self.stats['compose_steps'] = self.stats.get('compose_steps', 0) + 1
@@ -662,9 +740,10 @@ class OAMix:
             to_rgb = int(norm['to_rgb'])
             dt = 1 if out_norm.dtype == torch.bfloat16 else 0
             Hp, Wp = pad_shape
-        check(L.oadg_oamix_final(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(st.My),
-                                 ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp,
-                                 Wp, stream_ptr()), 'oadg_oamix_final')
+        self._do(lambda: check(
+            L.oadg_oamix_final(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(st.My),
+                               ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp,
+                               Wp, stream_ptr()), 'oadg_oamix_final'))
         return out_u8
 
     # ------------------------------------------------------------------------------------------ dict API

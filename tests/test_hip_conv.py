@@ -331,6 +331,10 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
     (2, 256, 64, 128, 1024),      # layer3: 16-pixel sub-tiles, four columns
     (2, 256, 64, 64, 2048),       # eight columns on 64 pixel ranges (exactly 8 sub-tiles each)
     (4, 64, 128, 128, 512),       # 64 input channels (128-byte pixel rows), two columns
+    (4, 512, 128, 128, 128),      # round 4, the read-heavy mirror (32 output channels per wave): layer2 conv1 form, one column
+    (4, 512, 64, 128, 256),       # two columns of 128 channels share a pixel range
+    (2, 512, 32, 64, 2048),       # layer4 conv3 form: sixteen columns on 32 pixel ranges (8 sub-tiles each)
+    (9, 512, 72, 128, 128),       # uneven: 5184 sub-tiles over 512 workgroups
 ])
 def test_streaming_pointwise_kernel_equals_the_tile_kernel(dev, N, C, H, W, K):
     """csrc conv_pw_stream_kernel (variant 4: weights in registers, LDS-DMA pixel ring, operands one sub-tile ahead)
@@ -366,7 +370,7 @@ def test_streaming_pointwise_kernel_equals_the_tile_kernel(dev, N, C, H, W, K):
         assert torch.equal(y3, y4)
         assert (c3 - c4).abs().max().item() <= 1e-4 * y3.float().abs().sum((0, 2, 3)).max().item()
         assert torch.equal(run(4, want_colsum=True, **kw)[1], c4)              # deterministic
-    assert L.oadg_conv2d_pixel_tiles(N, H, W, C, K, 1, 1, 1, 0, 1, 4) == 512 // (K // 256)   # one row per pixel range
+    assert L.oadg_conv2d_pixel_tiles(N, H, W, C, K, 1, 1, 1, 0, 1, 4) == 512 // (K // (128 if C >= 512 else 256))   # one row per pixel range
     # the automatic choice falls back to the tile kernel for operands the streaming kernel does not take
     ym = hip_conv.conv_forward(x, w, None, None, 1, 0, 1, False, mask=res)
     assert torch.equal(ym, hip_conv.conv_forward(x, w, None, None, 1, 0, 1, False, variant=3, mask=res))

@@ -285,3 +285,51 @@ def test_oamix_helper_threads_equal_independent_sequential_workers(dev):
     torch.cuda.synchronize()
     assert out2['img2'].shape == out['img2'].shape and bool(torch.isfinite(out2['img2']).all())
     assert not torch.equal(out2['img2'], out['img2'])
+
+
+@pytest.mark.parametrize('plan_in_c', [True, False])
+def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monkeypatch, plan_in_c):
+    """OAMix.oamix_many (round 4): the images of a batch record their device commands and advance their bboxes_only_*
+    chains level by level TOGETHER (csrc oadg_oamix_bbox_chain_multi: one launch pair per level for all images).  Against
+    the image-by-image pass with the same numpy stream: both views byte-identical, the same box lists, the stream left
+    in the same state - for images with many, few and no boxes, dense small boxes (deep chains) and both host planners;
+    and the lockstep pass really shares launches (fewer level rounds than the sum of the chains' depths)."""
+    import os
+    from oadg_amd import Config
+    from oadg_amd.pipelines import DevicePipeline
+    from oadg_amd.pipelines import oa_mix
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
+    monkeypatch.setattr(oa_mix, 'PLAN_IN_C', plan_in_c)
+    cases = [_case(40 + i, 256, 384, n, small=True) for i, n in enumerate((9, 3, 0, 14, 6))]
+    rs = np.random.RandomState(9)
+    cases.append((lowpass_image(rs, 256, 384, 4), synthetic_boxes(rs, 96, 256, 384, 8, 40)))     # config-5-like density
+    imgs = torch.from_numpy(np.stack([c[0] for c in cases])).to(dev)
+    gts = [c[1] for c in cases]
+    labels = [np.zeros(len(g), np.int64) for g in gts]
+    out, stats, rng_after = {}, {}, {}
+    for lock in (True, False):
+        monkeypatch.setattr(oa_mix, 'LOCKSTEP', lock)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.float32)
+        pipe.oamix.stats = {}
+        np.random.seed(11)
+        out[lock] = pipe(imgs, gts, labels)
+        torch.cuda.synchronize()
+        rng_after[lock] = np.random.random()
+        stats[lock] = dict(pipe.oamix.stats)
+        # a second batch through the same pipeline object (buffers of the slots are reused)
+        out[lock, 2] = pipe(imgs.flip(0), gts[::-1], labels[::-1])
+        torch.cuda.synchronize()
+    assert rng_after[True] == rng_after[False]
+    for key in (True, (True, 2)):
+        a, b = out[key], out[False if key is True else (False, 2)]
+        assert torch.equal(a['img'], b['img']) and torch.equal(a['img2'], b['img2'])
+        for i in range(len(cases)):
+            assert np.array_equal(a['oamix_boxes'][i].numpy(), b['oamix_boxes'][i].numpy()), i
+            assert np.array_equal(a['multilevel_boxes'][i].numpy(), b['multilevel_boxes'][i].numpy()), i
+    assert not torch.equal(out[True]['img2'], out[True]['img'])
+    s = stats[True]
+    assert s['bbox_ops'] == stats[False]['bbox_ops'] > 0 and s['bbox_levels'] == stats[False]['bbox_levels']
+    assert 0 < s['lockstep_rounds'] <= s['bbox_ops']
+    assert s['lockstep_levels'] < s['bbox_levels'], s          # levels issued (deepest chain per round) < sum of depths
+    assert 'lockstep_rounds' not in stats[False]
