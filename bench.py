@@ -128,7 +128,7 @@ FAMILIES = (('conv256 forward / data gradient', ('conv_igemm256_kernel',), 'mfma
             ('weight gradient 256-tile (single-layer launches + grouped multi-layer launches)',
              ('conv_wgrad256_kernel', 'conv_wgrad256_multi_kernel'), 'mfma'),
             ('weight gradient 128-tile', ('conv_wgrad_kernel',), 'hbm'),
-            ('pointwise streaming (1x1, C <= 256)', ('conv_pw_stream_kernel',), 'hbm'),
+            ('pointwise streaming (1x1, C <= 512)', ('conv_pw_stream_kernel',), 'hbm'),
             ('128-tile convolution', ('conv_igemm_kernel',), 'mfma'))
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (xf32-free) MFMA peak
 
@@ -209,7 +209,8 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
     rows = ms_of('oamix_bbox_chain')
     if rows:
         ms, by = sum(r[0] for r in rows), sum(r[1] for r in rows)
-        e = {'family': 'OA-Mix per-box blend chains (side stream)', 'kernels': ['bbox_blend_multi_kernel', 'rect_copy_multi_kernel'],
+        e = {'family': 'OA-Mix per-box blend chains (side stream; the images of a batch in lockstep)',
+             'kernels': ['bbox_blend_imgs_kernel', 'rect_copy_imgs_kernel'],
              'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1), 'ms_per_step': round(ms / steps, 3),
              'achieved': round(by / ms / 1e6, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
              'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 5), 'algorithmic_bytes_per_step': int(by / steps)}
