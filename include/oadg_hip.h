@@ -398,6 +398,7 @@ typedef struct oadg_wgrad_job {
     long P;                    /* plan: N*Ho*Wo */
     int N, H, W, C, K, R, S, stride, pad, dil;
     int Ho, Wo, splits, chunks_per_split, first_block, blocks;      /* plan */
+    int strip_rows, pad_;      /* plan: > 0 = a split is this many whole output rows, swept in 64-column strips */
 } oadg_wgrad_job;
 long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs_host, int n, int target_blocks);
 int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const void* zeros16, void* stream);

@@ -1083,6 +1083,8 @@ struct WgradArgs {
     float* part;                  // [splits][K][R*S][C] fp32
     const unsigned short* zeros;
     int N, H, W, C, K, R, S, Ho, Wo, stride, pad, dil, splits, chunks_per_split;
+    int strip_rows;               // > 0 (256-tile kernel, Wo % 64 == 0): a split = strip_rows whole output rows, K-tiles in
+                                  // row-strip order (see wgrad256_tile); 0: a split = chunks_per_split consecutive 64-pixel chunks
     long P;
 };
 
@@ -1317,6 +1319,7 @@ __device__ __forceinline__ bf16x8 tr_frag16(const unsigned char* half, int pix0,
 // per x piece) the load phase of one wave group was longer than the 32-MFMA phase of its partner (round-2 ISA count:
 // 84 + 61 + 30 VALU per K-tile against 30 + 28 in the forward kernel).
 struct PixState {
+    int t, k, sidx;       // ordinal of the K-tile in this workgroup's sweep; row / strip counters of the row-strip order
     long ch;              // K-tile (64-pixel chunk) index (uniform)
     int ho[2], wo[2];     // output pixel of the piece's row
     int hi[2], wi[2];     // its input coordinates for this workgroup's tap
@@ -1334,10 +1337,29 @@ __device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int spli
     const int rs = combo / (ct_n * kt_n);
     const int r = rs / a.S, s = rs - r * a.S;
     const int k0 = kt * 256, c0 = ct * 256;
+    // K-tile order.  Linear (1x1 layers, ragged widths): the split's 64-pixel chunks in memory order.  ROW-STRIP (round 4;
+    // filters with taps, Wo % 64 == 0): the split owns whole output rows and sweeps them strip by strip - 64 columns, all
+    // its rows top to bottom, then the next 64 columns.  The workgroups of the R*S taps of a split run side by side on one
+    // XCD; tap (r, s) of K-tile t reads input row (row_t + r - 1): in row-strip order the row a tap needs was staged by
+    // its neighbour tap ONE K-tile earlier (linear order: Wo / 64 = 8 K-tiles earlier on P2, i.e. 3.5 splits x 8 x 66 KB
+    // apart in a 4 MiB L2 that also streams dy - rocprofv3 FETCH_SIZE of the P2 3x3 launch was 5.6x its operand bytes).
+    const bool strip = a.strip_rows > 0;
+    const int spr = a.Wo / WP;                                  // 64-column strips per output row (strip mode)
     const long nchunks = (a.P + WP - 1) / WP;
-    const long ch0 = (long)split * a.chunks_per_split;
-    const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
-    const int nk = ch1 > ch0 ? (int)(ch1 - ch0) : 0;
+    long ch0, row0 = 0;
+    int nk, nrows = 0;
+    if (strip) {
+        const long rows_total = (long)a.N * a.Ho;
+        row0 = (long)split * a.strip_rows;
+        const long row1 = row0 + a.strip_rows < rows_total ? row0 + a.strip_rows : rows_total;
+        nrows = row1 > row0 ? (int)(row1 - row0) : 0;
+        nk = nrows * spr;
+        ch0 = row0 * spr;
+    } else {
+        ch0 = (long)split * a.chunks_per_split;
+        const long ch1 = ch0 + a.chunks_per_split < nchunks ? ch0 + a.chunks_per_split : nchunks;
+        nk = ch1 > ch0 ? (int)(ch1 - ch0) : 0;
+    }
 
     // loader geometry: piece q = i*512 + tid -> pixel row q >> 4 (0..63) of the K-tile, 16-byte slot q & 15
     int lrow[2], lslot[2];
@@ -1379,6 +1401,26 @@ __device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int spli
         }
     };
     auto advance = [&](PixState& st) {
+        st.t++;
+        if (strip) {
+            if (++st.k >= nrows) {                 // next strip of this split's rows (uniform, once per nrows K-tiles)
+                st.k = 0;
+                ++st.sidx;
+                if (st.t < nk) init_state(st, row0 * spr + st.sidx);
+            } else {                               // same columns, next output row
+                st.ch += spr;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ++st.ho[i]; st.hi[i] += a.stride;
+                    st.xoff[i] += dH;
+                    if (st.ho[i] >= a.Ho) {        // first row of the next image
+                        st.ho[i] -= a.Ho; st.hi[i] -= hi_wrap;
+                        st.xoff[i] += add_wrap_h;
+                    }
+                }
+            }
+            return;
+        }
         st.ch++;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1399,7 +1441,7 @@ __device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int spli
     auto stage_dy = [&](int h, const PixState& st, int buf) {
         unsigned char* dst = smem + buf * BUF_BYTES + h * HALF_BYTES + wave * 1024;
         const long left = a.P - st.ch * WP;                       // pixels from this chunk's first to the end (uniform)
-        const int rows = st.ch < ch1 ? (left < WP ? (int)left : WP) : 0;
+        const int rows = st.t < nk ? (left < WP ? (int)left : WP) : 0;
         const uintptr_t off = (uintptr_t)(st.ch * chunk_dy + h * 128) * 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1410,7 +1452,7 @@ __device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int spli
     auto stage_x = [&](int h, const PixState& st, int buf) {
         unsigned char* dst = smem + buf * BUF_BYTES + (2 + h) * HALF_BYTES + wave * 1024;
         const long left = a.P - st.ch * WP;
-        const int rows = st.ch < ch1 ? (left < WP ? (int)left : WP) : 0;
+        const int rows = st.t < nk ? (left < WP ? (int)left : WP) : 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool ok = lrow[i] < rows && (unsigned)st.hi[i] < (unsigned)a.H && (unsigned)st.wi[i] < (unsigned)a.W;
@@ -1491,6 +1533,7 @@ __device__ __forceinline__ void wgrad256_tile(const WgradArgs& a, const int spli
     } while (0)
 
     PixState s1, s2;
+    s1.t = s1.k = s1.sidx = 0;
     init_state(s1, ch0);
     stage_dy(0, s1, 0);
     stage_x(0, s1, 0);
@@ -1593,6 +1636,7 @@ __global__ __launch_bounds__(512) void conv_wgrad256_multi_kernel(const oadg_wgr
     a.x = (const unsigned short*)jb.x; a.dy = (const unsigned short*)jb.dy; a.part = (float*)jb.part; a.zeros = zeros;
     a.N = jb.N; a.H = jb.H; a.W = jb.W; a.C = jb.C; a.K = jb.K; a.R = jb.R; a.S = jb.S; a.Ho = jb.Ho; a.Wo = jb.Wo;
     a.stride = jb.stride; a.pad = jb.pad; a.dil = jb.dil; a.splits = jb.splits; a.chunks_per_split = jb.chunks_per_split;
+    a.strip_rows = jb.strip_rows;
     a.P = jb.P;
     const int local = w - jb.first_block;
     const int combos = (a.K / 256) * (a.C / 256) * a.R * a.S;
@@ -1631,6 +1675,19 @@ bool wgrad_use256(long P, int K, int C, int RS) {
     return nchunks / wgrad256_splits(P, K, C, RS) >= 8;      // at least 8 K-tiles per workgroup
 }
 int wgrad_stages(int RS) { return RS > 1 ? 1 : 2; }
+
+// row-strip K-tile order of the 256-tile kernel (wgrad256_tile): filters with taps on maps whose width is a multiple of
+// the 64-pixel K-tile.  A split becomes a number of whole output rows; returns that number (0: linear order) and
+// replaces splits / chunks_per_split by the equivalent row-aligned values (never more splits than before).
+int wgrad_strip(int N, int Ho, int Wo, int RS, int& splits, int& chunks_per_split) {
+    const long rows = (long)N * Ho;
+    static const bool off = getenv("OADG_WGRAD_STRIP") && getenv("OADG_WGRAD_STRIP")[0] == '0';      // (A/B probes)
+    if (off || RS <= 1 || Wo % WP != 0 || rows < splits || splits < 1) return 0;
+    const long per = (rows + splits - 1) / splits;
+    splits = (int)((rows + per - 1) / per);
+    chunks_per_split = (int)(per * (Wo / WP));
+    return (int)per;
+}
 
 int wgrad_splits(long P, int K, int C, int RS) {
     if (wgrad_use256(P, K, C, RS)) return (int)wgrad256_splits(P, K, C, RS);
@@ -1681,7 +1738,9 @@ int wgrad_launch(const void* x, const void* dy, float* dw, const void* zeros16, 
     const size_t need = (size_t)a.splits * K * R * S * C * sizeof(float);
     if (workspace_bytes < need) return OADG_ESIZE;
     hipStream_t st = (hipStream_t)stream;
+    a.strip_rows = 0;
     if (wgrad_use256(a.P, K, C, R * S)) {
+        a.strip_rows = wgrad_strip(N, a.Ho, a.Wo, R * S, a.splits, a.chunks_per_split);
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad256_kernel,
@@ -1764,6 +1823,19 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
         j.splits = (int)sp;
         total += (long)(j.K / 256) * (j.C / 256) * j.R * j.S * sp;
     }
+    while (total > target_blocks) {           // (jobs rounded up to one split pushed the list over: take splits back where
+        int best = -1;                        //  the workgroups are shortest)
+        double shortest = 1e300;
+        for (int i = 0; i < n; ++i) {
+            const oadg_wgrad_job& j = jobs[i];
+            if (j.splits <= 1) continue;
+            const double len = (double)((j.P + WP - 1) / WP) / j.splits;
+            if (len < shortest) { shortest = len; best = i; }
+        }
+        if (best < 0) break;
+        jobs[best].splits -= 1;
+        total -= (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
+    }
     for (;;) {
         int best = -1;
         double longest = 0.0;
@@ -1784,6 +1856,8 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
         const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
         j.chunks_per_split = (int)((nchunks + j.splits - 1) / j.splits);
         j.splits = (int)((nchunks + j.chunks_per_split - 1) / j.chunks_per_split);      // no empty pixel range
+        j.strip_rows = wgrad_strip(j.N, j.Ho, j.Wo, j.R * j.S, j.splits, j.chunks_per_split);
+        j.pad_ = 0;
         j.first_block = (int)first;
         j.blocks = (int)(tiles * j.splits);
         first += j.blocks;

@@ -204,11 +204,11 @@ _WQ_WORK = 0
 _WG_JOB = np.dtype([('x', 'u8'), ('dy', 'u8'), ('part', 'u8'), ('P', 'i8'), ('N', 'i4'), ('H', 'i4'), ('W', 'i4'),
                     ('C', 'i4'), ('K', 'i4'), ('R', 'i4'), ('S', 'i4'), ('stride', 'i4'), ('pad', 'i4'), ('dil', 'i4'),
                     ('Ho', 'i4'), ('Wo', 'i4'), ('splits', 'i4'), ('cps', 'i4'), ('first_block', 'i4'),
-                    ('blocks', 'i4')], align=True)                                                  # oadg_wgrad_job
+                    ('blocks', 'i4'), ('strip_rows', 'i4'), ('pad_', 'i4')], align=True)            # oadg_wgrad_job
 _PB_JOB = np.dtype([('part', 'u8'), ('gbias', 'u8'), ('w', 'u8'), ('scale', 'u8'), ('mean', 'u8'), ('var', 'u8'),
                     ('dw', 'u8'), ('dgamma', 'u8'), ('eps', 'f4'), ('splits', 'i4'), ('K', 'i4'), ('C', 'i4'),
                     ('R', 'i4'), ('S', 'i4'), ('w_krsc', 'i4'), ('first_block', 'i4')], align=True)  # oadg_prep_bwd_job
-assert _WG_JOB.itemsize == 96 and _PB_JOB.itemsize == 96
+assert _WG_JOB.itemsize == 104 and _PB_JOB.itemsize == 96
 
 
 class _TableStage:
@@ -223,7 +223,7 @@ class _TableStage:
         raw = tab.view(np.uint8).reshape(-1)
         st = self.dev.get(device)
         if st is None or st[0][0].numel() < raw.nbytes:
-            n = max(raw.nbytes, 64 * 96)
+            n = max(raw.nbytes, 64 * 104)
             st = self.dev[device] = ([torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)],
                                      [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.SLOTS)], [0],
                                      [None] * self.SLOTS)

@@ -143,6 +143,11 @@ def test_conv_autograd_matches_reference(dev):
     (2, 256, 320, 320, 256, 1, 1, 0, 1),    # 1x1 over >= 200k pixels (lateral P2 form) on the 256-tile kernel
     (4, 256, 128, 130, 512, 3, 2, 1, 1),    # stride 2, ragged, 18 tiles x 14 splits
     (8, 256, 256, 512, 512, 1, 2, 0, 1),    # layer2 downsample 1x1 / stride 2 at the bench size
+    # round 4, row-strip K-tile order (output width a multiple of 64): splits own whole rows, 64-column strips
+    (2, 256, 128, 256, 256, 3, 1, 1, 1),    # P3 form: four strips per row, 256 rows over 28 splits (ragged: 10 / 6 rows)
+    (3, 256, 50, 128, 256, 3, 1, 1, 1),     # two strips, rows crossing image boundaries inside a split
+    (2, 256, 128, 256, 256, 3, 2, 1, 1),    # stride 2: 64 x 128 outputs of a 128 x 256 input
+    (2, 256, 96, 64, 256, 3, 1, 2, 2),      # dilation 2, one strip per row
 ])
 def test_conv_wgrad_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
     from oadg_amd import hip_conv
@@ -903,7 +908,10 @@ def test_deferred_column_sums_give_the_same_gradients_bit_for_bit(dev):
 
 _WG_SHAPES = [(2, 256, 16, 24, 256, 3, 1, 1, 1), (2, 1024, 16, 24, 256, 1, 1, 0, 1), (2, 256, 16, 24, 1024, 1, 1, 0, 1),
               (2, 512, 8, 12, 512, 3, 1, 1, 1), (2, 512, 16, 24, 1024, 1, 2, 0, 1), (2, 256, 32, 48, 256, 3, 2, 1, 1),
-              (1, 512, 9, 13, 256, 3, 1, 2, 2), (3, 256, 5, 7, 256, 3, 1, 1, 1)]
+              (1, 512, 9, 13, 256, 3, 1, 2, 2), (3, 256, 5, 7, 256, 3, 1, 1, 1),
+              # row-strip order (output width a multiple of 64)
+              (2, 256, 16, 64, 256, 3, 1, 1, 1), (3, 256, 11, 128, 256, 3, 1, 1, 1), (1, 256, 64, 128, 256, 3, 2, 1, 1),
+              (2, 512, 12, 64, 512, 3, 1, 2, 2)]
 
 
 @pytest.mark.parametrize('target', [256, 64, 7])
