@@ -600,25 +600,32 @@ __global__ void roi_order_key_kernel(const float* __restrict__ rois, int K, int 
 __global__ __launch_bounds__(256) void roi_order_rank_kernel(const float* __restrict__ rois, int K, int n_img, int levels,
                                                              float finest_scale, int* __restrict__ order,
                                                              int* __restrict__ range) {
-    extern __shared__ unsigned long long rk_keys[];
-    for (int j = threadIdx.x; j < K; j += 256)
-        rk_keys[j] = ((unsigned long long)roi_order_key(rois, j, n_img, levels, finest_scale) << 16) | (unsigned)j;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long rk_keys[];
+    const int Kp = (K + 7) & ~7;                            // padded with keys that are smaller than nothing
+    for (int j = threadIdx.x; j < Kp; j += 256)
+        rk_keys[j] = j < K ? ((unsigned long long)roi_order_key(rois, j, n_img, levels, finest_scale) << 16) | (unsigned)j
+                           : ~0ull;
     __syncthreads();
+    // (round 4: eight keys per trip as four 16-byte broadcast reads and four independent counters - the one-key loop was a
+    //  dependent chain of 4198 LDS round trips per thread: 124 us on the critical path between the RoI sampler and RoIAlign)
+    auto count_below = [&](unsigned long long bound) {
+        const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(rk_keys);
+        int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        for (int j = 0; j < Kp / 2; j += 4) {
+            const ulonglong2 a = k2[j], b = k2[j + 1], c = k2[j + 2], d = k2[j + 3];
+            c0 += (a.x < bound ? 1 : 0) + (a.y < bound ? 1 : 0);
+            c1 += (b.x < bound ? 1 : 0) + (b.y < bound ? 1 : 0);
+            c2 += (c.x < bound ? 1 : 0) + (c.y < bound ? 1 : 0);
+            c3 += (d.x < bound ? 1 : 0) + (d.y < bound ? 1 : 0);
+        }
+        return (c0 + c1) + (c2 + c3);
+    };
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < K) {
-        const unsigned long long mine = rk_keys[i];
-        int rank = 0;
-        for (int j = 0; j < K; ++j) rank += rk_keys[j] < mine ? 1 : 0;
-        order[rank] = i;
-    }
+    if (i < K) order[count_below(rk_keys[i])] = i;
     const int groups = levels * n_img;
     if (blockIdx.x == gridDim.x - 1)                        // (the last workgroup is the least loaded one)
-        for (int g = threadIdx.x; g <= groups; g += 256) {
-            const unsigned long long bound = (unsigned long long)g << 36;       // group g's smallest key: g << 20, then << 16
-            int cnt = 0;
-            for (int j = 0; j < K; ++j) cnt += rk_keys[j] < bound ? 1 : 0;
-            range[g] = cnt;
-        }
+        for (int g = threadIdx.x; g <= groups; g += 256)
+            range[g] = count_below((unsigned long long)g << 36);     // group g's smallest key: g << 20, then << 16
 }
 
 int fill_pyramid(Pyramid& p, const void* const* feats, float* const* dfeats, const int* heights,
@@ -677,7 +684,7 @@ int oadg_roi_order_keys(const float* rois, int K, int n_img, int levels, float f
 int oadg_roi_order(const float* rois, int K, int n_img, int levels, float finest_scale, int* order, int* range,
                    void* stream) {
     if (!rois || !order || !range || K < 1 || K > 8192 || n_img < 1 || levels < 1 || levels > OADG_MAX_LEVELS) return OADG_EARG;
-    hipLaunchKernelGGL(roi_order_rank_kernel, dim3((K + 255) / 256), dim3(256), (size_t)K * sizeof(unsigned long long),
+    hipLaunchKernelGGL(roi_order_rank_kernel, dim3((K + 255) / 256), dim3(256), (size_t)((K + 7) & ~7) * sizeof(unsigned long long),
                        (hipStream_t)stream, rois, K, n_img, levels, finest_scale, order, range);
     OADG_LAUNCH_CHECK();
     return OADG_OK;

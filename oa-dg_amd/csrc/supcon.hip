@@ -56,26 +56,47 @@ __device__ __forceinline__ int twin_of(int i, int ori, int rp) {
     return -1;
 }
 
-__global__ void supcon_prep_kernel(const float* __restrict__ feats, const int64_t* __restrict__ labels,
-                                   int B, int D, int n_labels, float* __restrict__ fhat,
-                                   float* __restrict__ invnorm, WsHeader* hdr) {
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= B) return;
-    const float* f = feats + (size_t)row * D;
-    float ss = 0.f;
-    for (int d = lane; d < D; d += 64) { float v = f[d]; ss += v * v; }
-    ss = wave_sum(ss);
-    // F.normalize: x / max(||x||, 1e-12)
-    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-    const float inv = 1.0f / nrm;
-    for (int d = lane; d < D; d += 64) fhat[(size_t)row * D + d] = f[d] / nrm;
-    if (lane == 0) {
-        invnorm[row] = inv;
-        int l = label_of(labels, n_labels, row);
-        if (l < 0 || l >= MAX_LABELS) { atomicOr(&hdr->error, 1); l = l < 0 ? 0 : MAX_LABELS - 1; }
-        atomicAdd(&hdr->cnt[l], 1);
-        atomicMax(&hdr->bg_label, l);
+// PREP_ROWS rows per workgroup (a wave takes every fourth).  The label statistics go through an LDS histogram: one global
+// atomic per (workgroup, label that occurs in it) - round 3 issued two per ROW onto the same ~9 addresses, 17,000
+// serialised same-address atomics = 99 us on the critical path of the loss section (integer sums / maxima: any order
+// gives the same result).
+constexpr int PREP_ROWS = 32;
+__global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restrict__ feats,
+                                                          const int64_t* __restrict__ labels, int B, int D, int n_labels,
+                                                          float* __restrict__ fhat, float* __restrict__ invnorm,
+                                                          WsHeader* hdr) {
+    __shared__ int s_cnt[MAX_LABELS];
+    __shared__ int s_max, s_err;
+    for (int i = threadIdx.x; i < MAX_LABELS; i += 256) s_cnt[i] = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_err = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = blockIdx.x * PREP_ROWS;
+    for (int rr = wave; rr < PREP_ROWS; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= B) break;
+        const float* f = feats + (size_t)row * D;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) { float v = f[d]; ss += v * v; }
+        ss = wave_sum(ss);
+        // F.normalize: x / max(||x||, 1e-12)
+        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+        const float inv = 1.0f / nrm;
+        for (int d = lane; d < D; d += 64) fhat[(size_t)row * D + d] = f[d] / nrm;
+        if (lane == 0) {
+            invnorm[row] = inv;
+            int l = label_of(labels, n_labels, row);
+            if (l < 0 || l >= MAX_LABELS) { atomicOr(&s_err, 1); l = l < 0 ? 0 : MAX_LABELS - 1; }
+            atomicAdd(&s_cnt[l], 1);
+            atomicMax(&s_max, l);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MAX_LABELS; i += 256)
+        if (s_cnt[i]) atomicAdd(&hdr->cnt[i], s_cnt[i]);
+    if (threadIdx.x == 0) {
+        atomicMax(&hdr->bg_label, s_max);
+        if (s_err) atomicOr(&hdr->error, 1);
     }
 }
 
@@ -343,7 +364,7 @@ int oadg_supcon_fwd(const float* feats, const int64_t* labels, int B, int D, int
     char* ws = (char*)workspace;
     hipError_t e = hipMemsetAsync(ws, 0, sizeof(WsHeader), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(supcon_prep_kernel, dim3(oadg_cdiv(B, 4)), dim3(256), 0, st, feats, labels, B, D,
+    hipLaunchKernelGGL(supcon_prep_kernel, dim3(oadg_cdiv(B, PREP_ROWS)), dim3(256), 0, st, feats, labels, B, D,
                        n_labels, (float*)(ws + p.off_fhat), (float*)(ws + p.off_inv), (WsHeader*)ws);
     OADG_LAUNCH_CHECK();
     const float inv_t = 1.0f / temper;
