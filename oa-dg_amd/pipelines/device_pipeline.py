@@ -347,6 +347,9 @@ def _oamix_parallel(self, states, views, na, pad_shape):
     ready.record(cur)
     results = [None] * len(states)
 
+    lockstep = _oa_mix.LOCKSTEP
+    recs = [None] * len(states)
+
     def task(k):
         h = self._helpers[k]
         om = h['om']
@@ -357,15 +360,24 @@ def _oamix_parallel(self, states, views, na, pad_shape):
             h['stream'].wait_event(ready)
             for i in range(k, len(states), K):
                 om._history = {}
-                om.oamix(states[i], out_u8=None, out_norm=_PtrView(views[i], self.dtype), norm=na, pad_shape=pad_shape)
-                results[i] = (torch.from_numpy(np.asarray(om._history['random_box_list'])),
-                              torch.from_numpy(np.stack(om._history['oa_random_box_list'], axis=0)))
+                out_norm = _PtrView(views[i], self.dtype)
+                if lockstep:
+                    # round 4: the helper PLANS its images (draws, C plan calls, descriptor uploads on its stream); the
+                    # caller then runs the recorded device commands of the whole batch in lockstep (OAMix.execute)
+                    recs[i], hist = om.record(states[i], i, out_norm, na, pad_shape)
+                else:
+                    om.oamix(states[i], out_u8=None, out_norm=out_norm, norm=na, pad_shape=pad_shape)
+                    hist = om._history
+                results[i] = (torch.from_numpy(np.asarray(hist['random_box_list'])),
+                              torch.from_numpy(np.stack(hist['oa_random_box_list'], axis=0)))
             ev = torch.cuda.Event()
             ev.record()
         return ev
     futs = [self._helpers[k]['pool'].submit(task, k) for k in range(K)]
     for f in futs:
         cur.wait_event(f.result())
+    if lockstep:
+        self.oamix.execute(recs)
     if self.oamix.stats is not None:
         for k in range(K):
             for key, n in (self._helpers[k]['om'].stats or {}).items():

@@ -158,7 +158,7 @@ class _PinnedRing:
     """Per-thread ring of pinned staging buffers for the small descriptor uploads: ``tensor.pin_memory()`` allocates
     (hipHostMalloc, ~2 ms for a 4096-box descriptor table) on every call; a slot of the ring is reused once the copy
     that read it has completed (event recorded behind the copy on its stream)."""
-    SLOTS = 16
+    SLOTS = 96
 
     def __init__(self):
         self.bufs, self.events, self.k = [None] * self.SLOTS, [None] * self.SLOTS, 0
@@ -338,17 +338,30 @@ class OAMix:
         (csrc oadg_oamix_bbox_chain_multi).  The images own disjoint buffers (``_buffers`` slots) and every image's own
         command order is kept, so the views are byte-identical to the sequential pass; launches per batch drop from
         2 x (sum of the chain depths) to 2 x (sum over rounds of the deepest chain).  Returns the per-image histories."""
-        L = _lib.lib()
         recs, hist = [], []
         for i, st in enumerate(states):
-            st.slot = i
-            self._history, self._rec = {}, []
-            try:
-                self.oamix(st, out_u8=None, out_norm=out_norms[i], norm=norm, pad_shape=pad_shape)
-            finally:
-                rec, self._rec = self._rec, None
+            rec, h = self.record(st, i, out_norms[i], norm, pad_shape)
             recs.append(rec)
-            hist.append(self._history)
+            hist.append(h)
+        self.execute(recs)
+        return hist
+
+    def record(self, st, slot, out_norm, norm, pad_shape):
+        """the host half of ``oamix`` for one image: every draw, every plan, every upload - and the list of device commands
+        it would have issued (``execute`` runs the lists of a batch in lockstep).  ``slot`` selects the image's private
+        work buffers.  Returns (command list, history)."""
+        st.slot = slot
+        self._history, self._rec = {}, []
+        try:
+            self.oamix(st, out_u8=None, out_norm=out_norm, norm=norm, pad_shape=pad_shape)
+        finally:
+            rec, self._rec = self._rec, None
+        return rec, self._history
+
+    def execute(self, recs):
+        """issue the recorded command lists of a batch's images on the current stream: every image up to its next per-box
+        chain, then those chains together, level by level (csrc oadg_oamix_bbox_chain_multi)"""
+        L = _lib.lib()
         at = [0] * len(recs)
         from .. import hip_ops
         while True:
@@ -374,7 +387,6 @@ class OAMix:
                 self.stats['lockstep_levels'] = self.stats.get('lockstep_levels', 0) + int(tab['n_levels'].max())
             for i in ready:
                 at[i] += 1
-        return hist
 
     # ------------------------------------------------------------------------------------------ buffers
     def _buffers(self, st):
