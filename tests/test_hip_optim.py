@@ -100,3 +100,31 @@ def test_fused_sgd_leaves_unsupported_settings_to_torch(dev):
     before = ps[1].detach().clone()
     oc.step()
     assert torch.equal(ps[1], before) and 'momentum_buffer' not in oc.state[ps[1]]
+
+
+@pytest.mark.parametrize('mode', ['absent', 'old_signature'])
+def test_fused_sgd_version_bump_fallback(dev, monkeypatch, mode):
+    """FusedSGD writes the parameters behind ATen's back and bumps their version counters through a private torch entry
+    point (torch._C._autograd._unsafe_set_version_counter with two lists).  A torch without it, or with the older
+    (Tensor, int) signature, takes the fallback - an in-place no-op per tensor - and everything keyed on the counters
+    (the bank of prepared convolution weights) still sees the update; values stay bit-identical to torch.optim.SGD."""
+    from oadg_amd.apis import FusedSGD
+    if mode == 'absent':
+        monkeypatch.delattr(torch._C._autograd, '_unsafe_set_version_counter', raising=False)
+    else:
+        def old(t, v):
+            if not isinstance(t, torch.Tensor):
+                raise TypeError('_unsafe_set_version_counter(): argument "t" must be Tensor, not list')
+        monkeypatch.setattr(torch._C._autograd, '_unsafe_set_version_counter', old, raising=False)
+    a, b = _params(dev), _params(dev)
+    oa = torch.optim.SGD(a, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    ob = FusedSGD(b, lr=0.02, momentum=0.9, weight_decay=1e-4)
+    for step in range(2):
+        _set_grads(a, step, dev)
+        _set_grads(b, step, dev)
+        v0 = [p._version for p in b]
+        oa.step()
+        ob.step()
+        assert ob._tables, 'the fused path did not run'
+        for x, y, v in zip(a, b, v0):
+            assert torch.equal(x, y) and y._version > v

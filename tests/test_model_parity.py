@@ -467,3 +467,50 @@ def test_flat_reducer_over_rccl_world1_with_deferred_launches(dev):
     finally:
         hip_conv.enable(False)
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_r101_dc5_step_through_the_rccl_reducer_with_128_mb_buckets(dev, monkeypatch):
+    """BASELINE configs[3]'s 737 MB of gradients through FlatGradReducer over RCCL (world size 1 - no
+    multi-GPU box) with OADG_BUCKET_MB=128: the five buckets of DESIGN section 7 (the 411 MB FC weight alone makes the first
+    one 416.7 MB), every collective issued in bucket order, finite losses over two steps at bs 2 / 736 x 1280, all
+    parameters updated, .grad of every parameter a slice of the flat buffer."""
+    import torch.distributed as dist
+    from oadg_amd import Config, build_detector, hip_conv
+    from oadg_amd.apis import TrainEngine, build_optimizer, set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    monkeypatch.setenv('OADG_BUCKET_MB', '128')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(25450 + os.getpid() % 2000), RANK='0', WORLD_SIZE='1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r101_dc5_1x_dwd_oadg.py'))
+        set_random_seed(0)
+        det = build_detector(cfg.model)
+        det.init_weights(allow_missing_pretrained=True)
+        det = det.to(dev).to(memory_format=torch.channels_last).train()
+        det.log_vars_on_host = False
+        eng = TrainEngine(det, build_optimizer(det, cfg.optimizer), distributed=True, amp_dtype=torch.bfloat16)
+        red = eng.reducer
+        assert red is not None
+        sizes = [round((b['end'] - b['start']) * 4 / 1e6, 1) for b in red.buckets]
+        assert sizes == [416.7, 151.6, 134.5, 28.8, 5.4], sizes
+        order = []
+        orig = red._launch
+        red._launch = lambda b: (order.append([x is b for x in red.buckets].index(True)), orig(b))[1]
+        ds = SyntheticCityscapes(img_shape=(736, 1280), num_boxes=12, num_classes=7, box_size=(24, 300), device=dev)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
+        w0 = {n: p.detach().clone() for n, p in det.named_parameters() if p.requires_grad}
+        for it in range(2):
+            out = eng.step(pipe(*ds.batch([2 * it, 2 * it + 1])))
+            torch.cuda.synchronize()
+            assert np.isfinite(float(out['loss'])) and float(out['loss']) > 0
+        assert order == [0, 1, 2, 3, 4] * 2, order
+        lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
+        assert red.flat.numel() * 4 > 730e6
+        assert all(lo <= p.grad.data_ptr() < hi for p in red.params)
+        same = [n for n, p in det.named_parameters() if p.requires_grad and torch.equal(p.detach(), w0[n])]
+        assert not same, same[:5]
+    finally:
+        hip_conv.enable(False)
+        dist.destroy_process_group()
