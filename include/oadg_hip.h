@@ -448,6 +448,23 @@ int oadg_prep_conv_weights_bwd(const void* gwf, const float* gbias, const float*
                                const float* mean, const float* var, float eps, int K, int C, int R, int S, float* dw,
                                float* dgamma, int w_krsc, void* stream);
 
+/* 1x1 convolutions with at most 16 output channels (round 4): the RPN head - rpn_cls + rpn_reg, 3 + 12 channels per
+ * pixel (dense_heads/rpn_head.py:54-68) - on 16-channel-wide maps (32-byte pixel rows) instead of a 128-channel tile.
+ * x bf16 [M][C] (C = 128 or 256), w16 bf16 [16][C] (rows past the live output channels zero), bias16 fp32 [16] or NULL,
+ * y bf16 [M][16].  _dgrad: dx[m][c] = sum_k dy[m][k] wt[c][k] (wt bf16 [C][16]) with the data-gradient epilogue of
+ * oadg_conv2d_nhwc_bf16_ex: mask_bits (one bit per element of dx, [M][C / 8] bytes) or NULL, colsum_part
+ * [oadg_conv1x1_n16_dgrad_rows(M)][C] partial column sums of the stored dx or NULL (reduce: oadg_colsum_reduce).
+ * _wgrad: part [rows][16][C] fp32 split partials of dW[k][c] = sum_m dy[m][k] x[m][c] and bias_part [rows][16] of
+ * sum_m dy[m][k], rows = oadg_conv1x1_n16_wgrad_rows(M) (sum the rows in order: deterministic). */
+int oadg_conv1x1_n16_fwd(const void* x, const void* w16, const float* bias16, void* y, long M, int C, void* stream);
+long oadg_conv1x1_n16_dgrad_rows(long M);
+int oadg_conv1x1_n16_dgrad(const void* dy, const void* wt, void* dx, const void* mask_bits, float* colsum_part, long M, int C,
+                           void* stream);
+long oadg_conv1x1_n16_wgrad_splits(long M);
+long oadg_conv1x1_n16_wgrad_rows(long M);
+int oadg_conv1x1_n16_wgrad(const void* x, const void* dy, float* part, float* bias_part, const void* zeros16, long M, int C,
+                           void* stream);
+
 /* ResNet stem convolution (backbones/resnet.py:585-596 conv1: 7x7, stride 2, padding 3, 3 -> 64 channels) on the matrix
  * cores: x bf16 NHWC [N,H,W,3], wp = prepared weights bf16 [64][7][8][4] (k = filter row, 8 input pixels starting
  * one left of the filter - pixel 0 zero -, 4 channels - channel 3 zero), y = round_bf16(conv) NHWC [N,Ho,Wo,64] without

@@ -112,6 +112,12 @@ SIGNATURES = {
     'oadg_sample_select': (ci, [vp, ci, cl, ci, vp, vp, vp, ctypes.c_size_t, vp]),
     'oadg_anchor_targets': (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_colsum_reduce_multi': (ci, [vp, ci, ci, vp]),
+    'oadg_conv1x1_n16_fwd': (ci, [vp, vp, vp, vp, cl, ci, vp]),
+    'oadg_conv1x1_n16_dgrad_rows': (cl, [cl]),
+    'oadg_conv1x1_n16_dgrad': (ci, [vp, vp, vp, vp, vp, cl, ci, vp]),
+    'oadg_conv1x1_n16_wgrad_splits': (cl, [cl]),
+    'oadg_conv1x1_n16_wgrad_rows': (cl, [cl]),
+    'oadg_conv1x1_n16_wgrad': (ci, [vp, vp, vp, vp, vp, cl, ci, vp]),
     'oadg_conv2d_wgrad_multi_plan': (ctypes.c_long, [vp, ci, ci]),
     'oadg_conv2d_wgrad_multi': (ci, [vp, ci, ci, vp, vp]),
     'oadg_prep_conv_weights_bwd_parts_multi': (ci, [vp, ci, ci, ci, vp]),

@@ -388,8 +388,14 @@ class RPNHead(AnchorHead):
             x = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok,
                        in_token=getattr(x, '_oadg_token', None), owner=c)
             if getattr(x.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA'):
-                w, b = self._fused_head_params()
-                y = conv2d(x, w, b, 1, 0, 1, in_token=tok)
+                if hip_conv.NARROW_HEAD and n_cls + n_reg <= 16 and self.feat_channels in (128, 256) and \
+                        self.rpn_cls.bias is not None and self.rpn_reg.bias is not None:
+                    # round 4: 16-channel-wide head maps (csrc/narrow_head.hip) instead of a 128-channel tile with 15 live
+                    # channels - the head's output and its gradient are written and re-read by five passes per step
+                    y = hip_conv.narrow_head(x, *self._narrow_head_params(), in_token=tok)
+                else:
+                    w, b = self._fused_head_params()
+                    y = conv2d(x, w, b, 1, 0, 1, in_token=tok)
                 cls, reg = _SplitHeads.apply(y, n_cls, n_reg)
                 cls._oadg_y = y          # (AnchorHead._fused_loss reads the head's map in place)
                 return cls, reg
@@ -413,12 +419,25 @@ class RPNHead(AnchorHead):
             self._fused_cache = c
         return c
 
+    def _narrow_head_params(self):
+        """[rpn_cls; rpn_reg] weight / bias and their 16-row bf16 forms for csrc/narrow_head.hip, built once per forward pass"""
+        c = getattr(self, '_narrow_cache', None)
+        if c is not None:
+            return c
+        from . import hip_conv
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight])
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias])
+        c = (w, b) + hip_conv.narrow_params(w, b)
+        if torch.is_grad_enabled():
+            self._narrow_cache = c
+        return c
+
     def forward(self, feats):
-        self._fused_cache = None
+        self._fused_cache = self._narrow_cache = None
         try:
             return super().forward(feats)
         finally:
-            self._fused_cache = None
+            self._fused_cache = self._narrow_cache = None
 
     def loss(self, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
         losses = super().loss(cls_scores, bbox_preds, gt_bboxes, None, img_metas,

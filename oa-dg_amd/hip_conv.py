@@ -1006,6 +1006,87 @@ class _Conv2dMFMA(torch.autograd.Function):
         return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None, None, None, None, None
 
 
+NARROW_HEAD = os.environ.get('OADG_NARROW_HEAD', '1') == '1'
+
+
+def narrow_params(w_cat, b_cat):
+    """(w16 bf16 [16, C], wt16 bf16 [C, 16], b16 fp32 [16]) of a 1x1 convolution with <= 16 output channels: the operands of
+    csrc/narrow_head.hip (rows / entries past the live channels zero).  Built once per forward pass by the caller."""
+    KN, C = w_cat.shape[0], w_cat.shape[1]
+    with torch.no_grad():
+        w16 = torch.zeros((16, C), dtype=torch.bfloat16, device=w_cat.device)
+        w16[:KN].copy_(w_cat.detach().reshape(KN, C))
+        wt16 = w16.t().contiguous()
+        b16 = torch.zeros((16,), dtype=torch.float32, device=w_cat.device)
+        if b_cat is not None:
+            b16[:KN].copy_(b_cat.detach())
+    return w16, wt16, b16
+
+
+class _NarrowHead(torch.autograd.Function):
+    """y [N, 16, H, W] = conv1x1(x, w) + b for a head with <= 16 output channels (the RPN head's rpn_cls + rpn_reg,
+    rpn_head.py:54-68) on 16-channel-wide maps: csrc/narrow_head.hip forward / data gradient / weight gradient.  The data
+    gradient finishes ``in_token`` (ReLU mask bits + bias-gradient column sums of the tensor x = relu(rpn_conv(...)))
+    like _Conv2dMFMA's does."""
+
+    @staticmethod
+    def forward(ctx, x, w_cat, b_cat, w16, wt16, b16, in_token):
+        L = _lib.lib()
+        x16 = _nhwc_bf16(x)
+        N, C, H, W = x16.shape
+        if in_token is not None:
+            in_token.armed = True
+        y = torch.empty((N, 16, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
+        check(L.oadg_conv1x1_n16_fwd(ptr(x16), ptr(w16), ptr(b16), ptr(y), N * H * W, C, stream_ptr()), 'oadg_conv1x1_n16_fwd')
+        ctx.save_for_backward(x16, wt16)
+        ctx.meta = (w_cat.shape[0], x.dtype, b_cat is not None)
+        ctx.token = in_token
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x16, wt16 = ctx.saved_tensors
+        KN, xdt, has_b = ctx.meta
+        tok = ctx.token
+        N, C, H, W = x16.shape
+        M = N * H * W
+        gy = _nhwc_bf16(gy)
+        gx = dw = db = None
+        extra = None
+        if tok is not None:
+            extra, tok.extra = tok.extra, None
+            tok.closed = True
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=gy.device, memory_format=torch.channels_last)
+            mb = tok.bits if (tok is not None and tok.masked) else None
+            finish = tok is not None and extra is None and (mb is not None or not tok.masked)
+            part = None
+            if finish:
+                part = torch.empty((L.oadg_conv1x1_n16_dgrad_rows(M), C), dtype=torch.float32, device=gy.device)
+            check(L.oadg_conv1x1_n16_dgrad(ptr(gy), ptr(wt16), ptr(gx), ptr(mb) if finish else None, ptr(part), M, C,
+                                           stream_ptr()), 'oadg_conv1x1_n16_dgrad')
+            if finish:
+                tok.colsum = _colsum(part, C)
+                tok.grad_ptr = gx.data_ptr()
+            elif extra is not None:
+                gx = gx + extra               # (another consumer deposited a gradient: the producer masks / reduces the sum)
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            rows = L.oadg_conv1x1_n16_wgrad_rows(M)
+            part = torch.empty((rows, 16, C), dtype=torch.float32, device=gy.device)
+            bpart = torch.empty((rows, 16), dtype=torch.float32, device=gy.device)
+            check(L.oadg_conv1x1_n16_wgrad(ptr(x16), ptr(gy), ptr(part), ptr(bpart), ptr(_zeros(gy.device)), M, C,
+                                           stream_ptr()), 'oadg_conv1x1_n16_wgrad')
+            dw = part.sum(0)[:KN].reshape(KN, C, 1, 1)
+            if has_b:
+                db = bpart.sum(0)[:KN]
+        return (gx.to(xdt) if gx is not None else None), dw, db, None, None, None, None
+
+
+def narrow_head(x, w_cat, b_cat, w16, wt16, b16, in_token=None):
+    return _NarrowHead.apply(x, w_cat, b_cat, w16, wt16, b16, in_token)
+
+
 def _norm3(stride, padding, dilation):
     t = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v, v)  # noqa: E731
     return t(stride), t(padding), t(dilation)

@@ -1013,3 +1013,102 @@ def test_deferred_grouped_weight_gradients_in_a_backward_pass(dev, monkeypatch):
     finally:
         hip_conv.enable(False)
         hip_conv.DEFER_COLSUM = hip_conv.DEFER_WGRAD = False
+
+
+@pytest.mark.parametrize('C,M', [(256, 2 * 40 * 56), (256, 4 * 13 * 7 + 3), (128, 64 * 9 + 1), (256, 8 * 256 * 512 // 16)])
+def test_narrow_head_kernels_match_fp32(dev, C, M):
+    """csrc/narrow_head.hip: the 16-output-channel 1x1 forward, data gradient (+ ReLU mask bits + column sums) and weight
+    gradient (+ bias gradient) against fp32 matmuls on the same bf16 operands - ragged pixel counts included."""
+    from oadg_amd import _lib
+    from oadg_amd.hip_conv import ptr, stream_ptr, check, _zeros
+    L = _lib.lib()
+    g = torch.Generator(device=dev).manual_seed(C + M)
+    x = torch.randn(M, C, device=dev, generator=g).to(torch.bfloat16)
+    w = torch.zeros(16, C, device=dev)
+    w[:15] = torch.randn(15, C, device=dev, generator=g) * 0.05
+    w16 = w.to(torch.bfloat16)
+    b = torch.zeros(16, device=dev)
+    b[:15] = torch.randn(15, device=dev, generator=g)
+    y = torch.full((M, 16), float('nan'), device=dev, dtype=torch.bfloat16)
+    check(L.oadg_conv1x1_n16_fwd(ptr(x), ptr(w16), ptr(b), ptr(y), M, C, stream_ptr()), 'fwd')
+    ref = x.float() @ w16.float().t() + b
+    assert torch.equal(y, ref.to(torch.bfloat16)) or (y.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+    assert (y[:, 15] == 0).all()
+
+    dy = torch.randn(M, 16, device=dev, generator=g).to(torch.bfloat16)
+    dy[:, 15] = 0
+    wt = w16.t().contiguous()
+    mask = torch.rand(M, C, device=dev, generator=g) < 0.6
+    bits = (mask.view(M, C // 8, 8).to(torch.int32) << torch.arange(8, device=dev, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    rows = L.oadg_conv1x1_n16_dgrad_rows(M)
+    for masked in (False, True):
+        dx = torch.full((M, C), float('nan'), device=dev, dtype=torch.bfloat16)
+        part = torch.full((rows, C), float('nan'), device=dev)
+        check(L.oadg_conv1x1_n16_dgrad(ptr(dy), ptr(wt), ptr(dx), ptr(bits) if masked else None, ptr(part), M, C,
+                                       stream_ptr()), 'dgrad')
+        r = dy.float() @ w16.float()
+        if masked:
+            r = r * mask
+        assert (dx.float() - r).abs().max().item() <= 2 ** -7 * r.abs().max().item() + 1e-6
+        cs = part.sum(0)
+        rc = r.to(torch.bfloat16).float().sum(0)
+        assert (cs - rc).abs().max().item() <= 2e-3 * rc.abs().max().item() + 1e-3, (cs - rc).abs().max().item()
+    # (no column sums asked for)
+    dx2 = torch.empty_like(dx)
+    check(L.oadg_conv1x1_n16_dgrad(ptr(dy), ptr(wt), ptr(dx2), ptr(bits), None, M, C, stream_ptr()), 'dgrad')
+    assert torch.equal(dx2, dx)
+
+    rows = L.oadg_conv1x1_n16_wgrad_rows(M)
+    part = torch.full((rows, 16, C), float('nan'), device=dev)
+    bpart = torch.full((rows, 16), float('nan'), device=dev)
+    check(L.oadg_conv1x1_n16_wgrad(ptr(x), ptr(dy), ptr(part), ptr(bpart), ptr(_zeros(dev)), M, C, stream_ptr()), 'wgrad')
+    dw = part.sum(0)
+    rw = dy.float().t() @ x.float()
+    assert (dw - rw).abs().max().item() <= 1e-3 * rw.abs().max().item() + 1e-4, (dw - rw).abs().max().item()
+    rb = dy.float().sum(0)
+    assert (bpart.sum(0) - rb).abs().max().item() <= 1e-3 * rb.abs().max().item() + 1e-4
+
+
+def test_rpn_head_narrow_matches_padded_tile(dev, monkeypatch):
+    """The RPN head on 16-channel maps (csrc/narrow_head.hip) against the same head on the zero-padded 128-channel tile:
+    outputs bit-equal (same bf16 operands, fp32 accumulation - up to summation order), gradients of every parameter and of
+    the input within bf16 rounding."""
+    from oadg_amd import hip_conv
+    from oadg_amd.dense_heads import RPNHead
+    torch.manual_seed(0)
+    head = RPNHead(in_channels=256, feat_channels=256,
+                   anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4]),
+                   loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                   loss_bbox=dict(type='L1Loss', loss_weight=1.0)).to(dev)
+    for m in (head.rpn_conv, head.rpn_cls, head.rpn_reg):
+        torch.nn.init.normal_(m.weight, 0, 0.05)
+        torch.nn.init.normal_(m.bias, 0, 0.1)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x0 = torch.randn(2, 256, 40, 56, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    gc = torch.randn(2, 3, 40, 56, device=dev, generator=g)
+    gr = torch.randn(2, 12, 40, 56, device=dev, generator=g)
+    res = {}
+    hip_conv.enable(True)
+    try:
+        for mode in (True, False):
+            monkeypatch.setattr(hip_conv, 'NARROW_HEAD', mode)
+            head.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                cls, reg = head((x,))
+                cls, reg = cls[0], reg[0]
+            assert cls._oadg_y.shape[1] == (16 if mode else 128)
+            ((cls.float() * gc).sum() + (reg.float() * gr).sum()).backward()
+            res[mode] = (cls.detach().float(), reg.detach().float(), x.grad.float(),
+                         {n: p.grad.float().clone() for n, p in head.named_parameters()})
+    finally:
+        hip_conv.enable(False)
+    for i in (0, 1):
+        d = (res[True][i] - res[False][i]).abs()
+        assert d.max().item() <= 2 ** -7 * res[False][i].abs().max().item()
+    def close(a, b, what, tol):
+        d = (a - b).abs()
+        assert d.max().item() <= tol * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
+    close(res[True][2], res[False][2], 'x.grad', 1e-2)
+    for n in res[False][3]:
+        close(res[True][3][n], res[False][3][n], n, 1e-2)
