@@ -31,6 +31,11 @@ __device__ __forceinline__ void glds16n(const void* g, void* l) {
 #define ZERO8 (bf16x8{0, 0, 0, 0, 0, 0, 0, 0})
 
 // ---------------------------------------------------------------------------------------------------------------- forward
+// The reduction index of MFMA ks is a permutation of the channels (the same for both operands): lane quarter fq takes the
+// 8 channels at 64 (ks / 2) + 16 fq + 8 (ks % 2), so that a lane's two loads of an MFMA pair are 32 contiguous bytes and
+// the four quarters of a pixel cover one 128-byte line per pair (instead of 64 bytes of two lines).
+__device__ __forceinline__ int kofs(int ks, int fq) { return 64 * (ks >> 1) + 16 * fq + 8 * (ks & 1); }
+
 // One wave = one 16-pixel tile per trip (grid-stride: the chip streams through one compact window of x); the 8 (C = 256)
 // fragment loads of a tile are independent 16-byte loads, two tiles in flight per wave.
 template <int C>
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void n16_fwd_kernel(const unsigned short* __re
     const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
     bf16x8 a[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(w16 + (size_t)fr * C + ks * 32 + fq * 8);
+    for (int ks = 0; ks < KS; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(w16 + (size_t)fr * C + kofs(ks, fq));
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = bias16 ? bias16[4 * fq + r] : 0.f;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void n16_fwd_kernel(const unsigned short* __re
             const bool ok = (t + u * nw) < n_tiles && p[u] < M;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                b[u][ks] = ok ? *reinterpret_cast<const bf16x8*>(x + (size_t)p[u] * C + ks * 32 + fq * 8) : ZERO8;
+                b[u][ks] = ok ? *reinterpret_cast<const bf16x8*>(x + (size_t)p[u] * C + kofs(ks, fq)) : ZERO8;
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -77,32 +82,38 @@ __global__ __launch_bounds__(256) void n16_fwd_kernel(const unsigned short* __re
 
 // ---------------------------------------------------------------------------------------------------------- data gradient
 // Per 16-pixel tile one 16-byte load of dy per lane (k-groups 2, 3 are the zero padding of the reduction), C / 16 MFMAs
-// against the register-resident w^T fragments; a lane ends up with 4 consecutive channels of its pixel per MFMA.
+// against the register-resident w^T fragments.  The A rows of the four MFMAs of a 64-channel quad are a permutation of
+// its channels - row 4 fq + r of MFMA j is channel 64 q + 32 (j / 2) + 8 fq + 4 (j % 2) + r - so that a lane ends up with
+// two runs of 8 consecutive channels of its pixel per quad: two 16-byte stores, in each of which the four quarters of a
+// pixel write 64 contiguous bytes (the whole 128-byte line between them).
 template <int C>
 __global__ __launch_bounds__(256) void n16_dgrad_kernel(const unsigned short* __restrict__ dy,
                                                         const unsigned short* __restrict__ wt,
                                                         unsigned short* __restrict__ dx,
                                                         const unsigned char* __restrict__ bits,
                                                         float* __restrict__ colsum_part, long M) {
-    constexpr int CG = C / 16, NW32 = C / 32;
+    constexpr int NQ = C / 64, NW32 = C / 32;
     __shared__ float red[4][C];
     const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, wave = threadIdx.x >> 6;
     const long gw = (long)blockIdx.x * 4 + wave, nw = (long)gridDim.x * 4;
-    bf16x8 a[CG];
+    bf16x8 a[NQ][4];
 #pragma unroll
-    for (int cg = 0; cg < CG; ++cg)
-        a[cg] = fq < 2 ? *reinterpret_cast<const bf16x8*>(wt + (size_t)(cg * 16 + fr) * 16 + fq * 8) : ZERO8;
-    float csum[CG][4];
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
-    for (int cg = 0; cg < CG; ++cg)
+        for (int j = 0; j < 4; ++j)
+            a[q][j] = fq < 2 ? *reinterpret_cast<const bf16x8*>(wt + (size_t)(64 * q + 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3)) * 16 + fq * 8)
+                             : ZERO8;
+    float csum[NQ][16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) csum[cg][r] = 0.f;
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) csum[q][e] = 0.f;
     const long n_tiles = (M + 15) >> 4;
-    for (long t = gw; t < n_tiles; t += nw) {
+    // one tile ahead: the next tile's dy row and mask words are in flight while this one is multiplied and stored
+    auto fetch = [&](long t, bf16x8& b, unsigned (&mb)[NW32]) {
         const long p = t * 16 + fr;
-        const bool ok = p < M;
-        const bf16x8 b = (ok && fq < 2) ? *reinterpret_cast<const bf16x8*>(dy + (size_t)p * 16 + fq * 8) : ZERO8;
-        unsigned mb[NW32];
+        const bool ok = t < n_tiles && p < M;
+        b = (ok && fq < 2) ? *reinterpret_cast<const bf16x8*>(dy + (size_t)p * 16 + fq * 8) : ZERO8;
         if (bits) {
 #pragma unroll
             for (int j = 0; j < NW32; j += 4) {
@@ -110,38 +121,66 @@ __global__ __launch_bounds__(256) void n16_dgrad_kernel(const unsigned short* __
                 mb[j] = v.x; mb[j + 1] = v.y; mb[j + 2] = v.z; mb[j + 3] = v.w;
             }
         }
+    };
+    bf16x8 b, bn;
+    unsigned mb[NW32], mbn[NW32];
+    fetch(gw, bn, mbn);
+    for (long t = gw; t < n_tiles; t += nw) {
+        const long p = t * 16 + fr;
+        const bool ok = p < M;
+        b = bn;
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg) {
-            f32x4n acc = {0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[cg], b, acc, 0, 0, 0);
-            unsigned short o[4];
+        for (int j = 0; j < NW32; ++j) mb[j] = mbn[j];
+        fetch(t + nw, bn, mbn);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(acc[r]);
+        for (int q = 0; q < NQ; ++q) {
+            unsigned short o[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q][j], b, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[4 * j + r] = f32_to_bf16(acc[r]);
+            }
             if (bits) {
-                // bit e of byte j = channel 8 j + e (little-endian words): channels cg * 16 + 4 fq .. + 3 sit in word cg / 2
-                const unsigned nib = (mb[cg >> 1] >> ((cg & 1) * 16 + 4 * fq)) & 15u;
+                // bit e of byte j = channel 8 j + e (little-endian words): o[8 h ..] = channels 64 q + 32 h + 8 fq .. + 7 are
+                // byte fq of word 2 q + h
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (!((nib >> r) & 1u)) o[r] = 0;
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned byte = (mb[2 * q + h] >> (8 * fq)) & 0xffu;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (!((byte >> e) & 1u)) o[8 * h + e] = 0;
+                }
             }
             if (ok) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) csum[cg][r] += bf16_to_f32(o[r]);
-                uint2 pk;
-                pk.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
-                pk.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
-                *reinterpret_cast<uint2*>(dx + (size_t)p * C + cg * 16 + 4 * fq) = pk;
+                for (int e = 0; e < 16; ++e) csum[q][e] += bf16_to_f32(o[e]);
+                uint4 pk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    pk[h].x = (unsigned)o[8 * h + 0] | ((unsigned)o[8 * h + 1] << 16);
+                    pk[h].y = (unsigned)o[8 * h + 2] | ((unsigned)o[8 * h + 3] << 16);
+                    pk[h].z = (unsigned)o[8 * h + 4] | ((unsigned)o[8 * h + 5] << 16);
+                    pk[h].w = (unsigned)o[8 * h + 6] | ((unsigned)o[8 * h + 7] << 16);
+                }
+                uint4* dst = reinterpret_cast<uint4*>(dx + (size_t)p * C + 64 * q + 8 * fq);
+                dst[0] = pk[0];                 // (the four quarters of a pixel: 64 contiguous bytes per store)
+                dst[4] = pk[1];
             }
         }
     }
     if (colsum_part) {          // one row of partial column sums per workgroup (fixed order: deterministic)
 #pragma unroll
-        for (int cg = 0; cg < CG; ++cg)
+        for (int q = 0; q < NQ; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = csum[cg][r];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (fr == 0) red[wave][cg * 16 + 4 * fq + r] = v;
+            for (int e = 0; e < 16; ++e) {
+                float v = csum[q][e];           // sum over the 16 pixels of a lane row: rotations within the DPP row
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+                v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+                if (fr == 0) red[wave][64 * q + 32 * (e >> 3) + 8 * fq + (e & 7)] = v;
             }
         __syncthreads();
         for (int c = threadIdx.x; c < C; c += 256)
@@ -281,8 +320,8 @@ int oadg_conv1x1_n16_fwd(const void* x, const void* w16, const float* bias16, vo
 }
 
 long oadg_conv1x1_n16_dgrad_rows(long M) {
-    const long tiles = (M + 15) / 16;
-    return tiles / 16 < 1024 ? (tiles + 15) / 16 : 1024;
+    const long tiles = (M + 15) / 16;           // (165 registers: two workgroups per CU resident - one round of 512)
+    return tiles / 4 < 512 ? (tiles + 3) / 4 : 512;
 }
 
 int oadg_conv1x1_n16_dgrad(const void* dy, const void* wt, void* dx, const void* mask_bits, float* colsum_part, long M, int C,
