@@ -432,9 +432,45 @@ class RPNHead(AnchorHead):
             self._narrow_cache = c
         return c
 
+    def _narrow_ok(self, x):
+        from . import hip_conv
+        n = self.rpn_cls.out_channels + self.rpn_reg.out_channels
+        return hip_conv.NARROW_HEAD and hip_conv.ENABLED and x.is_cuda and n <= 16 and self.feat_channels in (128, 256) and \
+            (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) and torch.is_grad_enabled() and \
+            self.rpn_cls.bias is not None and self.rpn_reg.bias is not None
+
+    def _forward_narrow(self, feats):
+        """all pyramid levels through the 16-channel head as ONE autograd node (hip_conv._NarrowHead): rpn_conv per level,
+        then the shared rpn_cls + rpn_reg on every level whose rpn_conv ran on the MFMA kernels"""
+        from . import hip_conv
+        c = self.rpn_conv
+        n_cls, n_reg = self.rpn_cls.out_channels, self.rpn_reg.out_channels
+        hs, toks = [], []
+        for x in feats:
+            tok = hip_conv.GradToken()
+            h = conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, relu=True, out_token=tok,
+                       in_token=getattr(x, '_oadg_token', None), owner=c)
+            hs.append(h)
+            toks.append(tok if getattr(h.grad_fn, 'name', lambda: '')().startswith('_Conv2dMFMA') else None)
+        sel = [i for i, t in enumerate(toks) if t is not None]
+        ys = dict(zip(sel, hip_conv.narrow_head_levels([hs[i] for i in sel], *self._narrow_head_params(),
+                                                        tokens=[toks[i] for i in sel]))) if sel else {}
+        cls_scores, bbox_preds = [], []
+        for i, h in enumerate(hs):
+            if i in ys:
+                cls, reg = _SplitHeads.apply(ys[i], n_cls, n_reg)
+                cls._oadg_y = ys[i]      # (AnchorHead._fused_loss reads the head's map in place)
+            else:
+                cls, reg = self.rpn_cls(h), self.rpn_reg(h)
+            cls_scores.append(cls)
+            bbox_preds.append(reg)
+        return cls_scores, bbox_preds
+
     def forward(self, feats):
         self._fused_cache = self._narrow_cache = None
         try:
+            if len(feats) and self._narrow_ok(feats[0]):
+                return self._forward_narrow(feats)
             return super().forward(feats)
         finally:
             self._fused_cache = self._narrow_cache = None

@@ -261,6 +261,18 @@ class _WgradJob:
         self.prep, self.targets = None, []
 
 
+class _PartsJob:
+    """a weight gradient whose split partials already exist (a single-layer launch): only its CONSUMER (BN-fold chain rule,
+    layout change, sum over the splits) waits for the group's consumer launch"""
+    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets', 'parts', 'splits')
+
+    def __init__(self, parts, splits, K, C, R, S):
+        self.x = self.gy = None
+        self.geo = (0, 0, 0, C, K, R, S, 1, 0, 1)
+        self.work, self.parts, self.splits = 0, parts, int(splits)
+        self.prep, self.targets = None, []
+
+
 def wgrad_multi(jobs, target_blocks=256):
     """[(x16, gy16, K, R, S, stride, pad, dil)] -> (workspace, [(part pointer, splits)] per job): the weight gradients of
     several layers as fp32 split partials from ONE launch (csrc oadg_conv2d_wgrad_multi)"""
@@ -310,8 +322,11 @@ def flush_wgrads():
     if not jobs:
         return 0
     L = _lib.lib()
-    dev = jobs[0].x.device
-    ws, parts = wgrad_multi([(j.x, j.gy) + j.geo[4:] for j in jobs])
+    dev = jobs[0].prep[1].device
+    launch = [j for j in jobs if j.x is not None]
+    ws, parts = wgrad_multi([(j.x, j.gy) + j.geo[4:] for j in launch]) if launch else (None, [])
+    parts = iter(parts)
+    parts = [next(parts) if j.x is not None else (j.parts.data_ptr(), j.splits) for j in jobs]
     tab = np.zeros(len(jobs), dtype=_PB_JOB)
     first, max_crs = 0, 0
     p_ = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
@@ -335,6 +350,8 @@ def flush_wgrads():
                 g.copy_(alias)
         j.x = j.gy = j.prep = None
         j.targets = []
+        if isinstance(j, _PartsJob):
+            j.parts = None
     return len(jobs)
 
 
@@ -640,6 +657,19 @@ class _PrepWeights(torch.autograd.Function):
             _WQ_WORK += job.work
             if not defer or _WQ_WORK >= WGRAD_GROUP:
                 flush_wgrads()       # (not deferrable after all: the gradient is summed on arrival - run the group now)
+        elif gwf is not None and parts is not None and DEFER_WGRAD and C * R * S <= 36000 and ctx.leaf_inputs and \
+                ent is not None and ent.step == _STEP and ent.count == 1 and all(t.grad is None for t in ent.src):
+            # partials of a single-layer launch inside TrainEngine's backward: their consumer joins the group's (one launch
+            # for all of them instead of one per layer - 14 launches of 9 - 22 us per step)
+            dw = torch.empty_like(w)
+            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            job = _PartsJob(parts[0], parts[1], K, C, R, S)
+            job.prep = (gb_now, w, scale, mean, var, eps, int(krsc) | raw, dw.detach(),
+                        dgamma.detach() if dgamma is not None else None)
+            job.targets.append((ent.src[0], job.prep[7]))
+            if dgamma is not None:
+                job.targets.append((ent.src[1], job.prep[8]))
+            _WQ.append(job)
         elif gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
             dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
             dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
@@ -1024,46 +1054,56 @@ def narrow_params(w_cat, b_cat):
 
 
 class _NarrowHead(torch.autograd.Function):
-    """y [N, 16, H, W] = conv1x1(x, w) + b for a head with <= 16 output channels (the RPN head's rpn_cls + rpn_reg,
-    rpn_head.py:54-68) on 16-channel-wide maps: csrc/narrow_head.hip forward / data gradient / weight gradient.  The data
-    gradient finishes ``in_token`` (ReLU mask bits + bias-gradient column sums of the tensor x = relu(rpn_conv(...)))
-    like _Conv2dMFMA's does."""
+    """ys[l] [N, 16, H_l, W_l] = conv1x1(xs[l], w) + b for a head with <= 16 output channels shared by the pyramid levels
+    (the RPN head's rpn_cls + rpn_reg, rpn_head.py:54-68, anchor_head.py:147-163) on 16-channel-wide maps:
+    csrc/narrow_head.hip forward / data gradient / weight gradient.  All levels are ONE autograd node: the weight / bias
+    gradient partials of every level land in one buffer and are summed once (instead of a sum per level and autograd's
+    accumulation of five gradients).  The data gradient of level l finishes ``toks[l]`` (ReLU mask bits + bias-gradient
+    column sums of x_l = relu(rpn_conv(...))) like _Conv2dMFMA's does."""
 
     @staticmethod
-    def forward(ctx, x, w_cat, b_cat, w16, wt16, b16, in_token):
+    def forward(ctx, w_cat, b_cat, w16, wt16, b16, toks, *xs):
         L = _lib.lib()
-        x16 = _nhwc_bf16(x)
-        N, C, H, W = x16.shape
-        if in_token is not None:
-            in_token.armed = True
-        y = torch.empty((N, 16, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
-        check(L.oadg_conv1x1_n16_fwd(ptr(x16), ptr(w16), ptr(b16), ptr(y), N * H * W, C, stream_ptr()), 'oadg_conv1x1_n16_fwd')
-        ctx.save_for_backward(x16, wt16)
-        ctx.meta = (w_cat.shape[0], x.dtype, b_cat is not None)
-        ctx.token = in_token
-        return y
+        xs16, ys = [], []
+        for x, tok in zip(xs, toks):
+            x16 = _nhwc_bf16(x)
+            N, C, H, W = x16.shape
+            if tok is not None:
+                tok.armed = True
+            y = torch.empty((N, 16, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
+            check(L.oadg_conv1x1_n16_fwd(ptr(x16), ptr(w16), ptr(b16), ptr(y), N * H * W, C, stream_ptr()),
+                  'oadg_conv1x1_n16_fwd')
+            xs16.append(x16)
+            ys.append(y)
+        ctx.save_for_backward(wt16, *xs16)
+        ctx.meta = (w_cat.shape[0], [x.dtype for x in xs], b_cat is not None)
+        ctx.toks = list(toks)
+        return tuple(ys)
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, *gys):
         L = _lib.lib()
-        x16, wt16 = ctx.saved_tensors
-        KN, xdt, has_b = ctx.meta
-        tok = ctx.token
-        N, C, H, W = x16.shape
-        M = N * H * W
-        gy = _nhwc_bf16(gy)
-        gx = dw = db = None
-        extra = None
-        if tok is not None:
-            extra, tok.extra = tok.extra, None
-            tok.closed = True
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=gy.device, memory_format=torch.channels_last)
+        wt16, *xs16 = ctx.saved_tensors
+        KN, xdts, has_b = ctx.meta
+        dev = wt16.device
+        C = xs16[0].shape[1]
+        gys = [_nhwc_bf16(g) if g is not None else torch.zeros((x.shape[0], 16) + tuple(x.shape[2:]), dtype=torch.bfloat16,
+                                                              device=dev).contiguous(memory_format=torch.channels_last)
+               for g, x in zip(gys, xs16)]
+        Ms = [x.shape[0] * x.shape[2] * x.shape[3] for x in xs16]
+        gxs = []
+        for l, (x16, gy, tok, M) in enumerate(zip(xs16, gys, ctx.toks, Ms)):
+            extra = None
+            if tok is not None:
+                extra, tok.extra = tok.extra, None
+                tok.closed = True
+            if not ctx.needs_input_grad[6 + l]:
+                gxs.append(None)
+                continue
+            gx = torch.empty(x16.shape, dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
             mb = tok.bits if (tok is not None and tok.masked) else None
             finish = tok is not None and extra is None and (mb is not None or not tok.masked)
-            part = None
-            if finish:
-                part = torch.empty((L.oadg_conv1x1_n16_dgrad_rows(M), C), dtype=torch.float32, device=gy.device)
+            part = torch.empty((L.oadg_conv1x1_n16_dgrad_rows(M), C), dtype=torch.float32, device=dev) if finish else None
             check(L.oadg_conv1x1_n16_dgrad(ptr(gy), ptr(wt16), ptr(gx), ptr(mb) if finish else None, ptr(part), M, C,
                                            stream_ptr()), 'oadg_conv1x1_n16_dgrad')
             if finish:
@@ -1071,20 +1111,32 @@ class _NarrowHead(torch.autograd.Function):
                 tok.grad_ptr = gx.data_ptr()
             elif extra is not None:
                 gx = gx + extra               # (another consumer deposited a gradient: the producer masks / reduces the sum)
-        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
-            rows = L.oadg_conv1x1_n16_wgrad_rows(M)
-            part = torch.empty((rows, 16, C), dtype=torch.float32, device=gy.device)
-            bpart = torch.empty((rows, 16), dtype=torch.float32, device=gy.device)
-            check(L.oadg_conv1x1_n16_wgrad(ptr(x16), ptr(gy), ptr(part), ptr(bpart), ptr(_zeros(gy.device)), M, C,
-                                           stream_ptr()), 'oadg_conv1x1_n16_wgrad')
+            gxs.append(gx.to(xdts[l]))
+        dw = db = None
+        if ctx.needs_input_grad[0] or (has_b and ctx.needs_input_grad[1]):
+            rows = [int(L.oadg_conv1x1_n16_wgrad_rows(M)) for M in Ms]
+            part = torch.empty((sum(rows), 16, C), dtype=torch.float32, device=dev)
+            bpart = torch.empty((sum(rows), 16), dtype=torch.float32, device=dev)
+            z, off = _zeros(dev), 0
+            for x16, gy, M, r in zip(xs16, gys, Ms, rows):
+                check(L.oadg_conv1x1_n16_wgrad(ptr(x16), ptr(gy), ctypes.c_void_p(part.data_ptr() + off * 16 * C * 4),
+                                               ctypes.c_void_p(bpart.data_ptr() + off * 16 * 4), ptr(z), M, C, stream_ptr()),
+                      'oadg_conv1x1_n16_wgrad')
+                off += r
             dw = part.sum(0)[:KN].reshape(KN, C, 1, 1)
             if has_b:
                 db = bpart.sum(0)[:KN]
-        return (gx.to(xdt) if gx is not None else None), dw, db, None, None, None, None
+        return (dw, db, None, None, None, None) + tuple(gxs)
+
+
+def narrow_head_levels(xs, w_cat, b_cat, w16, wt16, b16, tokens=None):
+    """the 16-channel head on every tensor of ``xs`` (one autograd node, see _NarrowHead): list of [N, 16, H, W] maps"""
+    toks = list(tokens) if tokens is not None else [None] * len(xs)
+    return list(_NarrowHead.apply(w_cat, b_cat, w16, wt16, b16, toks, *xs))
 
 
 def narrow_head(x, w_cat, b_cat, w16, wt16, b16, in_token=None):
-    return _NarrowHead.apply(x, w_cat, b_cat, w16, wt16, b16, in_token)
+    return narrow_head_levels([x], w_cat, b_cat, w16, wt16, b16, [in_token])[0]
 
 
 def _norm3(stride, padding, dilation):

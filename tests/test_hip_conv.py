@@ -1070,45 +1070,45 @@ def test_narrow_head_kernels_match_fp32(dev, C, M):
 
 
 def test_rpn_head_narrow_matches_padded_tile(dev, monkeypatch):
-    """The RPN head on 16-channel maps (csrc/narrow_head.hip) against the same head on the zero-padded 128-channel tile:
-    outputs bit-equal (same bf16 operands, fp32 accumulation - up to summation order), gradients of every parameter and of
-    the input within bf16 rounding."""
+    """The RPN head on 16-channel maps (csrc/narrow_head.hip, all pyramid levels one autograd node) against the same head
+    on the zero-padded 128-channel tile, level by level: outputs equal up to the summation order (same bf16 operands,
+    fp32 accumulation), gradients of every parameter (summed over the levels) and of the inputs within bf16 rounding."""
     from oadg_amd import hip_conv
     from oadg_amd.dense_heads import RPNHead
     torch.manual_seed(0)
     head = RPNHead(in_channels=256, feat_channels=256,
-                   anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4]),
+                   anchor_generator=dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16]),
                    loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
                    loss_bbox=dict(type='L1Loss', loss_weight=1.0)).to(dev)
     for m in (head.rpn_conv, head.rpn_cls, head.rpn_reg):
         torch.nn.init.normal_(m.weight, 0, 0.05)
         torch.nn.init.normal_(m.bias, 0, 0.1)
     g = torch.Generator(device=dev).manual_seed(1)
-    x0 = torch.randn(2, 256, 40, 56, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
-    gc = torch.randn(2, 3, 40, 56, device=dev, generator=g)
-    gr = torch.randn(2, 12, 40, 56, device=dev, generator=g)
+    shapes = [(40, 56), (20, 28), (10, 14)]
+    x0 = [torch.randn(2, 256, h, w, device=dev, generator=g).contiguous(memory_format=torch.channels_last) for h, w in shapes]
+    gc = [torch.randn(2, 3, h, w, device=dev, generator=g) for h, w in shapes]
+    gr = [torch.randn(2, 12, h, w, device=dev, generator=g) for h, w in shapes]
     res = {}
     hip_conv.enable(True)
     try:
         for mode in (True, False):
             monkeypatch.setattr(hip_conv, 'NARROW_HEAD', mode)
             head.zero_grad(set_to_none=True)
-            x = x0.clone().requires_grad_(True)
+            xs = [x.clone().requires_grad_(True) for x in x0]
             with torch.autocast('cuda', dtype=torch.bfloat16):
-                cls, reg = head((x,))
-                cls, reg = cls[0], reg[0]
-            assert cls._oadg_y.shape[1] == (16 if mode else 128)
-            ((cls.float() * gc).sum() + (reg.float() * gr).sum()).backward()
-            res[mode] = (cls.detach().float(), reg.detach().float(), x.grad.float(),
+                cls, reg = head(tuple(xs))
+            assert all(c._oadg_y.shape[1] == (16 if mode else 128) for c in cls)
+            sum((c.float() * a).sum() + (r.float() * b).sum() for c, r, a, b in zip(cls, reg, gc, gr)).backward()
+            res[mode] = ([c.detach().float() for c in cls] + [r.detach().float() for r in reg], [x.grad.float() for x in xs],
                          {n: p.grad.float().clone() for n, p in head.named_parameters()})
     finally:
         hip_conv.enable(False)
-    for i in (0, 1):
-        d = (res[True][i] - res[False][i]).abs()
-        assert d.max().item() <= 2 ** -7 * res[False][i].abs().max().item()
+    for a, b in zip(res[True][0], res[False][0]):
+        assert (a - b).abs().max().item() <= 2 ** -7 * b.abs().max().item()
     def close(a, b, what, tol):
         d = (a - b).abs()
         assert d.max().item() <= tol * b.abs().max().item() + 1e-6, (what, d.max().item(), b.abs().max().item())
-    close(res[True][2], res[False][2], 'x.grad', 1e-2)
-    for n in res[False][3]:
-        close(res[True][3][n], res[False][3][n], n, 1e-2)
+    for l, (a, b) in enumerate(zip(res[True][1], res[False][1])):
+        close(a, b, f'x{l}.grad', 1e-2)
+    for n in res[False][2]:
+        close(res[True][2][n], res[False][2][n], n, 1e-2)

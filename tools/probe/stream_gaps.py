@@ -34,3 +34,13 @@ for g, a, b in gaps:
 print('gaps >= 10 us by (kernel before, kernel after), per step:')
 for (a, b), (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
     print(f'  {n / steps:5.1f} x {t / 1e6 / steps:6.3f} ms   after {a:44s} before {b}')
+# the training queue's small launches (average under 25 us): what the "tail" of the step consists of
+tab = collections.defaultdict(lambda: [0, 0])
+for a, b, k in seg:
+    tab[k][0] += 1
+    tab[k][1] += b - a
+small = {k: v for k, v in tab.items() if v[1] / v[0] < 25e3}
+print(f'launches under 25 us on this queue: {sum(v[0] for v in small.values()) / steps:.0f} per step, '
+      f'{sum(v[1] for v in small.values()) / 1e6 / steps:.3f} ms per step')
+for k, (n, t) in sorted(small.items(), key=lambda kv: -kv[1][1])[:60]:
+    print(f'  {n / steps:6.1f} x {t / n / 1e3:6.1f} us = {t / 1e6 / steps:6.3f} ms   {k}')
