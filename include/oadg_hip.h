@@ -227,6 +227,10 @@ int oadg_oamix_box_profiles(const int* qbox, const double* sigma, int n, int H, 
                             float* Mx, void* stream);
 int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, float* union_f,
                         uint8_t* union_u8, void* stream);
+/* the same union from the masks' support rects (device int32 [n][4]: x0, y0, w, h; w <= 0 = empty mask): work
+ * proportional to the rect areas instead of n * H * W (a 4096-box image: 4.3 ms -> < 0.1 ms).  Byte-identical outputs. */
+int oadg_oamix_fg_union_rects(const float* My, const float* Mx, const int* rects_dev, int n, int H, int W, float* union_f,
+                              uint8_t* union_u8, void* stream);
 /* workspace: oadg_oamix_saliency_workspace_bytes(n) bytes (the 64x64 maps and integer totals between the launches) */
 size_t oadg_oamix_saliency_workspace_bytes(int n);
 int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
@@ -290,6 +294,13 @@ int oadg_oamix_final(const uint8_t* img, const float* acc, int H, int W, const o
                      int n_targets, const float* My, const float* Mx, double m_beta, const float* mean_host,
                      const float* stdinv_host, int to_rgb, uint8_t* out_u8, void* out_norm, int out_dtype,
                      int Hp, int Wp, void* stream);
+/* oadg_oamix_final for images with many targets: targets binned into 32 x 32 pixel tiles (in target order), a pixel only
+ * visits its tile's list.  fg_rects_dev as for oadg_oamix_fg_union_rects; 1 <= n_targets <= 65535.  Byte-identical. */
+size_t oadg_oamix_final_tiles_workspace_bytes(int H, int W, int n_targets);
+int oadg_oamix_final_tiles(const uint8_t* img, const float* acc, int H, int W, const oadg_mix_target* targets,
+                           int n_targets, const int* fg_rects_dev, const float* My, const float* Mx, double m_beta,
+                           const float* mean_host, const float* stdinv_host, int to_rgb, uint8_t* out_u8, void* out_norm,
+                           int out_dtype, int Hp, int Wp, void* workspace, size_t workspace_bytes, void* stream);
 int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_host, const float* stdinv_host,
                          int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
 

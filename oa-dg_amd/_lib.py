@@ -133,6 +133,7 @@ SIGNATURES = {
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
+    'oadg_oamix_fg_union_rects': (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_saliency_workspace_bytes': (cs, [ci]),
     'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp, cs, vp]),
     'oadg_oamix_hist': (ci, [vp, cl, vp, vp]),
@@ -147,6 +148,9 @@ SIGNATURES = {
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
                               ci, vp]),
+    'oadg_oamix_final_tiles_workspace_bytes': (ctypes.c_size_t, [ci, ci, ci]),
+    'oadg_oamix_final_tiles': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
+                                    ci, vp, ctypes.c_size_t, vp]),
     'oadg_oamix_normalize': (ci, [vp, ci, ci, POINTER(cf), POINTER(cf), ci, vp, ci, ci, ci, vp]),
 }
 

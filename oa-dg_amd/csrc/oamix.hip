@@ -183,6 +183,33 @@ __global__ void fg_union_kernel(const float* __restrict__ My, const float* __res
     u8[p] = (uint8_t)(m * 255.0f);
 }
 
+// The same union for MANY boxes (a 4096-box image: the loop above is 8.6 G mask evaluations, 4.3 ms): every mask is zero
+// outside its support rect (`rects` [n][4] = x0, y0, w, h; w <= 0: empty), and all mask values are >= 0, so the union is
+// the maximum of 0 and the masks over their rects - one workgroup row per box, integer atomicMax on the float bits (the
+// order of non-negative floats is the order of their bit patterns; a maximum does not depend on the visiting order:
+// bit-identical to fg_union_kernel).  `uf` must be zero on entry.
+__global__ __launch_bounds__(256) void fg_union_scatter_kernel(const float* __restrict__ My, const float* __restrict__ Mx,
+                                                               const int* __restrict__ rects, int H, int W,
+                                                               unsigned* __restrict__ uf_bits) {
+    const int i = blockIdx.x;
+    const int x0 = rects[4 * i], y0 = rects[4 * i + 1], rw = rects[4 * i + 2], rh = rects[4 * i + 3];
+    if (rw <= 0 || rh <= 0) return;
+    const float* my = My + (size_t)i * H;
+    const float* mx = Mx + (size_t)i * W;
+    const int area = rw * rh;
+    for (int q = blockIdx.y * 256 + threadIdx.x; q < area; q += gridDim.y * 256) {
+        const int yy = q / rw, xx = q - yy * rw;
+        const int x = x0 + xx, y = y0 + yy;
+        if (x < 0 || y < 0 || x >= W || y >= H) continue;
+        const float v = my[y] * mx[x];
+        if (v > 0.f) atomicMax(uf_bits + (size_t)y * W + x, __float_as_uint(v));
+    }
+}
+__global__ void fg_union_u8_kernel(const float* __restrict__ uf, long npix, uint8_t* __restrict__ u8) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npix) u8[p] = (uint8_t)(uf[p] * 255.0f);
+}
+
 // ------------------------------------------------------------------------------------------------ histogram / LUTs
 __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ img, long npix,
                                                    int* __restrict__ hist) {
@@ -616,14 +643,65 @@ __device__ __forceinline__ void write_norm(T* out, int Wp, int x, int y, const u
     }
 }
 
-template <typename T>
+// Tile bins of the mixing targets (images with many of them: every target at every pixel is n_tg x H x W mask
+// evaluations - 1.2 ms for the ~4100 targets of a 4096-box image).  A target whose mask is zero at a pixel leaves the
+// pixel's running sums untouched (mask_sum + 0, max(mask_max, 0), weight 0: every update adds +0), so a pixel only has to
+// visit, IN TARGET ORDER, the targets whose rect (support rect of the fg mask / the random box) reaches its 32 x 32 tile.
+// One workgroup per tile compacts the target indices in order (ballot + prefix over the waves): `lists` [tiles][cap]
+// uint16, `counts` [tiles] (a count above cap = list truncated: the pixels of that tile visit every target).
+constexpr int MIX_TS = 32;
+__global__ __launch_bounds__(256) void mix_bins_kernel(const oadg_mix_target* __restrict__ tg, int n_tg,
+                                                       const int* __restrict__ fg_rects, int tiles_x, int cap,
+                                                       int* __restrict__ counts, unsigned short* __restrict__ lists) {
+    __shared__ int wcnt[4];
+    const int tile = blockIdx.x, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int X0 = tx * MIX_TS, Y0 = ty * MIX_TS, X1 = X0 + MIX_TS, Y1 = Y0 + MIX_TS;      // [X0, X1) x [Y0, Y1)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned short* out = lists + (size_t)tile * cap;
+    int total = 0;
+    for (int base = 0; base < n_tg; base += 256) {
+        const int t = base + threadIdx.x;
+        bool hit = false;
+        if (t < n_tg) {
+            const oadg_mix_target g = tg[t];
+            int x0, y0, x1, y1;
+            if (g.fg_index >= 0) {
+                const int* r = fg_rects + 4 * g.fg_index;
+                x0 = r[0]; y0 = r[1]; x1 = r[0] + r[2]; y1 = r[1] + r[3];
+            } else {
+                x0 = g.rect[0]; y0 = g.rect[1]; x1 = g.rect[2]; y1 = g.rect[3];
+            }
+            hit = x0 < X1 && x1 > X0 && y0 < Y1 && y1 > Y0;
+        }
+        const unsigned long long m = __ballot(hit);
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, nh = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            if (w2 < wave) before += wcnt[w2];
+            nh += wcnt[w2];
+        }
+        if (hit) {
+            const int pos = total + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) out[pos] = (unsigned short)t;
+        }
+        total += nh;
+    }
+    if (threadIdx.x == 0) counts[tile] = total;
+}
+
+template <typename T, bool BINNED>
 __global__ __launch_bounds__(256) void final_mix_kernel(const uint8_t* __restrict__ img,
                                                         const float* __restrict__ acc, int H, int W,
                                                         const oadg_mix_target* __restrict__ tg, int n_tg,
                                                         const float* __restrict__ My,
                                                         const float* __restrict__ Mx, double m_beta,
                                                         NormArgs nrm, uint8_t* __restrict__ out_u8,
-                                                        T* __restrict__ out_norm, int Hp, int Wp) {
+                                                        T* __restrict__ out_norm, int Hp, int Wp,
+                                                        const int* __restrict__ counts,
+                                                        const unsigned short* __restrict__ lists, int tiles_x, int cap) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     if (p >= (long)Hp * Wp) return;
     const int y = (int)(p / Wp), x = (int)(p - (long)y * Wp);
@@ -636,13 +714,21 @@ __global__ __launch_bounds__(256) void final_mix_kernel(const uint8_t* __restric
 #pragma unroll
     for (int c = 0; c < 3; ++c) { im[c] = (float)img[q + c]; ag[c] = acc[q + c]; }
     float mask_sum = 0.f, mask_max = 0.f;
-    for (int t = 0; t < n_tg; ++t) {
+    int n_visit = n_tg;
+    const unsigned short* list = nullptr;
+    if (BINNED) {
+        const int tile = (y / MIX_TS) * tiles_x + x / MIX_TS;
+        const int cnt = counts[tile];
+        if (cnt <= cap) { n_visit = cnt; list = lists + (size_t)tile * cap; }
+    }
+    for (int j = 0; j < n_visit; ++j) {
+        const int t = (BINNED && list) ? (int)list[j] : j;
         const oadg_mix_target g = tg[t];
         float mask;
         if (g.fg_index >= 0) mask = My[(size_t)g.fg_index * H + y] * Mx[(size_t)g.fg_index * W + x];
         else mask = (x >= g.rect[0] && x < g.rect[2] && y >= g.rect[1] && y < g.rect[3]) ? 1.0f : 0.0f;
         mask_sum = mask_sum + mask;
-        mask_max = t == 0 ? mask : fmaxf(mask_max, mask);
+        mask_max = j == 0 ? mask : fmaxf(mask_max, mask);         // (masks are >= 0 and mask_max starts at 0: the same)
         const float overlap = mask_sum - mask_max;
         const float wgt = mask - overlap * 0.5f;
         const float a = 1.0f - g.m_oa;
@@ -921,6 +1007,25 @@ int oadg_oamix_fg_union(const float* My, const float* Mx, int n, int H, int W, f
     return OADG_OK;
 }
 
+// as oadg_oamix_fg_union, given the masks' support rects on the device (int32 [n][4]: x0, y0, w, h; w <= 0 = empty mask):
+// work proportional to the rect areas instead of n x H x W.  Byte-identical outputs.
+int oadg_oamix_fg_union_rects(const float* My, const float* Mx, const int* rects_dev, int n, int H, int W, float* union_f,
+                              uint8_t* union_u8, void* stream) {
+    if (!union_f || !union_u8 || n < 0 || (n > 0 && (!My || !Mx || !rects_dev))) return OADG_EARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(union_f, 0, (size_t)H * W * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (n > 0) {
+        hipLaunchKernelGGL(fg_union_scatter_kernel, dim3(n, n >= 1024 ? 2 : 16), dim3(256), 0, st, My, Mx, rects_dev, H, W,
+                           (unsigned*)union_f);
+        OADG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(fg_union_u8_kernel, dim3(grid1d((long)H * W, 256)), dim3(256), 0, st, (const float*)union_f,
+                       (long)H * W, union_u8);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
 size_t oadg_oamix_saliency_workspace_bytes(int n) {
     return n > 0 ? (size_t)n * (SN * SN * sizeof(float) + sizeof(unsigned long long)) : 0;
 }
@@ -1117,11 +1222,53 @@ int oadg_oamix_final(const uint8_t* img, const float* acc, int H, int W, const o
     const int g = grid1d((long)Hp * Wp, 256);
     hipStream_t st = (hipStream_t)stream;
     if (out_dtype == 1)
-        hipLaunchKernelGGL((final_mix_kernel<unsigned short>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
-                           n_targets, My, Mx, m_beta, nrm, out_u8, (unsigned short*)out_norm, Hp, Wp);
+        hipLaunchKernelGGL((final_mix_kernel<unsigned short, false>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (unsigned short*)out_norm, Hp, Wp, nullptr, nullptr, 0, 0);
     else
-        hipLaunchKernelGGL((final_mix_kernel<float>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
-                           n_targets, My, Mx, m_beta, nrm, out_u8, (float*)out_norm, Hp, Wp);
+        hipLaunchKernelGGL((final_mix_kernel<float, false>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (float*)out_norm, Hp, Wp, nullptr, nullptr, 0, 0);
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
+}
+
+// oadg_oamix_final for MANY targets: the targets are first binned into 32 x 32 pixel tiles (in target order) and a pixel
+// only visits its tile's list.  fg_rects_dev: the support rects of the fg masks (int32 [n_fg][4]: x0, y0, w, h; as for
+// oadg_oamix_fg_union_rects); workspace: oadg_oamix_final_tiles_workspace_bytes(H, W, n_targets) bytes.  Byte-identical to
+// oadg_oamix_final (a target with a zero mask at a pixel adds +0 to every running sum of that pixel).
+static int mix_cap(int n_targets) { return n_targets < 1024 ? (n_targets > 0 ? n_targets : 1) : 1024; }
+
+size_t oadg_oamix_final_tiles_workspace_bytes(int H, int W, int n_targets) {
+    if (H < 1 || W < 1 || n_targets < 0) return 0;
+    const size_t tiles = (size_t)((W + MIX_TS - 1) / MIX_TS) * ((H + MIX_TS - 1) / MIX_TS);
+    return tiles * sizeof(int) + tiles * (size_t)mix_cap(n_targets) * sizeof(unsigned short) + 16;
+}
+
+int oadg_oamix_final_tiles(const uint8_t* img, const float* acc, int H, int W, const oadg_mix_target* targets,
+                           int n_targets, const int* fg_rects_dev, const float* My, const float* Mx, double m_beta,
+                           const float* mean_host, const float* stdinv_host, int to_rgb, uint8_t* out_u8, void* out_norm,
+                           int out_dtype, int Hp, int Wp, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!img || !acc || n_targets < 1 || n_targets > 65535 || !targets || !fg_rects_dev || Hp < H || Wp < W)
+        return OADG_EARG;
+    if (!out_u8 && !out_norm) return OADG_EARG;
+    if (!workspace || workspace_bytes < oadg_oamix_final_tiles_workspace_bytes(H, W, n_targets)) return OADG_ESIZE;
+    NormArgs nrm = {};
+    if (out_norm && fill_norm(nrm, mean_host, stdinv_host, to_rgb)) return OADG_EARG;
+    const int tiles_x = (W + MIX_TS - 1) / MIX_TS, tiles = tiles_x * ((H + MIX_TS - 1) / MIX_TS), cap = mix_cap(n_targets);
+    int* counts = (int*)workspace;
+    unsigned short* lists = (unsigned short*)(counts + tiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mix_bins_kernel, dim3(tiles), dim3(256), 0, st, targets, n_targets, fg_rects_dev, tiles_x, cap, counts,
+                       lists);
+    OADG_LAUNCH_CHECK();
+    const int g = grid1d((long)Hp * Wp, 256);
+    if (out_dtype == 1)
+        hipLaunchKernelGGL((final_mix_kernel<unsigned short, true>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (unsigned short*)out_norm, Hp, Wp, (const int*)counts,
+                           (const unsigned short*)lists, tiles_x, cap);
+    else
+        hipLaunchKernelGGL((final_mix_kernel<float, true>), dim3(g), dim3(256), 0, st, img, acc, H, W, targets,
+                           n_targets, My, Mx, m_beta, nrm, out_u8, (float*)out_norm, Hp, Wp, (const int*)counts,
+                           (const unsigned short*)lists, tiles_x, cap);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

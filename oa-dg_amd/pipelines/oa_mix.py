@@ -59,6 +59,19 @@ BBOX_CHAIN_DTYPE = np.dtype([('img', '<u8'), ('steps_dev', '<u8'), ('tile_prefix
 LOCKSTEP = os.environ.get('OADG_OAMIX_LOCKSTEP', '1') == '1'    # the images of a batch advance their per-box chains together
 BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
 PLAN_IN_C = os.environ.get('OADG_OAMIX_PLAN_C', '1') == '1'     # the op's host arithmetic in one C call (else numpy)
+PLAN_THREADS = int(os.environ.get('OADG_OAMIX_PLAN_THREADS', '4'))    # planner threads of the lockstep pass (0: none)
+MIX_TILES_MIN_TARGETS = 64      # from this many mixing targets on object_aware_mixing visits tile-binned target lists
+UNION_RECTS_MIN_BOXES = 64      # from this many boxes on the fg-mask union is built from the masks' support rects
+ASYNC_PLAN_MIN_BOXES = 512      # below this a plan call takes less than the hand-over to a thread
+_PLAN_POOL = None
+
+
+def _plan_pool():
+    global _PLAN_POOL
+    if _PLAN_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _PLAN_POOL = ThreadPoolExecutor(max(PLAN_THREADS, 1), thread_name_prefix='oadg-oamix-plan')
+    return _PLAN_POOL
 
 
 def dependency_levels(rects, minvs, H, W):
@@ -236,8 +249,14 @@ class _ImageState:
             self._sigma = _upload(sigma, dev)
             check(L.oadg_oamix_box_profiles(ptr(self._qbox), ptr(self._sigma), n, H, W, spatial_ratio,
                                             ptr(self.My), ptr(self.Mx), stream_ptr()), 'oadg_oamix_box_profiles')
-        check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
-                                    stream_ptr()), 'oadg_oamix_fg_union')
+        self._rects = None
+        if n >= UNION_RECTS_MIN_BOXES:
+            # many boxes: the union from the masks' support rects (work ~ rect areas, not n x H x W); byte-identical
+            check(L.oadg_oamix_fg_union_rects(ptr(self.My), ptr(self.Mx), ptr(self.rects_dev()), n, H, W, ptr(self.union_f),
+                                              ptr(self.union_u8), stream_ptr()), 'oadg_oamix_fg_union_rects')
+        else:
+            check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
+                                        stream_ptr()), 'oadg_oamix_fg_union')
         # --- saliency scores (oa_mix.py:98-111): launched now, read when object-aware mixing needs them -----
         self._scores = None
         if n:
@@ -253,6 +272,15 @@ class _ImageState:
             self._scores_host.copy_(self._scores_dev, non_blocking=True)
             self._scores_evt = torch.cuda.Event()
             self._scores_evt.record()
+
+    def rects_dev(self):
+        """device int32 [n, 4]: (x0, y0, w, h) of every fg mask's support, zeros for an empty mask (uploaded once)"""
+        if self._rects is None:
+            n = self.n
+            rows = self._support_rows.reshape(n, 4)
+            ok = ~self._support_empty.reshape(n) & (rows[:, 2] > 0) & (rows[:, 3] > 0)
+            self._rects = _upload(np.where(ok[:, None], rows, 0).astype(np.int32).reshape(max(n, 0), 4), self.img.device)
+        return self._rects
 
     def _supports(self, qbox, sxy, blur, ratio):
         """per box (x0, y0, w, h) of the pixels where its (blurred, x4 resized) mask can be non-zero, None if empty"""
@@ -319,6 +347,7 @@ class OAMix:
         self.kwargs = kwargs            # unknown kwargs are swallowed like the reference (oa_mix.py:72)
         self._bufs = {}
         self._rec = None                # a list while oamix_many() records an image's device commands
+        self._pending_plans = 0         # plans handed to planner threads whose staging slots are still taken
         self.trace = None               # set to [] to record the op sequence (tests)
         self.stats = None               # set to {} to count compose steps / bbox-step pixels (tools/bench_oamix.py)
 
@@ -366,8 +395,15 @@ class OAMix:
         from .. import hip_ops
         while True:
             for i, rec in enumerate(recs):
-                while at[i] < len(rec) and rec[at[i]][0] == 'call':
-                    rec[at[i]][1]()
+                while at[i] < len(rec) and rec[at[i]][0] != 'chain':
+                    kind, payload = rec[at[i]]
+                    if kind == 'call':
+                        payload()
+                    else:                       # 'plan': a plan that ran on a planner thread - its chain, or nothing
+                        c = payload()
+                        if c is not None:
+                            rec[at[i]] = ('chain', c)
+                            continue
                     at[i] += 1
             ready = [i for i, rec in enumerate(recs) if at[i] < len(rec)]
             if not ready:
@@ -533,7 +569,10 @@ class OAMix:
     def _bbox_chain_c(self, st, T, kind, step):
         """_box_matrices + _bbox_chain with the host arithmetic in ONE C call (csrc/oamix_host.hip oadg_oamix_bbox_plan:
         draws -> matrices -> inverses -> dependency levels -> level-major step table, written into the pinned staging
-        slot; ctypes releases the interpreter lock for its duration), one copy to the device, the level launches."""
+        slot; ctypes releases the interpreter lock for its duration), one copy to the device, the level launches.
+        Inside oamix_many() the call of an image with many boxes runs on a PLANNER THREAD (the draws are taken here, in
+        stream order; nothing of the plan is needed before the batch's commands are executed): the ~0.8 ms per op of a
+        4096-box image overlap the recording of the following ops and images."""
         L = _lib.lib()
         b = self._buffers(st)
         H, W = st.H, st.W
@@ -543,48 +582,80 @@ class OAMix:
         if n == 0:
             return
         nbytes = L.oadg_oamix_bbox_plan_bytes(n)
-        ring = getattr(_TLS, 'ring', None)
+        deferred = self._rec is not None and PLAN_THREADS > 0 and n >= ASYNC_PLAN_MIN_BOXES
+        name = 'plan_ring' if deferred else 'ring'          # (deferred plans hold their slot until execute(): own ring)
+        ring = getattr(_TLS, name, None)
         if ring is None:
-            ring = _TLS.ring = _PinnedRing()
+            ring = _PinnedRing()
+            setattr(_TLS, name, ring)
+        if deferred and self._pending_plans >= ring.SLOTS - 1:
+            deferred = False
+            ring = getattr(_TLS, 'ring', None) or _PinnedRing()
+            _TLS.ring = ring
         k, buf = ring.slot(nbytes)
-        lf = getattr(_TLS, 'level_first', None)
-        if lf is None or lf.size < n + 2:
-            lf = _TLS.level_first = np.empty((max(n + 2, 64),), np.int32)
+        if deferred:
+            lf = np.empty((n + 2,), np.int32)
+        else:
+            lf = getattr(_TLS, 'level_first', None)
+            if lf is None or lf.size < n + 2:
+                lf = _TLS.level_first = np.empty((max(n + 2, 64),), np.int32)
         out = (ctypes.c_int * 3)()
         area = ctypes.c_longlong(0)
         r = np.ascontiguousarray(r, np.float64)
-        check(L.oadg_oamix_bbox_plan(self._KIND_ID[kind], float(self.severity), ib.ctypes.data, sup.ctypes.data, n,
-                                     r.ctypes.data, int(r.size), H, W, buf.data_ptr(), nbytes, lf.ctypes.data, out,
-                                     ctypes.byref(area)), 'oadg_oamix_bbox_plan')
-        n_live, n_levels = int(out[0]), int(out[1])
-        if self.stats is not None:
-            self.stats['bbox_levels'] = self.stats.get('bbox_levels', 0) + n_levels
-            self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n_live
-        if n_live == 0:
-            return
-        used = n_live * BBOX_STEP_DTYPE.itemsize + (n_live + 1) * 4
-        dev = st.img.device
-        dst = torch.empty((used,), dtype=torch.uint8, device=dev)
-        dst.copy_(buf[:used], non_blocking=True)
-        ev = ring.events[k] = ring.events[k] or torch.cuda.Event()
-        ev.record()
-        step.setdefault('keepalive', []).append(dst)              # descriptor tensor lives until the step's launches ran
-        tiles_off = n_live * BBOX_STEP_DTYPE.itemsize
-        from .. import hip_ops
-        work = float(9 * area.value)
-        if self._rec is not None:
+        args = (self._KIND_ID[kind], float(self.severity), ib.ctypes.data, sup.ctypes.data, n, r.ctypes.data, int(r.size), H, W,
+                buf.data_ptr(), nbytes, lf.ctypes.data, out, ctypes.byref(area))
+        keep = (ib, sup, r, buf, lf, out, area)             # the call's operands stay alive until it has run
+
+        def finish(rc):
+            """the plan has run: statistics, the table's copy to the device, the chain's launch operands (or None)"""
+            check(rc, 'oadg_oamix_bbox_plan')
+            n_live, n_levels = int(out[0]), int(out[1])
+            if self.stats is not None:
+                self.stats['bbox_levels'] = self.stats.get('bbox_levels', 0) + n_levels
+                self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n_live
+            if n_live == 0:
+                return None
+            used = n_live * BBOX_STEP_DTYPE.itemsize + (n_live + 1) * 4
+            dst = torch.empty((used,), dtype=torch.uint8, device=st.img.device)
+            dst.copy_(buf[:used], non_blocking=True)
+            ev = ring.events[k] = ring.events[k] or torch.cuda.Event()
+            ev.record()
+            step.setdefault('keepalive', []).append(dst)          # descriptor tensor lives until the step's launches ran
+            tiles_off = n_live * BBOX_STEP_DTYPE.itemsize
+            return dict(dst=dst, tiles_off=tiles_off, n_live=n_live, n_levels=n_levels, work=float(9 * area.value))
+
+        def chain_rec(f):
             # lockstep: this chain waits for the other images of the batch (oamix_many).  The plan's host tables live in
             # buffers the next plan reuses (thread-local level list, pinned staging slot): private copies travel along
-            self._rec.append(('chain', dict(
+            dst, tiles_off, n_live, n_levels = f['dst'], f['tiles_off'], f['n_live'], f['n_levels']
+            return dict(
                 img=T.data_ptr(), H=H, W=W, steps_dev=dst.data_ptr(), tile_prefix_dev=dst.data_ptr() + tiles_off,
                 level_first=lf[:n_levels + 1].copy(),
                 tile_prefix=buf[tiles_off:tiles_off + (n_live + 1) * 4].numpy().view(np.int32).copy(), n_levels=n_levels,
-                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=work, keep=(T, dst, st))))
+                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=f['work'], keep=(T, dst, st))
+
+        if deferred:
+            fut = _plan_pool().submit(L.oadg_oamix_bbox_plan, *args)
+            self._pending_plans += 1
+
+            def resolve(fut=fut, keep=keep):
+                self._pending_plans -= 1
+                f = finish(fut.result())
+                return None if f is None else chain_rec(f)
+            self._rec.append(('plan', resolve))
             return
+        f = finish(L.oadg_oamix_bbox_plan(*args))
+        if f is None:
+            return
+        if self._rec is not None:
+            self._rec.append(('chain', chain_rec(f)))
+            return
+        dst, tiles_off = f['dst'], f['tiles_off']
+        from .. import hip_ops
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, dst.data_ptr(),
-                             dst.data_ptr() + tiles_off, lf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
+                             dst.data_ptr() + tiles_off, lf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), f['n_levels'],
                              ctypes.cast(buf.data_ptr() + tiles_off, ctypes.POINTER(ctypes.c_int)), ptr(st.My),
-                             ptr(st.Mx), ptr(b['scratch']), stream_ptr(), work=work), 'oadg_oamix_bbox_chain')
+                             ptr(st.Mx), ptr(b['scratch']), stream_ptr(), work=f['work']), 'oadg_oamix_bbox_chain')
 
     def _box_matrices(self, st, kind):
         """The per-box loop above for ALL boxes at once: (rows, rects [m,4], inverted matrices [m,6]) of the boxes that
@@ -740,9 +811,17 @@ class OAMix:
         # object_aware_mixing (oa_mix.py:281-309)
         m = rng.beta(self.aug_prob_coeff, self.aug_prob_coeff)
         tg = np.zeros((len(targets),), MIX_TARGET_DTYPE)
-        for t, (idx, rect, score) in enumerate(targets):
-            hi = 0.5 if score <= self.score_thresh else 1.0
-            tg[t] = (idx, rect, np.float32(rng.uniform(0.0, hi)))
+        if len(targets) >= MIX_TILES_MIN_TARGETS:
+            # the targets' mixing weights in one draw: uniform(0, hi) = 0.0 + (hi - 0.0) * next_double() per target
+            # (numpy's legacy uniform), i.e. the next len(targets) doubles of the stream in target order
+            hi = np.where(np.array([sc for _, _, sc in targets], np.float64) <= self.score_thresh, 0.5, 1.0)
+            tg['fg_index'] = [idx for idx, _, _ in targets]
+            tg['rect'] = [rect for _, rect, _ in targets]
+            tg['m_oa'] = (0.0 + (hi - 0.0) * rng.random_sample(len(targets))).astype(np.float32)
+        else:
+            for t, (idx, rect, score) in enumerate(targets):
+                hi = 0.5 if score <= self.score_thresh else 1.0
+                tg[t] = (idx, rect, np.float32(rng.uniform(0.0, hi)))
         tg_dev = _upload(tg.view(np.uint8).reshape(-1), st.img.device) if len(targets) else None
         mean = stdinv = None
         to_rgb, dt, Hp, Wp = 0, 0, H, W
@@ -752,6 +831,18 @@ class OAMix:
             to_rgb = int(norm['to_rgb'])
             dt = 1 if out_norm.dtype == torch.bfloat16 else 0
             Hp, Wp = pad_shape
+        if MIX_TILES_MIN_TARGETS <= len(targets) <= 65535 and st.n:
+            # many targets: binned into 32 x 32 pixel tiles first (csrc mix_bins_kernel), byte-identical
+            nb = int(L.oadg_oamix_final_tiles_workspace_bytes(H, W, len(targets)))
+            ws = b.get('mix_ws')
+            if ws is None or ws.numel() < nb:
+                ws = b['mix_ws'] = torch.empty((nb,), dtype=torch.uint8, device=st.img.device)
+            fg_rects = st.rects_dev()
+            self._do(lambda: check(
+                L.oadg_oamix_final_tiles(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(fg_rects), ptr(st.My),
+                                         ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp, Wp,
+                                         ptr(ws), nb, stream_ptr()), 'oadg_oamix_final_tiles'))
+            return out_u8
         self._do(lambda: check(
             L.oadg_oamix_final(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(st.My),
                                ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp,

@@ -287,13 +287,16 @@ def test_oamix_helper_threads_equal_independent_sequential_workers(dev):
     assert not torch.equal(out2['img2'], out['img2'])
 
 
-@pytest.mark.parametrize('plan_in_c', [True, False])
-def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monkeypatch, plan_in_c):
+@pytest.mark.parametrize('plan_in_c,planner_threads', [(True, False), (True, True), (False, False)])
+def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monkeypatch, plan_in_c, planner_threads):
     """OAMix.oamix_many (round 4): the images of a batch record their device commands and advance their bboxes_only_*
     chains level by level TOGETHER (csrc oadg_oamix_bbox_chain_multi: one launch pair per level for all images).  Against
     the image-by-image pass with the same numpy stream: both views byte-identical, the same box lists, the stream left
     in the same state - for images with many, few and no boxes, dense small boxes (deep chains) and both host planners;
-    and the lockstep pass really shares launches (fewer level rounds than the sum of the chains' depths)."""
+    and the lockstep pass really shares launches (fewer level rounds than the sum of the chains' depths).  The lockstep
+    pass blends levels of small rects IN PLACE (one launch, csrc bbox_blend_inplace_imgs_kernel) where the sequential pass
+    goes through the scratch image and a copy launch, and with ``planner_threads`` every plan call runs on a planner
+    thread (as for images with >= 512 boxes)."""
     import os
     from oadg_amd import Config
     from oadg_amd.pipelines import DevicePipeline
@@ -301,6 +304,7 @@ def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monk
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
     monkeypatch.setattr(oa_mix, 'PLAN_IN_C', plan_in_c)
+    monkeypatch.setattr(oa_mix, 'ASYNC_PLAN_MIN_BOXES', 1 if planner_threads else 1 << 30)
     cases = [_case(40 + i, 256, 384, n, small=True) for i, n in enumerate((9, 3, 0, 14, 6))]
     rs = np.random.RandomState(9)
     cases.append((lowpass_image(rs, 256, 384, 4), synthetic_boxes(rs, 96, 256, 384, 8, 40)))     # config-5-like density
@@ -333,3 +337,57 @@ def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monk
     assert 0 < s['lockstep_rounds'] <= s['bbox_ops']
     assert s['lockstep_levels'] < s['bbox_levels'], s          # levels issued (deepest chain per round) < sum of depths
     assert 'lockstep_rounds' not in stats[False]
+
+
+def test_fg_union_from_support_rects_is_byte_identical(dev, monkeypatch):
+    """oadg_oamix_fg_union_rects (images with many boxes: the union of the blurred fg masks built from the masks' support
+    rects by integer atomicMax) against oadg_oamix_fg_union (every box at every pixel): the float union and its uint8
+    image byte for byte - dense small boxes, boxes at the image border, empty masks."""
+    from oadg_amd.pipelines import oa_mix
+    H, W = 256, 384
+    rs = np.random.RandomState(5)
+    gt = synthetic_boxes(rs, 70, H, W, 8, 36).astype(np.float32)
+    gt[:4] = [[0, 0, 30, 20], [W - 33, H - 21, W - 1, H - 1], [10, 10, 12, 11], [100, 50, 100, 90]]   # border, tiny, empty
+    img = torch.from_numpy(lowpass_image(rs, H, W, 4)).to(dev)
+    out = {}
+    for mode, thr in (('rects', 1), ('dense', 1 << 30)):
+        monkeypatch.setattr(oa_mix, 'UNION_RECTS_MIN_BOXES', thr)
+        st = oa_mix._ImageState(img, gt, 4, 0.3)
+        torch.cuda.synchronize()
+        out[mode] = (st.union_f.clone(), st.union_u8.clone())
+    assert torch.equal(out['rects'][0], out['dense'][0])
+    assert torch.equal(out['rects'][1], out['dense'][1])
+    assert out['dense'][0].max().item() > 0.5 and (out['dense'][0] == 0).any().item()
+
+
+def test_oamix_many_box_paths_are_byte_identical(dev, monkeypatch):
+    """The paths an image with MANY boxes takes (fg-mask union from the support rects, object-aware mixing over tile-binned
+    target lists with the targets' weights drawn in one call, plans on planner threads) against the few-box paths on the
+    same images with the same numpy stream: both views byte-identical, the stream left in the same state."""
+    import os
+    from oadg_amd import Config
+    from oadg_amd.pipelines import DevicePipeline
+    from oadg_amd.pipelines import oa_mix
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
+    rs = np.random.RandomState(3)
+    cases = [(lowpass_image(rs, 256, 384, 4), synthetic_boxes(rs, n, 256, 384, 8, 40)) for n in (150, 40, 260)]
+    imgs = torch.from_numpy(np.stack([c[0] for c in cases])).to(dev)
+    gts = [c[1] for c in cases]
+    labels = [np.zeros(len(g), np.int64) for g in gts]
+    out, after, n_targets = {}, {}, {}
+    real_final = oa_mix._lib.lib().oadg_oamix_final_tiles
+    for many in (True, False):
+        thr = 1 if many else 1 << 30
+        for name in ('MIX_TILES_MIN_TARGETS', 'UNION_RECTS_MIN_BOXES', 'ASYNC_PLAN_MIN_BOXES'):
+            monkeypatch.setattr(oa_mix, name, thr)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.float32)
+        np.random.seed(21)
+        out[many] = pipe(imgs, gts, labels)
+        torch.cuda.synchronize()
+        after[many] = np.random.random()
+    assert after[True] == after[False]
+    assert torch.equal(out[True]['img'], out[False]['img']) and torch.equal(out[True]['img2'], out[False]['img2'])
+    assert not torch.equal(out[True]['img2'], out[True]['img'])
+    for i in range(len(cases)):
+        assert np.array_equal(out[True]['oamix_boxes'][i].numpy(), out[False]['oamix_boxes'][i].numpy())

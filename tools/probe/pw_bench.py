@@ -27,6 +27,23 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e3
 
 
+COLD = '--cold' in sys.argv        # every launch after a 1 GiB fill: operands come from HBM, as inside the training step
+if COLD:
+    _flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    _warm = timeit
+
+    def timeit(fn, iters=10):       # noqa: F811
+        _warm(fn, 1)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i, (a, b) in enumerate(ev):
+            _flush.fill_(i)
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / iters * 1e3
+
+
 for N, C, H, W, K in SHAPES:
     x = torch.randn(N, C, H, W, device=dev).bfloat16().contiguous(**cl)
     w = (torch.randn(K, C, 1, 1, device=dev) / C ** 0.5).bfloat16().contiguous(**cl)
