@@ -1053,6 +1053,20 @@ def narrow_params(w_cat, b_cat):
     return w16, wt16, b16
 
 
+def _n16_launch(kind, M, C, extra_bytes, fn):
+    """one launch of csrc/narrow_head.hip, with an event pair when bench.py times the kernel families"""
+    if TIMERS is None or not _timed('n16'):
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    # algorithmic bytes: the C-channel map and the 16-channel map once each (+ the mask bits of the data gradient)
+    TIMERS.append((e0, e1, 2.0 * M * C * 16, M * (2.0 * C + 32.0) + extra_bytes, 'n16_%s_kernel<%d>' % (kind, C),
+                   (1, M, 1, C, 16, 1, 1, False, kind == 'dgrad')))
+    return r
+
+
 class _NarrowHead(torch.autograd.Function):
     """ys[l] [N, 16, H_l, W_l] = conv1x1(xs[l], w) + b for a head with <= 16 output channels shared by the pyramid levels
     (the RPN head's rpn_cls + rpn_reg, rpn_head.py:54-68, anchor_head.py:147-163) on 16-channel-wide maps:
@@ -1071,8 +1085,8 @@ class _NarrowHead(torch.autograd.Function):
             if tok is not None:
                 tok.armed = True
             y = torch.empty((N, 16, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
-            check(L.oadg_conv1x1_n16_fwd(ptr(x16), ptr(w16), ptr(b16), ptr(y), N * H * W, C, stream_ptr()),
-                  'oadg_conv1x1_n16_fwd')
+            check(_n16_launch('fwd', N * H * W, C, 0.0, lambda: L.oadg_conv1x1_n16_fwd(
+                ptr(x16), ptr(w16), ptr(b16), ptr(y), N * H * W, C, stream_ptr())), 'oadg_conv1x1_n16_fwd')
             xs16.append(x16)
             ys.append(y)
         ctx.save_for_backward(wt16, *xs16)
@@ -1104,8 +1118,9 @@ class _NarrowHead(torch.autograd.Function):
             mb = tok.bits if (tok is not None and tok.masked) else None
             finish = tok is not None and extra is None and (mb is not None or not tok.masked)
             part = torch.empty((L.oadg_conv1x1_n16_dgrad_rows(M), C), dtype=torch.float32, device=dev) if finish else None
-            check(L.oadg_conv1x1_n16_dgrad(ptr(gy), ptr(wt16), ptr(gx), ptr(mb) if finish else None, ptr(part), M, C,
-                                           stream_ptr()), 'oadg_conv1x1_n16_dgrad')
+            check(_n16_launch('dgrad', M, C, M * C / 8.0 if (finish and mb is not None) else 0.0,
+                              lambda: L.oadg_conv1x1_n16_dgrad(ptr(gy), ptr(wt16), ptr(gx), ptr(mb) if finish else None,
+                                                               ptr(part), M, C, stream_ptr())), 'oadg_conv1x1_n16_dgrad')
             if finish:
                 tok.colsum = _colsum(part, C)
                 tok.grad_ptr = gx.data_ptr()
@@ -1119,9 +1134,9 @@ class _NarrowHead(torch.autograd.Function):
             bpart = torch.empty((sum(rows), 16), dtype=torch.float32, device=dev)
             z, off = _zeros(dev), 0
             for x16, gy, M, r in zip(xs16, gys, Ms, rows):
-                check(L.oadg_conv1x1_n16_wgrad(ptr(x16), ptr(gy), ctypes.c_void_p(part.data_ptr() + off * 16 * C * 4),
-                                               ctypes.c_void_p(bpart.data_ptr() + off * 16 * 4), ptr(z), M, C, stream_ptr()),
-                      'oadg_conv1x1_n16_wgrad')
+                check(_n16_launch('wgrad', M, C, 0.0, lambda: L.oadg_conv1x1_n16_wgrad(
+                    ptr(x16), ptr(gy), ctypes.c_void_p(part.data_ptr() + off * 16 * C * 4),
+                    ctypes.c_void_p(bpart.data_ptr() + off * 16 * 4), ptr(z), M, C, stream_ptr())), 'oadg_conv1x1_n16_wgrad')
                 off += r
             dw = part.sum(0)[:KN].reshape(KN, C, 1, 1)
             if has_b:

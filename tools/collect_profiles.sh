@@ -24,7 +24,7 @@ for r in csv.DictReader(open(f)):
     if r['Counter_Name'] != c:
         continue
     k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
-    if not k.startswith('conv_'):              # our conv kernels keep their template arguments (one row each)
+    if not k.startswith(('conv_', 'n16_')):    # our conv kernels keep their template arguments (one row each)
         k = k.split('<')[0]
     k = k[-70:]
     agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
