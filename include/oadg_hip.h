@@ -676,6 +676,14 @@ int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, i
 int oadg_host_randperm_prefix(uint64_t* state624, int* left, uint64_t* next, int64_t n, int64_t k,
                               int64_t* out);
 
+/* ------------------------------------------------------------------------------------------------
+ * A frozen ResNet bottleneck block (identity shortcut, 256 -> 64 -> 64 -> 256, stride 1) as one launch:
+ *   mmdet/models/backbones/resnet.py:263-302 Bottleneck.forward with the BatchNorms folded (eval mode, frozen_stages).
+ * x, y [N][H][W][256] bf16 NHWC (y must not alias x); w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16 with the BN
+ * scales folded in; b1, b2 [64], b3 [256] fp32 = the folded BN shifts.  H, W multiples of 16.  No backward pass. */
+int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                               const void* w3, const float* b3, void* y, int N, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,9 @@ class Bottleneck(nn.Module):
         # consumer.  t_in rides on x when the previous block produced it.  In a stage's first block x has several
         # consumers: conv1 finishes its gradient, the downsample convolution (run AFTER conv2 here, so that autograd
         # runs its backward BEFORE conv1's) and the FPN lateral deposit theirs on the token (hip_conv.GradToken).
+        out = hip_conv.frozen_bottleneck(x, self)           # a frozen identity block of stage 1: one launch
+        if out is not None:
+            return out
         t_in = getattr(x, '_oadg_token', None)
         if hip_conv.tokens_ok(x, self.conv1, self.conv2, self.conv3) and not (self.bn1.training or self.bn2.training
                                                                               or self.bn3.training):

@@ -1187,6 +1187,37 @@ def conv_bn(x, conv, bn, relu=False, residual=None, in_token=None, out_token=Non
                              out_token, res_token, dep_token)
 
 
+FUSED_FROZEN_BLOCK = os.environ.get('OADG_FUSED_FROZEN_BLOCK', '1') == '1'
+
+
+def frozen_bottleneck(x, block):
+    """A frozen identity-shortcut bottleneck block (256 -> 64 -> 64 -> 256, stride 1, eval-mode BN) as ONE launch
+    (csrc/bottleneck_frozen.hip): x is read once and y written once, where the three convolution launches move twice the
+    bytes (resnet.py:263-302 under _freeze_stages).  Returns None when the block / input is not of that kind - the caller
+    runs its convolutions one by one.  No autograd graph: nothing upstream of a frozen block needs a gradient."""
+    if not (ENABLED and FUSED_FROZEN_BLOCK and x.is_cuda and x.dim() == 4 and not x.requires_grad and
+            block.downsample is None and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
+        return None
+    c1, c2, c3 = block.conv1, block.conv2, block.conv3
+    if tuple(c1.weight.shape) != (64, 256, 1, 1) or tuple(c2.weight.shape) != (64, 64, 3, 3) or \
+            tuple(c3.weight.shape) != (256, 64, 1, 1) or x.shape[1] != 256 or x.shape[2] % 16 or x.shape[3] % 16:
+        return None
+    for c in (c1, c2, c3):
+        st, pd, dl = _norm3(c.stride, c.padding, c.dilation)
+        if c.bias is not None or st != (1, 1) or dl != (1, 1) or pd != ((1, 1) if c is c2 else (0, 0)):
+            return None
+    bns = (block.bn1, block.bn2, block.bn3)
+    if any(bn.training for bn in bns) or any(p.requires_grad for m in (c1, c2, c3) + bns for p in m.parameters()):
+        return None
+    (w1, b1, _), (w2, b2, _), (w3, b3, _) = (prepared(c.weight, bn, None, 0, c) for c, bn in zip((c1, c2, c3), bns))
+    x16 = _nhwc_bf16(x)
+    N, C, H, W = x16.shape
+    y = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
+    check(_lib.lib().oadg_bottleneck_frozen_256(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(y), N, H, W,
+                                                stream_ptr()), 'oadg_bottleneck_frozen_256')
+    return y
+
+
 ENABLED = False
 
 

@@ -1112,3 +1112,42 @@ def test_rpn_head_narrow_matches_padded_tile(dev, monkeypatch):
         close(a, b, f'x{l}.grad', 1e-2)
     for n in res[False][2]:
         close(res[True][2][n], res[False][2][n], n, 1e-2)
+
+
+@pytest.mark.parametrize('shape', [(2, 48, 80), (1, 16, 16), (3, 32, 16)])
+def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkeypatch, shape):
+    """csrc/bottleneck_frozen.hip (a frozen identity block of ResNet stage 1 as ONE launch: conv1 on the tile's halo,
+    conv2 and conv3 out of LDS, x read once) against the block's three convolution launches and against fp32 arithmetic on
+    the same folded operands: tile borders, image borders (zero padding of conv2's INPUT, not of x), several images."""
+    from oadg_amd import hip_conv
+    from oadg_amd.backbones import Bottleneck
+    torch.manual_seed(3)
+    N, H, W = shape
+    blk = Bottleneck(256, 64).to(dev).eval()
+    for bn in (blk.bn1, blk.bn2, blk.bn3):
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0, 0.2)
+        bn.running_mean.normal_(0, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(N, 256, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    out = {}
+    hip_conv.enable(True)
+    try:
+        for fused in (True, False):
+            monkeypatch.setattr(hip_conv, 'FUSED_FROZEN_BLOCK', fused)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out[fused] = blk(x).float()
+    finally:
+        hip_conv.enable(False)
+    assert hip_conv.frozen_bottleneck(x, blk) is None            # (disabled again: the caller's three launches)
+    with torch.no_grad():
+        ref = blk.float()(x.float())                             # fp32 arithmetic, unfolded BN
+    scale = ref.abs().max().item()
+    for fused in (True, False):
+        assert (out[fused] - ref).abs().max().item() <= 3e-2 * scale, fused
+        assert (out[fused] - ref).abs().mean().item() <= 4e-3 * ref.abs().mean().item() + 1e-4, fused
+    d = (out[True] - out[False]).abs()
+    assert d.max().item() <= 2e-2 * scale and (d > 0).float().mean().item() < 0.2, (d.max().item(), (d > 0).float().mean().item())
