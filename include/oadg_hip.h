@@ -683,6 +683,11 @@ int oadg_host_randperm_prefix(uint64_t* state624, int* left, uint64_t* next, int
  * scales folded in; b1, b2 [64], b3 [256] fp32 = the folded BN shifts.  H, W multiples of 16.  No backward pass. */
 int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                                const void* w3, const float* b3, void* y, int N, int H, int W, void* stream);
+/* the stage's FIRST block (64 -> 64 -> 64 -> 256 with the 1x1 downsample convolution wd / bd on the shortcut):
+ * x [N][H][W][64] (the max-pool output), y [N][H][W][256]; w1 [64][64], w3, wd [256][64]. */
+int oadg_bottleneck_frozen_first_64(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                    const void* w3, const float* b3, const void* wd, const float* bd, void* y, int N, int H,
+                                    int W, void* stream);
 
 #ifdef __cplusplus
 }

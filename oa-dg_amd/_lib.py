@@ -116,6 +116,7 @@ SIGNATURES = {
     'oadg_conv1x1_n16_dgrad_rows': (cl, [cl]),
     'oadg_conv1x1_n16_dgrad': (ci, [vp, vp, vp, vp, vp, cl, ci, vp]),
     'oadg_bottleneck_frozen_256': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
+    'oadg_bottleneck_frozen_first_64': (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     'oadg_conv1x1_n16_wgrad_splits': (cl, [cl]),
     'oadg_conv1x1_n16_wgrad_rows': (cl, [cl]),
     'oadg_conv1x1_n16_wgrad': (ci, [vp, vp, vp, vp, vp, cl, ci, vp]),

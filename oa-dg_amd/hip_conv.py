@@ -1191,30 +1191,46 @@ FUSED_FROZEN_BLOCK = os.environ.get('OADG_FUSED_FROZEN_BLOCK', '1') == '1'
 
 
 def frozen_bottleneck(x, block):
-    """A frozen identity-shortcut bottleneck block (256 -> 64 -> 64 -> 256, stride 1, eval-mode BN) as ONE launch
-    (csrc/bottleneck_frozen.hip): x is read once and y written once, where the three convolution launches move twice the
-    bytes (resnet.py:263-302 under _freeze_stages).  Returns None when the block / input is not of that kind - the caller
-    runs its convolutions one by one.  No autograd graph: nothing upstream of a frozen block needs a gradient."""
+    """A frozen bottleneck block of ResNet stage 1 as ONE launch (csrc/bottleneck_frozen.hip): the identity blocks
+    (256 -> 64 -> 64 -> 256) and the stage's first block (64 -> 64 -> 64 -> 256 with the 1x1 downsample convolution on the
+    shortcut), stride 1, eval-mode BN folded.  x is read once and y written once, where the three / four convolution
+    launches move 2 - 4x the bytes (resnet.py:263-302 under _freeze_stages).  Returns None when the block / input is not
+    of that kind - the caller runs its convolutions one by one.  No autograd graph: nothing upstream of a frozen block
+    needs a gradient."""
     if not (ENABLED and FUSED_FROZEN_BLOCK and x.is_cuda and x.dim() == 4 and not x.requires_grad and
-            block.downsample is None and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
+            (x.dtype == torch.bfloat16 or torch.is_autocast_enabled())):
         return None
     c1, c2, c3 = block.conv1, block.conv2, block.conv3
-    if tuple(c1.weight.shape) != (64, 256, 1, 1) or tuple(c2.weight.shape) != (64, 64, 3, 3) or \
-            tuple(c3.weight.shape) != (256, 64, 1, 1) or x.shape[1] != 256 or x.shape[2] % 16 or x.shape[3] % 16:
+    ds = block.downsample
+    cin = 256 if ds is None else 64
+    if tuple(c1.weight.shape) != (64, cin, 1, 1) or tuple(c2.weight.shape) != (64, 64, 3, 3) or \
+            tuple(c3.weight.shape) != (256, 64, 1, 1) or x.shape[1] != cin or x.shape[2] % 16 or x.shape[3] % 16:
         return None
-    for c in (c1, c2, c3):
+    convs, bns = [c1, c2, c3], [block.bn1, block.bn2, block.bn3]
+    if ds is not None:
+        if len(ds) != 2 or tuple(ds[0].weight.shape) != (256, 64, 1, 1):
+            return None
+        convs.append(ds[0])
+        bns.append(ds[1])
+    for c in convs:
         st, pd, dl = _norm3(c.stride, c.padding, c.dilation)
         if c.bias is not None or st != (1, 1) or dl != (1, 1) or pd != ((1, 1) if c is c2 else (0, 0)):
             return None
-    bns = (block.bn1, block.bn2, block.bn3)
-    if any(bn.training for bn in bns) or any(p.requires_grad for m in (c1, c2, c3) + bns for p in m.parameters()):
+    if any(bn.training for bn in bns) or any(p.requires_grad for m in convs + bns for p in m.parameters()):
         return None
-    (w1, b1, _), (w2, b2, _), (w3, b3, _) = (prepared(c.weight, bn, None, 0, c) for c, bn in zip((c1, c2, c3), bns))
+    prep = [prepared(c.weight, bn, None, 0, c) for c, bn in zip(convs, bns)]
     x16 = _nhwc_bf16(x)
-    N, C, H, W = x16.shape
-    y = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
-    check(_lib.lib().oadg_bottleneck_frozen_256(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(y), N, H, W,
-                                                stream_ptr()), 'oadg_bottleneck_frozen_256')
+    N, _, H, W = x16.shape
+    y = torch.empty((N, 256, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
+    (w1, b1, _), (w2, b2, _), (w3, b3, _) = prep[:3]
+    L = _lib.lib()
+    if ds is None:
+        check(L.oadg_bottleneck_frozen_256(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(y), N, H, W,
+                                           stream_ptr()), 'oadg_bottleneck_frozen_256')
+    else:
+        wd, bd, _ = prep[3]
+        check(L.oadg_bottleneck_frozen_first_64(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(wd),
+                                                ptr(bd), ptr(y), N, H, W, stream_ptr()), 'oadg_bottleneck_frozen_first_64')
     return y
 
 

@@ -1114,8 +1114,9 @@ def test_rpn_head_narrow_matches_padded_tile(dev, monkeypatch):
         close(res[True][2][n], res[False][2][n], n, 1e-2)
 
 
+@pytest.mark.parametrize('first', [False, True])
 @pytest.mark.parametrize('shape', [(2, 48, 80), (1, 16, 16), (3, 32, 16)])
-def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkeypatch, shape):
+def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkeypatch, shape, first):
     """csrc/bottleneck_frozen.hip (a frozen identity block of ResNet stage 1 as ONE launch: conv1 on the tile's halo,
     conv2 and conv3 out of LDS, x read once) against the block's three convolution launches and against fp32 arithmetic on
     the same folded operands: tile borders, image borders (zero padding of conv2's INPUT, not of x), several images."""
@@ -1123,8 +1124,12 @@ def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkey
     from oadg_amd.backbones import Bottleneck
     torch.manual_seed(3)
     N, H, W = shape
-    blk = Bottleneck(256, 64).to(dev).eval()
-    for bn in (blk.bn1, blk.bn2, blk.bn3):
+    if first:       # the stage's first block: 64 input channels, 1x1 downsample convolution on the shortcut
+        from oadg_amd.backbones import make_res_layer
+        blk = make_res_layer(64, 64, 1, 1, 1, 'pytorch', dict(type='BN'))[0].to(dev).eval()
+    else:
+        blk = Bottleneck(256, 64).to(dev).eval()
+    for bn in (blk.bn1, blk.bn2, blk.bn3) + ((blk.downsample[1],) if first else ()):
         bn.weight.data.uniform_(0.5, 1.5)
         bn.bias.data.normal_(0, 0.2)
         bn.running_mean.normal_(0, 0.2)
@@ -1132,7 +1137,8 @@ def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkey
     for p in blk.parameters():
         p.requires_grad_(False)
     g = torch.Generator(device=dev).manual_seed(1)
-    x = torch.randn(N, 256, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, 64 if first else 256, H, W, device=dev, generator=g).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
     out = {}
     hip_conv.enable(True)
     try:

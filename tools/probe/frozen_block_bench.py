@@ -11,10 +11,15 @@ from oadg_amd.backbones import Bottleneck  # noqa: E402
 
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-blk = Bottleneck(256, 64).to(dev).eval()
+first = '--first' in sys.argv          # the stage's first block (64 input channels, downsample convolution)
+if first:
+    from oadg_amd.backbones import make_res_layer
+    blk = make_res_layer(64, 64, 1, 1, 1, 'pytorch', dict(type='BN'))[0].to(dev).eval()
+else:
+    blk = Bottleneck(256, 64).to(dev).eval()
 for p in blk.parameters():
     p.requires_grad_(False)
-x = torch.randn(8, 256, 256, 512, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+x = torch.randn(8, 64 if first else 256, 256, 512, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
 flush = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
 hip_conv.enable(True)
 for fused in (True, False, True, False):
@@ -30,5 +35,5 @@ for fused in (True, False, True, False):
             ev.append((a, b))
         torch.cuda.synchronize()
     us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)[len(ev) // 2]
-    gb = 2 * x.numel() * 2 / 1e9
-    print(f'fused={fused}: {us:7.1f} us per block  ({gb / us * 1e6 / 1e3:.2f} TB/s of the 1.07 GB a fused block has to move)', flush=True)
+    gb = (x.numel() + y.numel()) * 2 / 1e9
+    print(f'fused={fused}: {us:7.1f} us per block  ({gb / us * 1e6 / 1e3:.2f} TB/s of the {gb:.2f} GB a fused block has to move)', flush=True)
