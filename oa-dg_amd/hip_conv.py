@@ -1224,6 +1224,10 @@ def frozen_bottleneck(x, block):
     y = torch.empty((N, 256, H, W), dtype=torch.bfloat16, device=x16.device, memory_format=torch.channels_last)
     (w1, b1, _), (w2, b2, _), (w3, b3, _) = prep[:3]
     L = _lib.lib()
+    timed = TIMERS is not None and _timed('frozen_block')
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     if ds is None:
         check(L.oadg_bottleneck_frozen_256(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(y), N, H, W,
                                            stream_ptr()), 'oadg_bottleneck_frozen_256')
@@ -1231,6 +1235,14 @@ def frozen_bottleneck(x, block):
         wd, bd, _ = prep[3]
         check(L.oadg_bottleneck_frozen_first_64(ptr(x16), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(wd),
                                                 ptr(bd), ptr(y), N, H, W, stream_ptr()), 'oadg_bottleneck_frozen_first_64')
+    if timed:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        M = N * H * W
+        # algorithmic work of the block: its convolutions without the halo recomputation; bytes: x read once, y written once
+        TIMERS.append((e0, e1, 2.0 * M * (cin * 64 + 64 * 64 * 9 + 64 * 256 + (64 * 256 if ds is not None else 0)),
+                       2.0 * M * (cin + 256), 'bottleneck_frozen_kernel' if ds is None else 'bottleneck_frozen_first_kernel',
+                       (N, H, W, cin, 256, 3, 1, ds is None, False)))
     return y
 
 
