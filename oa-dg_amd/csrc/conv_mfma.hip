@@ -41,6 +41,10 @@ struct ConvArgs {
     // output scatter (stride-2 data gradients, one launch per parity class): pixel (n, ho, wo) of this launch is row
     // ((n * OH + ho * osh + oph) * OW + wo * osw + opw) of y / res / mask.  scatter == 0: row = m.
     int scatter, OH, OW, osh, osw, oph, opw;
+    // res_up (streaming pointwise kernel only): `res` is a HALF-resolution map [N, H/2, W/2, K] read through the nearest
+    // 2x upsampling (pixel (n, y, x) adds row ((n * H/2 + y/2) * W/2 + x/2)): the FPN top-down add (necks/fpn.py:166-175)
+    // in the lateral convolution's epilogue.  H = 2^lh, W = 2^lw.
+    int res_up, lh, lw;
 };
 
 __device__ __forceinline__ long out_row(const ConvArgs& a, long m) {
@@ -455,9 +459,15 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
 #pragma unroll
             for (int jj = 0; jj < NP; ++jj) {
                 const size_t off = (sub < n_sub ? (size_t)sub * sub_stride + jj * row8 : 0) + lane_off;   // past the end: any valid row
+                size_t roff = off;
+                if (RES && a.res_up) {          // the residual row of pixel (n, y, x) is row (n, y / 2, x / 2) of the half-size map
+                    const long prow = (sub < n_sub ? sub * SP + jj * PPP : 0) + ppx;
+                    const long x_ = prow & (a.W - 1), y_ = (prow >> a.lw) & (a.H - 1), n_ = prow >> (a.lw + a.lh);
+                    roff = (size_t)((((n_ << (a.lh - 1)) + (y_ >> 1)) << (a.lw - 1)) + (x_ >> 1)) * a.K + kcol + psl * 8;
+                }
                 // asm: the compiler must not see these loads, or it would wait for ALL vector memory (the LDS-DMA
                 // prefetches included) at their first use
-                if (RES) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[set][jj]) : "v"(a.res + off) : "memory");
+                if (RES) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rv[set][jj]) : "v"(a.res + roff) : "memory");
                 if (BIN) asm volatile("global_load_ubyte %0, %1, off" : "=v"(mb[set][jj]) : "v"(a.bits_in + (off >> 3)) : "memory");
             }
         };
@@ -904,6 +914,8 @@ int auto_variant(long M, int H, int W, int C, int K, int nchunks, int R = 0, int
     return pw_stream_ranges(M, C, K, R, S, stride, pad) > 0 ? 4 : 3;
 }
 
+static inline bool mask_bits_unused(const void* bits_in, const void* bits_out) { return bits_in != nullptr || bits_out != nullptr; }
+
 int conv_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, const void* zeros16,
                 int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int relu, int variant,
                 void* stream, const void* mask = nullptr, float* colsum_part = nullptr, const int* sc = nullptr,
@@ -920,10 +932,21 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     a.bits_in = (const unsigned char*)bits_in; a.bits_out = (unsigned char*)bits_out;
     if ((bits_in || bits_out) && K % 8 != 0) return OADG_EARG;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.dil = dil;
-    a.relu = relu;
+    a.relu = relu & 1;
     a.Ho = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
     a.Wo = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
     a.scatter = 0; a.OH = a.Ho; a.OW = a.Wo; a.osh = a.osw = 1; a.oph = a.opw = 0;
+    a.res_up = 0; a.lh = a.lw = 0;
+    if (relu & 2) {     // (relu bit 1: `residual` is a half-resolution map added through the nearest 2x upsampling)
+        auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+        a.lh = lg(H); a.lw = lg(W);
+        if (!residual || a.lh < 1 || a.lw < 1 || R != 1 || S != 1 || stride != 1 || pad != 0 || sc || mask || mask_bits_unused(bits_in, bits_out))
+            return OADG_EARG;
+        a.res_up = 1;
+        a.relu = relu & 1;
+        if (variant == 0) variant = 4;
+        if (variant != 4) return OADG_EARG;
+    }
     if (sc) {
         if (stride != 1 || sc[0] < 1 || sc[1] < 1 || sc[4] < 1 || sc[5] < 1 || sc[6] < 0 || sc[7] < 0) return OADG_EARG;
         if ((long)(sc[0] - 1) * sc[4] + sc[6] >= sc[2] || (long)(sc[1] - 1) * sc[5] + sc[7] >= sc[3]) return OADG_EARG;

@@ -355,8 +355,22 @@ def flush_wgrads():
     return len(jobs)
 
 
+def topdown_ok(x, K, top):
+    """may ``conv1x1(x) + nearest_upsample_2x(top)`` run as ONE launch (the FPN top-down add in the lateral convolution's
+    epilogue: csrc ConvArgs.res_up)?  The streaming pointwise kernel, power-of-two maps, ``top`` exactly half the size."""
+    if not (ENABLED and TOPDOWN_FUSED and x.is_cuda and top.is_cuda and x.dim() == 4 and top.dtype == torch.bfloat16):
+        return False
+    N, C, H, W = x.shape
+    if tuple(top.shape) != (N, K, H // 2, W // 2) or H & (H - 1) or W & (W - 1) or H < 2 or W < 2:
+        return False
+    return _lib.lib().oadg_conv2d_auto_variant(N, H, W, C, K, 1, 1, 1, 0, 1) == 4
+
+
+TOPDOWN_FUSED = os.environ.get('OADG_TOPDOWN_FUSED', '1') == '1'
+
+
 def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=None, want_colsum=False, mask_bits=None,
-                 bits_out=None):
+                 bits_out=None, res_up=False):
     """x [N,C,H,W] bf16 channels_last, w [K,C,R,S] bf16 channels_last -> y [N,K,Ho,Wo] bf16 channels_last.
     ``mask`` (same shape as y): y *= (mask > 0); ``want_colsum``: also return sum of the stored y over (N,H,W)
     (fp32 [K], deterministic) - the two together are the backward of a producer's bias + ReLU epilogue.
@@ -381,7 +395,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         rows = L.oadg_conv2d_pixel_tiles(N, H, W, C, K, R, S, stride, pad, dil, int(variant))
         part = torch.empty((rows, K), dtype=torch.float32, device=x.device)
     check(L.oadg_conv2d_nhwc_bf16_ex(ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(y), ptr(_zeros(x.device)), N,
-                                     H, W, C, K, R, S, stride, pad, dil, int(bool(relu)), int(variant), ptr(mask),
+                                     H, W, C, K, R, S, stride, pad, dil, int(bool(relu)) | (2 if res_up else 0), int(variant), ptr(mask),
                                      ptr(part), ptr(mask_bits), ptr(bits_out), stream_ptr()),
           'oadg_conv2d_nhwc_bf16')
     if timed:
@@ -389,7 +403,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
         v = variant
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S,
                        2.0 * (N * H * W * C + K * C * R * S +
-                              N * Ho * Wo * K * (1 + (residual is not None) + (mask is not None)) +
+                              N * Ho * Wo * K * (1 + (residual is not None) * (0.25 if res_up else 1) + (mask is not None)) +
                               N * Ho * Wo * K / 16.0 * ((mask_bits is not None) + (bits_out is not None))),
                        kernel_name(v, C, K, R, S, stride, pad, residual is not None, mask is not None, mask_bits is not None,
                                    bits_out is not None),
@@ -900,7 +914,8 @@ class _Conv2dMFMA(torch.autograd.Function):
     weight gradient by csrc conv_wgrad256_kernel where it beats MIOpen, else aten (MIOpen)."""
 
     @staticmethod
-    def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu, in_token, out_token, res_token, dep_token=None):
+    def forward(ctx, x, wf, bias, residual, wt, stride, pad, dil, relu, in_token, out_token, res_token, dep_token=None,
+                res_up=False):
         x16 = _nhwc_bf16(x)
         if in_token is not None and wt is not None and stride == 1:
             in_token.armed = True           # this convolution's data gradient will finish the tensor's gradient
@@ -911,7 +926,10 @@ class _Conv2dMFMA(torch.autograd.Function):
             # bf16 tensor for its ReLU-backward mask (1/16 of the bytes of an HBM-bound launch)
             bits = out_token.bits = torch.empty((y_numel(x16, wf, stride, pad, dil) // 8,), dtype=torch.uint8,
                                                 device=x16.device)
-        y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu, bits_out=bits)
+        # res_up: ``residual`` is the coarser FPN level, added through the nearest 2x upsampling (fpn.py:166-175) in this
+        # launch's epilogue; its gradient is the 2 x 2 sum of this convolution's output gradient (below)
+        y = conv_forward(x16, wf, bias, r16, stride, pad, dil, relu, bits_out=bits, res_up=bool(res_up))
+        ctx.res_up = tuple(r16.shape) if res_up else None
         ctx.save_for_backward(x16, wf, wt, y if relu else None)
         ctx.cfg = (stride, pad, dil, bias is not None, x.dtype, residual.dtype if residual is not None else None)
         ctx.tokens = (in_token, out_token, res_token, dep_token)
@@ -1033,7 +1051,14 @@ class _Conv2dMFMA(torch.autograd.Function):
                 res_token.extra = gy                  # folded into the block's first conv's data gradient
             else:
                 gres = gy.to(rdt)
-        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None, None, None, None, None
+            if ctx.res_up is not None:
+                ts = ctx.res_up                   # d top[n, :, y, x] = sum of the 2 x 2 output gradients above it
+                g16 = _nhwc_bf16(gy)
+                gres = torch.empty(ts, dtype=torch.bfloat16, device=gy.device, memory_format=torch.channels_last)
+                check(_lib.lib().oadg_fpn_topdown_bwd(ptr(g16), ptr(gres), g16.shape[0], g16.shape[2], g16.shape[3], ts[2],
+                                                      ts[3], g16.shape[1], stream_ptr()), 'oadg_fpn_topdown_bwd')
+                gres = gres.to(rdt)
+        return (gx.to(xdt) if gx is not None else None), gw, gb, gres, None, None, None, None, None, None, None, None, None, None
 
 
 NARROW_HEAD = os.environ.get('OADG_NARROW_HEAD', '1') == '1'
@@ -1165,7 +1190,7 @@ def _applies(x, weight, stride, padding, dilation):
 
 
 def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None, owner=None, in_token=None,
-           out_token=None, res_token=None, dep_token=None):
+           out_token=None, res_token=None, dep_token=None, res_up=False):
     """layers.conv2d implementation hook: returns None for shapes the kernel does not cover."""
     stride, padding, dilation = _norm3(stride, padding, dilation)
     if not _applies(x, weight, stride, padding, dilation):
@@ -1173,7 +1198,7 @@ def conv2d(x, weight, bias, stride, padding, dilation, relu=False, residual=None
     K, C, R, S = weight.shape
     wf, b, wt = prepared(weight, None, bias, _wt_useful(x, K, C, stride[0], padding[0], dilation[0], R), owner)
     return _Conv2dMFMA.apply(x, wf, b, residual, wt, stride[0], padding[0], dilation[0], bool(relu), in_token,
-                             out_token, res_token, dep_token)
+                             out_token, res_token, dep_token, bool(res_up))
 
 
 def conv_bn(x, conv, bn, relu=False, residual=None, in_token=None, out_token=None, res_token=None, dep_token=None):

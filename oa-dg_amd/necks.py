@@ -59,6 +59,15 @@ class FPN(nn.Module):
                                  owner=c)
         return conv(x)
 
+    def _merge(self, lat, top):
+        """lat + upsample(top) (fpn.py:166-175) for the levels whose lateral convolution did not take the add with it"""
+        if 'scale_factor' in self.upsample_cfg:
+            return lat + F.interpolate(top, **self.upsample_cfg)
+        if top.is_cuda and top.dtype == torch.bfloat16 and lat.dtype == torch.bfloat16 and \
+                self.upsample_cfg.get('mode') == 'nearest' and top.shape[1] % 8 == 0:
+            return hip_ops.fpn_topdown(lat, top)                          # fused, csrc/eltwise.hip
+        return lat + F.interpolate(top, size=lat.shape[2:], **self.upsample_cfg)
+
     @staticmethod
     def _fpn_conv(conv, x, token, in_token=None):
         # an output level is read by the RPN convolution and by RoIAlign: the RPN convolution's data gradient finishes
@@ -83,19 +92,28 @@ class FPN(nn.Module):
         x0 = inputs[self.start_level]
         t_lat0 = hip_conv.GradToken(masked=False) if (hip_conv.ENABLED and x0.is_cuda and torch.is_grad_enabled() and
                                                       (x0.dtype == torch.bfloat16 or torch.is_autocast_enabled())) else None
-        laterals = [self._lateral(conv, inputs[i + self.start_level], t_lat0 if i == 0 else None)
-                    for i, conv in enumerate(self.lateral_convs)]
-        n = len(laterals)
-        for i in range(n - 1, 0, -1):   # fpn.py:166-175
-            if 'scale_factor' in self.upsample_cfg:
-                laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], **self.upsample_cfg)
-            elif laterals[i].is_cuda and laterals[i].dtype == torch.bfloat16 and \
-                    laterals[i - 1].dtype == torch.bfloat16 and self.upsample_cfg.get('mode') == 'nearest' and \
-                    laterals[i].shape[1] % 8 == 0:
-                laterals[i - 1] = hip_ops.fpn_topdown(laterals[i - 1], laterals[i])      # fused, csrc/eltwise.hip
-            else:
-                laterals[i - 1] = laterals[i - 1] + F.interpolate(laterals[i], size=laterals[i - 1].shape[2:],
-                                                                  **self.upsample_cfg)
+        n = len(self.lateral_convs)
+        laterals = [None] * n
+        for i in range(n - 1, -1, -1):
+            # coarsest level first: level i adds the MERGED level i + 1 (fpn.py:166-175).  Where the lateral convolution runs
+            # on the streaming pointwise kernel with power-of-two maps (P2 / P3 of the 1024 x 2048 configs) the add happens
+            # in ITS epilogue - the un-merged lateral map is never written and re-read (hip_conv ConvArgs.res_up)
+            conv, x = self.lateral_convs[i], inputs[i + self.start_level]
+            top = laterals[i + 1] if i < n - 1 else None
+            out_token = t_lat0 if i == 0 else None
+            y = None
+            if top is not None and self.upsample_cfg.get('mode') == 'nearest' and 'scale_factor' not in self.upsample_cfg \
+                    and not (conv.with_norm or conv.with_activation) and \
+                    (x.dtype == torch.bfloat16 or torch.is_autocast_enabled()) and \
+                    hip_conv.topdown_ok(x, conv.conv.out_channels, top):
+                c = conv.conv
+                y = hip_conv.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, residual=top, owner=c,
+                                    dep_token=getattr(x, '_oadg_token', None), out_token=out_token, res_up=True)
+            if y is None:
+                y = self._lateral(conv, x, out_token)
+                if top is not None:
+                    y = self._merge(y, top)
+            laterals[i] = y
         outs = [self._fpn_conv(self.fpn_convs[i], laterals[i], token=i < n - 1 or self.num_outs == n,
                                in_token=t_lat0 if (i == 0 and n > 1) else None) for i in range(n)]
         for _ in range(self.num_outs - len(outs)):   # fpn.py:184-188

@@ -1157,3 +1157,51 @@ def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkey
         assert (out[fused] - ref).abs().mean().item() <= 4e-3 * ref.abs().mean().item() + 1e-4, fused
     d = (out[True] - out[False]).abs()
     assert d.max().item() <= 2e-2 * scale and (d > 0).float().mean().item() < 0.2, (d.max().item(), (d > 0).float().mean().item())
+
+
+def test_fpn_topdown_add_in_the_lateral_epilogue_is_bit_identical(dev, monkeypatch):
+    """necks.FPN with the top-down add `laterals[i] += upsample(laterals[i + 1])` (fpn.py:166-175) folded into the lateral
+    convolution's epilogue (streaming pointwise kernel, ConvArgs.res_up: the residual row of pixel (n, y, x) is row
+    (n, y / 2, x / 2) of the coarser map) against lateral launch + fpn_topdown launch: every output level and every
+    gradient (inputs, weights, biases) bit for bit - the same roundings in the same order."""
+    from oadg_amd import hip_conv
+    from oadg_amd.necks import FPN
+    torch.manual_seed(0)
+    fpn = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5).to(dev).to(memory_format=torch.channels_last)
+    g = torch.Generator(device=dev).manual_seed(2)
+    sizes = [(128, 256), (64, 128), (32, 64), (16, 32)]
+    x0 = [torch.randn(8, c, h, w, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+          for c, (h, w) in zip((256, 512, 1024, 2048), sizes)]
+    go = None
+    res = {}
+    taken = {True: 0, False: 0}
+    real = hip_conv.conv_forward
+
+    def counting(*a, **k):
+        taken[bool(k.get('res_up'))] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(hip_conv, 'conv_forward', counting)
+    hip_conv.enable(True)
+    try:
+        for fused in (True, False):
+            monkeypatch.setattr(hip_conv, 'TOPDOWN_FUSED', fused)
+            before = taken[True]
+            fpn.zero_grad(set_to_none=True)
+            xs = [x.clone().requires_grad_(True) for x in x0]
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                outs = fpn(xs)
+            if go is None:
+                go = [torch.randn(o.shape, device=dev, generator=g).to(o.dtype) for o in outs]
+            torch.autograd.backward(list(outs), go)
+            res[fused] = ([o.detach().clone() for o in outs], [x.grad.clone() for x in xs],
+                          {n_: p.grad.clone() for n_, p in fpn.named_parameters()})
+            assert taken[True] - before == (2 if fused else 0)        # the two finest laterals took the add with them
+    finally:
+        hip_conv.enable(False)
+    assert hip_conv.topdown_ok(x0[0], 256, res[True][0][1]) is False            # (kernels disabled again)
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    for n_ in res[False][2]:
+        assert torch.equal(res[True][2][n_], res[False][2][n_]), n_
