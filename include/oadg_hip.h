@@ -344,7 +344,11 @@ int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bia
  * mask_bits (may be NULL, instead of mask): the same ReLU mask as ONE BIT per element - [rows][K / 8] bytes, bit e of
  * byte j = channel 8 j + e - i.e. 1/16 of the bf16 mask's bytes on these HBM-bound launches;  relu_bits_out (may be
  * NULL): this launch additionally stores (y > 0) of what it writes in that format (the forward launch of the tensor
- * whose gradient a later launch masks).  Both need K % 8 == 0. */
+ * whose gradient a later launch masks).  Both need K % 8 == 0.
+ * relu: bit 0 = ReLU; bit 1 (round 4) = `residual` is a HALF-resolution map [N][H/2][W/2][K] added through the nearest 2x
+ * upsampling - pixel (n, y, x) adds row (n, y / 2, x / 2): `laterals[i - 1] += F.interpolate(laterals[i], ...)` of
+ * necks/fpn.py:166-175 in the lateral convolution's epilogue.  1x1 / stride 1 / pad 0 problems the streaming kernel takes
+ * (oadg_conv2d_auto_variant == 4) with H, W powers of two, no mask operands; OADG_EARG otherwise. */
 int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual, void* y,
                              const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                              int dil, int relu, int variant, const void* mask, float* colsum_part,
