@@ -684,7 +684,7 @@ int oadg_host_randperm_prefix(uint64_t* state624, int* left, uint64_t* next, int
  * A frozen ResNet bottleneck block (identity shortcut, 256 -> 64 -> 64 -> 256, stride 1) as one launch:
  *   mmdet/models/backbones/resnet.py:263-302 Bottleneck.forward with the BatchNorms folded (eval mode, frozen_stages).
  * x, y [N][H][W][256] bf16 NHWC (y must not alias x); w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16 with the BN
- * scales folded in; b1, b2 [64], b3 [256] fp32 = the folded BN shifts.  H, W multiples of 16.  No backward pass. */
+ * scales folded in; b1, b2 [64], b3 [256] fp32 = the folded BN shifts.  Any H, W (edge tiles masked).  No backward pass. */
 int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                                const void* w3, const float* b3, void* y, int N, int H, int W, void* stream);
 /* the stage's FIRST block (64 -> 64 -> 64 -> 256 with the 1x1 downsample convolution wd / bd on the shortcut):

@@ -206,8 +206,9 @@ __global__ __launch_bounds__(512) void bottleneck_frozen_kernel(FrozenBlockArgs 
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const unsigned short* px = xn + ((size_t)(y0 + py0 + q) * a.W + x0 + fr) * FB_C + 64 * sub + 8 * fq;
-                    res[q][0] = *reinterpret_cast<const uint4*>(px);
-                    res[q][1] = *reinterpret_cast<const uint4*>(px + 32);
+                    const bool in = y0 + py0 + q < a.H && x0 + fr < a.W;       // (edge tiles of maps that are no multiple of 16)
+                    res[q][0] = in ? *reinterpret_cast<const uint4*>(px) : make_uint4(0, 0, 0, 0);
+                    res[q][1] = in ? *reinterpret_cast<const uint4*>(px + 32) : make_uint4(0, 0, 0, 0);
                 }
                 f32x4q acc[2][4];
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void bottleneck_frozen_kernel(FrozenBlockArgs 
                         }
                         uint4 pk;
                         pk.x = pack2(o[0], o[1]); pk.y = pack2(o[2], o[3]); pk.z = pack2(o[4], o[5]); pk.w = pack2(o[6], o[7]);
-                        *reinterpret_cast<uint4*>(py_ + 32 * h) = pk;
+                        if (y0 + py0 + q < a.H && x0 + fr < a.W) *reinterpret_cast<uint4*>(py_ + 32 * h) = pk;
                     }
                 }
             }
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(512) void bottleneck_frozen_first_kernel(FrozenFirs
                 }
                 uint4 pk;
                 pk.x = pack2(o[0], o[1]); pk.y = pack2(o[2], o[3]); pk.z = pack2(o[4], o[5]); pk.w = pack2(o[6], o[7]);
-                *reinterpret_cast<uint4*>(py_ + 32 * h) = pk;
+                if (y0 + py0 < a.H && x0 + fr < a.W) *reinterpret_cast<uint4*>(py_ + 32 * h) = pk;
             }
         }
         __syncthreads();             // stage 3 has read t0 / t2, the next halo is complete in t1: swap the two buffers
@@ -478,11 +479,11 @@ __global__ __launch_bounds__(512) void bottleneck_frozen_first_kernel(FrozenFirs
 extern "C" {
 
 // x, y [N][H][W][256] bf16 (NHWC); w1 [64][256], w2 [64][3][3][64], w3 [256][64] bf16 with the BN scales folded in,
-// b1 / b2 [64], b3 [256] fp32 (the folded BN shifts).  H and W must be multiples of 16.  y must not alias x.
+// b1 / b2 [64], b3 [256] fp32 (the folded BN shifts).  Any H, W >= 1 (edge tiles are masked).  y must not alias x.
 int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                                const void* w3, const float* b3, void* y, int N, int H, int W, void* stream) {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !y || x == y || N < 1 || H < 16 || W < 16) return OADG_EARG;
-    if (H % FB_TS != 0 || W % FB_TS != 0 || (long)N * H * W * FB_C >= (1L << 40)) return OADG_EARG;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !y || x == y || N < 1 || H < 1 || W < 1) return OADG_EARG;
+    if ((long)N * H * W * FB_C >= (1L << 40)) return OADG_EARG;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)bottleneck_frozen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -493,7 +494,7 @@ int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, c
     FrozenBlockArgs a;
     a.x = (const unsigned short*)x; a.w1 = (const unsigned short*)w1; a.w2 = (const unsigned short*)w2;
     a.w3 = (const unsigned short*)w3; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.y = (unsigned short*)y;
-    a.N = N; a.H = H; a.W = W; a.tiles_x = W / FB_TS; a.tiles_y = H / FB_TS;
+    a.N = N; a.H = H; a.W = W; a.tiles_x = (W + FB_TS - 1) / FB_TS; a.tiles_y = (H + FB_TS - 1) / FB_TS;
     const long total = (long)N * a.tiles_x * a.tiles_y;
     if (total > 0x7fffffffL) return OADG_EARG;
     const int grid = total >= 256 ? 256 : (int)((total + 7) / 8) * 8;         // one workgroup per CU, a multiple of 8 XCDs
@@ -507,8 +508,8 @@ int oadg_bottleneck_frozen_256(const void* x, const void* w1, const float* b1, c
 int oadg_bottleneck_frozen_first_64(const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
                                     const void* w3, const float* b3, const void* wd, const float* bd, void* y, int N, int H,
                                     int W, void* stream) {
-    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !wd || !bd || !y || N < 1 || H < 16 || W < 16) return OADG_EARG;
-    if (H % FB_TS != 0 || W % FB_TS != 0 || (long)N * H * W * FB_C >= (1L << 40)) return OADG_EARG;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !wd || !bd || !y || N < 1 || H < 1 || W < 1) return OADG_EARG;
+    if ((long)N * H * W * FB_C >= (1L << 40)) return OADG_EARG;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)bottleneck_frozen_first_kernel,
@@ -519,7 +520,7 @@ int oadg_bottleneck_frozen_first_64(const void* x, const void* w1, const float* 
     FrozenFirstArgs a;
     a.x = (const unsigned short*)x; a.w1 = (const unsigned short*)w1; a.w2 = (const unsigned short*)w2;
     a.w3 = (const unsigned short*)w3; a.wd = (const unsigned short*)wd; a.b1 = b1; a.b2 = b2; a.b3 = b3; a.bd = bd;
-    a.y = (unsigned short*)y; a.N = N; a.H = H; a.W = W; a.tiles_x = W / FB_TS; a.tiles_y = H / FB_TS;
+    a.y = (unsigned short*)y; a.N = N; a.H = H; a.W = W; a.tiles_x = (W + FB_TS - 1) / FB_TS; a.tiles_y = (H + FB_TS - 1) / FB_TS;
     const long total = (long)N * a.tiles_x * a.tiles_y;
     if (total > 0x7fffffffL) return OADG_EARG;
     const int grid = total >= 256 ? 256 : (int)((total + 7) / 8) * 8;

@@ -1229,7 +1229,7 @@ def frozen_bottleneck(x, block):
     ds = block.downsample
     cin = 256 if ds is None else 64
     if tuple(c1.weight.shape) != (64, cin, 1, 1) or tuple(c2.weight.shape) != (64, 64, 3, 3) or \
-            tuple(c3.weight.shape) != (256, 64, 1, 1) or x.shape[1] != cin or x.shape[2] % 16 or x.shape[3] % 16:
+            tuple(c3.weight.shape) != (256, 64, 1, 1) or x.shape[1] != cin:
         return None
     convs, bns = [c1, c2, c3], [block.bn1, block.bn2, block.bn3]
     if ds is not None:

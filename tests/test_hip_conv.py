@@ -1115,7 +1115,7 @@ def test_rpn_head_narrow_matches_padded_tile(dev, monkeypatch):
 
 
 @pytest.mark.parametrize('first', [False, True])
-@pytest.mark.parametrize('shape', [(2, 48, 80), (1, 16, 16), (3, 32, 16)])
+@pytest.mark.parametrize('shape', [(2, 48, 80), (1, 16, 16), (3, 32, 16), (2, 23, 40), (1, 184, 320), (1, 5, 7)])
 def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkeypatch, shape, first):
     """csrc/bottleneck_frozen.hip (a frozen identity block of ResNet stage 1 as ONE launch: conv1 on the tile's halo,
     conv2 and conv3 out of LDS, x read once) against the block's three convolution launches and against fp32 arithmetic on
