@@ -348,7 +348,7 @@ int oadg_conv2d_nhwc_bf16_variant(const void* x, const void* w, const float* bia
  * relu: bit 0 = ReLU; bit 1 (round 4) = `residual` is a HALF-resolution map [N][H/2][W/2][K] added through the nearest 2x
  * upsampling - pixel (n, y, x) adds row (n, y / 2, x / 2): `laterals[i - 1] += F.interpolate(laterals[i], ...)` of
  * necks/fpn.py:166-175 in the lateral convolution's epilogue.  1x1 / stride 1 / pad 0 problems the streaming kernel takes
- * (oadg_conv2d_auto_variant == 4) with H, W powers of two, no mask operands; OADG_EARG otherwise. */
+ * (oadg_conv2d_auto_variant == 4) with even H, W, no mask operands; OADG_EARG otherwise. */
 int oadg_conv2d_nhwc_bf16_ex(const void* x, const void* w, const float* bias, const void* residual, void* y,
                              const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
                              int dil, int relu, int variant, const void* mask, float* colsum_part,

@@ -43,7 +43,7 @@ struct ConvArgs {
     int scatter, OH, OW, osh, osw, oph, opw;
     // res_up (streaming pointwise kernel only): `res` is a HALF-resolution map [N, H/2, W/2, K] read through the nearest
     // 2x upsampling (pixel (n, y, x) adds row ((n * H/2 + y/2) * W/2 + x/2)): the FPN top-down add (necks/fpn.py:166-175)
-    // in the lateral convolution's epilogue.  H = 2^lh, W = 2^lw.
+    // in the lateral convolution's epilogue.  res_up 1: H = 2^lh, W = 2^lw (shifts); 2: any even H, W (divisions).
     int res_up, lh, lw;
 };
 
@@ -462,8 +462,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_stream_kernel(ConvArgs a, int 
                 size_t roff = off;
                 if (RES && a.res_up) {          // the residual row of pixel (n, y, x) is row (n, y / 2, x / 2) of the half-size map
                     const long prow = (sub < n_sub ? sub * SP + jj * PPP : 0) + ppx;
-                    const long x_ = prow & (a.W - 1), y_ = (prow >> a.lw) & (a.H - 1), n_ = prow >> (a.lw + a.lh);
-                    roff = (size_t)((((n_ << (a.lh - 1)) + (y_ >> 1)) << (a.lw - 1)) + (x_ >> 1)) * a.K + kcol + psl * 8;
+                    if (a.res_up == 1) {        // power-of-two map: shifts and masks
+                        const long x_ = prow & (a.W - 1), y_ = (prow >> a.lw) & (a.H - 1), n_ = prow >> (a.lw + a.lh);
+                        roff = (size_t)((((n_ << (a.lh - 1)) + (y_ >> 1)) << (a.lw - 1)) + (x_ >> 1)) * a.K + kcol + psl * 8;
+                    } else {                    // any even H, W (M < 2^31: 32-bit divisions)
+                        const unsigned t_ = (unsigned)prow / (unsigned)a.W, x_ = (unsigned)prow - t_ * (unsigned)a.W;
+                        const unsigned n_ = t_ / (unsigned)a.H, y_ = t_ - n_ * (unsigned)a.H;
+                        roff = ((size_t)(n_ * (unsigned)(a.H >> 1) + (y_ >> 1)) * (unsigned)(a.W >> 1) + (x_ >> 1)) * a.K + kcol + psl * 8;
+                    }
                 }
                 // asm: the compiler must not see these loads, or it would wait for ALL vector memory (the LDS-DMA
                 // prefetches included) at their first use
@@ -940,9 +946,10 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (relu & 2) {     // (relu bit 1: `residual` is a half-resolution map added through the nearest 2x upsampling)
         auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
         a.lh = lg(H); a.lw = lg(W);
-        if (!residual || a.lh < 1 || a.lw < 1 || R != 1 || S != 1 || stride != 1 || pad != 0 || sc || mask || mask_bits_unused(bits_in, bits_out))
+        if (!residual || (H & 1) || (W & 1) || H < 2 || W < 2 || (long)N * H * W >= (1L << 31) || R != 1 || S != 1 || stride != 1 ||
+            pad != 0 || sc || mask || mask_bits_unused(bits_in, bits_out))
             return OADG_EARG;
-        a.res_up = 1;
+        a.res_up = (a.lh >= 1 && a.lw >= 1) ? 1 : 2;
         a.relu = relu & 1;
         if (variant == 0) variant = 4;
         if (variant != 4) return OADG_EARG;

@@ -357,11 +357,11 @@ def flush_wgrads():
 
 def topdown_ok(x, K, top):
     """may ``conv1x1(x) + nearest_upsample_2x(top)`` run as ONE launch (the FPN top-down add in the lateral convolution's
-    epilogue: csrc ConvArgs.res_up)?  The streaming pointwise kernel, power-of-two maps, ``top`` exactly half the size."""
+    epilogue: csrc ConvArgs.res_up)?  The streaming pointwise kernel, even map sizes, ``top`` exactly half the size."""
     if not (ENABLED and TOPDOWN_FUSED and x.is_cuda and top.is_cuda and x.dim() == 4 and top.dtype == torch.bfloat16):
         return False
     N, C, H, W = x.shape
-    if tuple(top.shape) != (N, K, H // 2, W // 2) or H & (H - 1) or W & (W - 1) or H < 2 or W < 2:
+    if tuple(top.shape) != (N, K, H // 2, W // 2) or H & 1 or W & 1 or H < 2 or W < 2 or N * H * W >= 1 << 31:
         return False
     return _lib.lib().oadg_conv2d_auto_variant(N, H, W, C, K, 1, 1, 1, 0, 1) == 4
 

@@ -1159,7 +1159,8 @@ def test_frozen_bottleneck_one_launch_matches_the_three_convolutions(dev, monkey
     assert d.max().item() <= 2e-2 * scale and (d > 0).float().mean().item() < 0.2, (d.max().item(), (d > 0).float().mean().item())
 
 
-def test_fpn_topdown_add_in_the_lateral_epilogue_is_bit_identical(dev, monkeypatch):
+@pytest.mark.parametrize('base', [(128, 256), (96, 320)])
+def test_fpn_topdown_add_in_the_lateral_epilogue_is_bit_identical(dev, monkeypatch, base):
     """necks.FPN with the top-down add `laterals[i] += upsample(laterals[i + 1])` (fpn.py:166-175) folded into the lateral
     convolution's epilogue (streaming pointwise kernel, ConvArgs.res_up: the residual row of pixel (n, y, x) is row
     (n, y / 2, x / 2) of the coarser map) against lateral launch + fpn_topdown launch: every output level and every
@@ -1169,7 +1170,7 @@ def test_fpn_topdown_add_in_the_lateral_epilogue_is_bit_identical(dev, monkeypat
     torch.manual_seed(0)
     fpn = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5).to(dev).to(memory_format=torch.channels_last)
     g = torch.Generator(device=dev).manual_seed(2)
-    sizes = [(128, 256), (64, 128), (32, 64), (16, 32)]
+    sizes = [(base[0] >> i, base[1] >> i) for i in range(4)]        # (power-of-two maps: shifts; others: divisions)
     x0 = [torch.randn(8, c, h, w, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
           for c, (h, w) in zip((256, 512, 1024, 2048), sizes)]
     go = None
