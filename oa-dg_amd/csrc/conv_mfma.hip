@@ -1729,7 +1729,9 @@ int wgrad_splits(long P, int K, int C, int RS) {
     if (wgrad_use256(P, K, C, RS)) return (int)wgrad256_splits(P, K, C, RS);
     const long tiles = (long)(K / 128) * (C / 128) * RS;
     const long nchunks = (P + WP - 1) / WP;
-    const long target = RS > 1 ? 1024 : 512;
+    // (round 4, operands from HBM: 512 workgroups beat 1024 on the 3x3 layers too - layer2 3x3 164 / 178 us, its stride-2
+    //  first block 178 / 210 us incl. the reduction - and leave half the partial tiles to the consumer)
+    const long target = 512;
     long s = (target + tiles - 1) / tiles;
     if (s > nchunks / 4) s = nchunks / 4;
     if (s >= 8) s = (s + 7) / 8 * 8;       // multiples of 8: one pixel range per XCD at a time
