@@ -918,6 +918,7 @@ int auto_variant(long M, int H, int W, int C, int K, int nchunks, int R = 0, int
     const bool ok256 = K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
     if (ok256 && nchunks >= 12) return 2;
     if (pw_stream_ranges(M, C, K, R, S, stride, pad) > 0) return 4;
+    if (ok256 && nchunks >= 8) return 2;      // (512-channel 1x1 / stride 2: no streaming kernel; 97 / 108 us cold)
     // small maps with a long reduction (layer4 3x3, the P5 / P6 3x3 convolutions, 2048 -> 256): at most two 128-tile
     // workgroups per CU, so the single-stage form has nobody to cover its loads - the two-stage pipeline is 10 - 20 % faster
     // there (cold operands, round 4: 94 / 113 us at 512 x 512 x 3 x 3 on 32 x 64, 45 / 55 at 256 x 256 x 3 x 3)
