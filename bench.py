@@ -4,7 +4,12 @@ One "step" = one pass of the whole hot path over one batch of synthetic Cityscap
 resident in HBM: OA-Mix (view 2 of every image) + Normalize/Pad on the device -> Faster R-CNN R50-FPN forward
 (both views) -> RPN/RoI losses incl. OA-Loss -> backward -> (DDP all-reduce) -> SGD step.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config r50_fpn|r101_dc5] [--workload train|oamix_stress]
+
+Default = BASELINE configs[1] (R50-FPN, bs 4, 1024x2048), the configuration the metric is quoted on.  ``--config r101_dc5``
+runs configs[3] (R101-DC5, bs 2, 736x1280) through the same machinery; ``--workload oamix_stress`` runs configs[4] (OA-Mix
+with 4096 boxes per image + the OA-Loss at its 8 x 512 x 2 batch, bs 8).  The line also carries ``clocks``: sclk / socket
+power / hotspot temperature sampled inside the timed region (amdsmi), so that runs on different boxes can be compared.
 
 N > 1 is one process per GPU over RCCL: either launched by ``python -m torch.distributed.run --nproc-per-node N ...
 bench.py --gpus N`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or, when ``bench.py --gpus N`` is
@@ -28,8 +33,21 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-CFG = os.path.join(ROOT, 'configs', 'oadg', 'faster_rcnn_r50_fpn_1x_cityscapes_oadg.py')
 METRIC = 'images/sec training, Faster R-CNN R50-FPN + OA-DG, 1024x2048'
+# --config: the training workloads BASELINE.json lists.  r50_fpn = configs[1] (the configuration the metric is quoted on: the
+# default, and what the driver runs); r101_dc5 = configs[3] at its per-GPU size (bs 2; the reference's DWD configs resize to
+# (1280, 720), padded to a multiple of 32: 736 x 1280).  --workload oamix_stress = configs[4], the OA-Mix + OA-Loss isolate.
+CONFIGS = {
+    'r50_fpn': dict(cfg='faster_rcnn_r50_fpn_1x_cityscapes_oadg.py', batch=4, height=1024, width=2048, boxes=20, classes=8,
+                    box_size=(24, 400), roi_strides=[4, 8, 16, 32], roi_channels=256, metric=METRIC,
+                    label='faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss'),
+    'r101_dc5': dict(cfg='faster_rcnn_r101_dc5_1x_dwd_oadg.py', batch=2, height=736, width=1280, boxes=12, classes=7,
+                     box_size=(24, 300), roi_strides=[16], roi_channels=2048,
+                     metric='images/sec training, Faster R-CNN R101-DC5 + OA-DG, 736x1280 (BASELINE configs[3])',
+                     label='faster_rcnn_r101_dc5_1x_dwd_oadg: OA-Mix (augmix.all) + Faster R-CNN R101-DC5 (dilated C5, no FPN, '
+                           '15 anchors on one stride-16 level, 2048-channel RoIAlign) + OA-Loss'),
+}
+CFG = os.path.join(ROOT, 'configs', 'oadg', CONFIGS['r50_fpn']['cfg'])
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA ~2.5 PFLOP/s
 
@@ -77,9 +95,14 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
-    ap.add_argument('--height', type=int, default=1024)
-    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--config', default='r50_fpn', choices=sorted(CONFIGS),
+                    help='r50_fpn: BASELINE configs[1] (default, the metric\'s configuration); r101_dc5: configs[3]')
+    ap.add_argument('--workload', default='train', choices=['train', 'oamix_stress'],
+                    help='train: the whole training step; oamix_stress: BASELINE configs[4], OA-Mix with 4096 boxes per image '
+                         '+ the OA-Loss at its 8 x 512 x 2 contrastive batch, bs 8')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default: the configuration\'s, r50_fpn 4 / r101_dc5 2)')
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-families', action='store_true', help='skip the per-family table (3 extra steps after the timed region)')
@@ -87,7 +110,80 @@ def parse():
                     help='1: the data pipeline host code runs in a worker thread (DataLoader-worker analogue)')
     ap.add_argument('--conv', default='mfma', choices=['mfma', 'miopen'],
                     help='mfma: hand-written implicit-GEMM kernels where they apply; miopen: torch.conv2d only')
-    return ap.parse_args()
+    a = ap.parse_args()
+    wl = CONFIGS[a.config]
+    for k in ('batch', 'height', 'width'):
+        if getattr(a, k) is None:
+            setattr(a, k, 8 if (a.workload == 'oamix_stress' and k == 'batch') else
+                    (CONFIGS['r50_fpn'][k] if a.workload == 'oamix_stress' else wl[k]))
+    return a
+
+
+class ClockSampler:
+    """sclk / socket power / hotspot temperature of the bench's GPU while the timed region runs, from the amdsmi python
+    binding (one ``amdsmi_get_gpu_metrics_info`` call every ``period`` seconds on a helper thread; the call is a sysfs
+    table read: no subprocess, ~0.1 ms).  The run-to-run spread of a step (28.6 - 31.3 ms between boxes) is larger than
+    most single changes; the clock the chip held and the power it drew say whether two runs are comparable
+    (MI355X_MICROARCH.md, 'DVFS give-back').  Absent binding / permission: ``summary()`` is {'available': False}."""
+
+    def __init__(self, index=0, period=0.05):
+        self.rows, self.period, self._stop, self._thread, self._h, self.err = [], period, False, None, None, None
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            self._h = hs[min(index, len(hs) - 1)]
+            self._read()
+        except Exception as e:        # noqa: BLE001 (any failure = no sampler, never a failed bench)
+            self._h, self.err = None, repr(e)[:120]
+
+    def _read(self):
+        m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
+
+        def num(v):
+            return float(v) if isinstance(v, (int, float)) and 0 <= v < 60000 else None
+        clks = [c for c in (num(v) for v in (m.get('current_gfxclks') or [])) if c]
+        if not clks:
+            c = num(m.get('current_gfxclk'))
+            clks = [c] if c else []
+        return (sum(clks) / len(clks) if clks else None,
+                num(m.get('current_socket_power')) or num(m.get('average_socket_power')),
+                num(m.get('temperature_hotspot')))
+
+    def start(self):
+        if self._h is None:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                try:
+                    self.rows.append(self._read())
+                except Exception as e:  # noqa: BLE001
+                    self.err = repr(e)[:120]
+                    return
+                time.sleep(self.period)
+        self.rows, self._stop = [], False
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        return self.summary()
+
+    def summary(self):
+        def stat(i, nd=0):
+            v = [r[i] for r in self.rows if r[i] is not None]
+            return None if not v else {'min': round(min(v), nd), 'mean': round(sum(v) / len(v), nd), 'max': round(max(v), nd)}
+        if self._h is None or not self.rows:
+            return {'available': False, 'note': self.err or 'no samples'}
+        return {'available': True, 'source': "amdsmi gpu_metrics (mean of the XCDs' current_gfxclks), sampled every "
+                                             f'{int(self.period * 1e3)} ms inside the timed region',
+                'samples': len(self.rows), 'sclk_mhz': stat(0), 'socket_power_w': stat(1), 'hotspot_c': stat(2)}
 
 
 def roi_algorithmic_bytes(rois, strides, C, elem, finest_scale=56, fwd=False):
@@ -135,7 +231,7 @@ FAMILIES = (('conv256 forward / data gradient', ('conv_igemm256_kernel',), 'mfma
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (xf32-free) MFMA peak
 
 
-def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
+def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None, roi_strides=(4, 8, 16, 32), roi_channels=256):
     """roofline.families: achieved rate of every hand-written kernel family the north star names, from HIP events
     recorded on the launch stream during ``steps`` extra steps after the timed region; PMC traffic (bytes per launch)
     from the committed rocprofv3 counter passes of this same command."""
@@ -170,10 +266,10 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
         if rs_ is None:
             continue
         allr = torch.cat([r_.float() for r_ in rs_])
-        b_bwd = roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem)
+        b_bwd = roi_algorithmic_bytes(allr, list(roi_strides), roi_channels, elem)
         rois_bytes['roi_align_bwd'].append(b_bwd)
         # forward: read the unique footprint in the map dtype, write 49 C elements
-        rois_bytes['roi_align_fwd'].append(roi_algorithmic_bytes(allr, [4, 8, 16, 32], 256, elem, fwd=True))
+        rois_bytes['roi_align_fwd'].append(roi_algorithmic_bytes(allr, list(roi_strides), roi_channels, elem, fwd=True))
     from oadg_amd import hip_ops as _ho
     tiles = bool(_ho.BWD_TILES and elem == 2)
     bwd_kernel = 'roi_align_bwd_tiles_kernel' if tiles else 'roi_align_bwd_kernel'
@@ -182,7 +278,7 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
         # once + the slabs read once, NOT the SURVEY 8d scatter model (49 C read + fp32 read-modify-write of the footprint)
         survey = list(rois_bytes['roi_align_bwd'])
         rois_bytes['roi_align_bwd'] = [roi_tile_bwd_bytes(sum(r_.shape[0] for r_ in rs_), geom['n_imgs'], geom['height'],
-                                                          geom['width'], [4, 8, 16, 32], 256, elem)
+                                                          geom['width'], list(roi_strides), roi_channels, elem)
                                        for rs_ in roi_sets if rs_ is not None]
     for key, title in (('roi_align_fwd', 'RoIAlign forward'),
                        ('roi_align_bwd', 'RoIAlign backward (%s)' % bwd_kernel)):
@@ -196,7 +292,7 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
                  'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
                  'algorithmic_bytes_per_launch': int(by / len(rows))}
             if key == 'roi_align_bwd' and tiles and geom is not None:
-                e['bytes_model'] = 'dense bf16 gradient maps of P2-P5 written once + 49 C bf16 per RoI read once'
+                e['bytes_model'] = 'dense bf16 gradient maps of the RoI levels written once + 49 C bf16 per RoI read once'
                 e['survey_8d_scatter_model_bytes_per_launch'] = int(sum(survey) / len(survey))
             e.update({k: v for k, v in pmc_traffic(kname).items() if v})
             out.append(e)
@@ -220,9 +316,10 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None):
     return out
 
 
-def cpu_baseline(cfg, seconds_budget=30.0):
+def cpu_baseline(cfg, wl=None, seconds_budget=30.0):
     """The CPU port of the step (our host logic + oracle/ ops + the OA-Mix oracle) on ONE full-resolution image
-    (1024x2048, 20 boxes, both views): a bounded sample of the same workload, no extrapolation."""
+    (r50_fpn: 1024x2048, 20 boxes; r101_dc5: 736x1280, 12 boxes; both views): a bounded sample of the same workload, no
+    extrapolation."""
     from oadg_amd import build_detector
     from oadg_amd.apis import build_optimizer
     from oadg_amd.detectors import integrate_data
@@ -233,11 +330,12 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     prev_threads = torch.get_num_threads()
     threads = min(prev_threads, 32)      # many-core hosts: small CPU ops do not scale past a few dozen threads
     torch.set_num_threads(threads)
-    H, W = 1024, 2048
+    wl = wl or CONFIGS['r50_fpn']
+    H, W, nbox = wl['height'], wl['width'], wl['boxes']
     rs = np.random.RandomState(0)
     img = lowpass_image(rs, H, W)
-    gts = synthetic_boxes(rs, 20, H, W, 12, 200)
-    labels = rs.randint(0, 8, 20).astype(np.int64)
+    gts = synthetic_boxes(rs, nbox, H, W, 12, 200)
+    labels = rs.randint(0, wl['classes'], nbox).astype(np.int64)
     det = build_detector(cfg.model)
     det.init_weights(allow_missing_pretrained=True)
     det.train()
@@ -250,7 +348,8 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     np.random.seed(0)
     torch.manual_seed(0)
     t0 = time.time()
-    r = OO.OAMixOracle(version='augmix')(dict(img=img.copy(), gt_bboxes=gts.copy()))
+    okw = next(({k: v for k, v in t.items() if k != 'type'} for t in cfg.data.train.pipeline if t['type'] == 'OAMix'), {})
+    r = OO.OAMixOracle(**okw)(dict(img=img.copy(), gt_bboxes=gts.copy()))
     t_mix = time.time() - t0
     shape = (H, W, 3)
     data = dict(img=norm(img), img2=norm(r['img2']), gt_bboxes=[torch.from_numpy(gts)],
@@ -266,11 +365,134 @@ def cpu_baseline(cfg, seconds_budget=30.0):
     t_all = time.time() - t0
     torch.set_num_threads(prev_threads)
     return dict(value=round(1.0 / t_all, 5), unit='images/s', cores=threads, kind='port',
-                sample=f'1 image at {H}x{W} (one of the 4 images of a step): OA-Mix oracle {t_mix:.1f}s + '
+                sample=f'1 image at {H}x{W} (one of the {wl["batch"]} images of a step): OA-Mix oracle {t_mix:.1f}s + '
                        f'detector step with oracle ops {t_all - t_mix:.1f}s, torch {threads} threads, '
-                       f'nproc={os.cpu_count()}.  For comparison, the GENUINE reference python (tier-C harness, '
-                       f'SURVEY.md section 0) measured on the build container: 122.6 s per step of 2 images at 1024x2048 '
-                       f'on 8 cores = 0.016 images/s')
+                       f'nproc={os.cpu_count()}.' + ('  For comparison, the GENUINE reference python (tier-C harness, '
+                       'SURVEY.md section 0) measured on the build container: 122.6 s per step of 2 images at 1024x2048 '
+                       'on 8 cores = 0.016 images/s' if (H, W) == (1024, 2048) else ''))
+
+
+STRESS_METRIC = 'images/sec, OA-Mix (4096 boxes/image) + OA-Loss (8 x 512 x 2 RoI contrastive batch) isolate, 1024x2048 (BASELINE configs[4])'
+
+
+def stress_cpu_baseline(H, W, n_boxes_sample=6):
+    """the OA-Mix oracle on ONE full-resolution image with ``n_boxes_sample`` of the 4096 boxes (the restated reference warps
+    the whole image once per box step: ~4.5 s per box on these cores, 4096 boxes would take hours) + the OA-Loss oracle at
+    the full contrastive batch: a bounded sample, nothing extrapolated."""
+    from oracle import losses as OL
+    from oracle import oamix as OO
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from inputs import lowpass_image, supcon_inputs, synthetic_boxes
+    prev_threads = torch.get_num_threads()
+    threads = min(prev_threads, 32)
+    torch.set_num_threads(threads)
+    rs = np.random.RandomState(0)
+    img = lowpass_image(rs, H, W)
+    gts = synthetic_boxes(rs, n_boxes_sample, H, W, 8, 48)
+    np.random.seed(0)
+    t0 = time.time()
+    OO.OAMixOracle(version='augmix')(dict(img=img.copy(), gt_bboxes=gts.copy()))
+    t_mix = time.time() - t0
+    feats, labels = supcon_inputs(0, n_fg_per_img=100, n_rand=17, n_img=8, per_img=512, dim=256)
+    K, B = labels.shape[0], feats.shape[0]
+    f = torch.tensor(feats, requires_grad=True)
+    t0 = time.time()
+    lo = OL.supcon(f, torch.tensor(labels), ori_size=K // 2, rp_size=(B - K) // 2, temper=0.06, loss_weight=0.01)
+    lo.backward()
+    t_sup = time.time() - t0
+    torch.set_num_threads(prev_threads)
+    return dict(value=round(1.0 / (t_mix + t_sup / 8.0), 5), unit='images/s', cores=threads, kind='port',
+                sample=f'OA-Mix oracle on 1 image at {H}x{W} with {n_boxes_sample} boxes (NOT 4096: one full-image warp per '
+                       f'box step) {t_mix:.1f}s + OA-Loss oracle forward + backward at B = {B} rows {t_sup:.1f}s (1/8 of it '
+                       f'charged to the image), torch {threads} threads, nproc={os.cpu_count()}')
+
+
+def oamix_stress_run(a, rank, distributed, dev):
+    """BASELINE configs[4]: the augmentation + OA-Loss kernels in isolation.  One step = the device pipeline pass (OA-Mix
+    of every image + Normalize / Pad) over ``--batch`` (8) images of 1024 x 2048 with 4096 boxes of 8 - 48 px each, then the
+    OA-Loss (supcon forward + backward) at the contrastive batch 8 x 512 RoIs x 2 views + the random RoIs.  Inputs are
+    resident in HBM; the same barrier / synchronise / max-over-ranks protocol as the training workload."""
+    import oadg_amd  # noqa: F401
+    from oadg_amd import Config, hip_ops
+    from oadg_amd.apis import set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from inputs import supcon_inputs
+    H, W, NB = a.height, a.width, 4096
+    cfg = Config.fromfile(CFG)
+    set_random_seed(1 + rank)
+    ds = SyntheticCityscapes(img_shape=(H, W), num_boxes=NB, num_classes=8, box_size=(8, 48), seed=rank, device=dev)
+    pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
+    nb = 2
+    batches = [ds.batch(range(i * a.batch, (i + 1) * a.batch)) for i in range(nb)]
+    feats, labels = supcon_inputs(rank, n_fg_per_img=100, n_rand=17, n_img=8, per_img=512, dim=256)
+    K, B = labels.shape[0], feats.shape[0]
+    f = torch.tensor(feats, device=dev, requires_grad=True)
+    lab = torch.tensor(labels, device=dev)
+    torch.cuda.synchronize()
+    ev = {'pass': [], 'supcon': []}
+    record = [False]
+
+    def step(i):
+        es = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if record[0] else None
+        if es:
+            es[0].record()
+        data = pipe(*batches[i % nb])
+        if es:
+            es[1].record()
+        f.grad = None
+        loss = hip_ops.supcon_loss(f, lab, K // 2, (B - K) // 2, 0.06, 10, 0.01)
+        loss.backward()
+        if es:
+            es[2].record()
+            ev['pass'].append((es[0], es[1]))
+            ev['supcon'].append((es[1], es[2]))
+        return {'loss': loss, 'img2': data['img2']}
+    np.random.seed(1000 + rank)
+    for i in range(a.warmup):
+        step(i)
+    pipe.oamix.stats = {}
+    record[0] = True
+    clocks = ClockSampler(torch.cuda.current_device()).start() if rank == 0 else None
+    dt, out = timed_region(step, a, distributed, dev, torch.cuda.synchronize)
+    clock_summary = clocks.stop() if clocks is not None else None
+    if rank != 0:
+        return
+    st = pipe.oamix.stats
+    views = a.steps * a.batch
+    S = st.get('compose_steps', 0)
+    # SURVEY.md 8d OA-Mix row, "materialise every step" model with the S actually drawn: 3 H W (2 S + C + 2) per view + the
+    # per-box steps' rect bytes
+    model = 3.0 * H * W * (2 * S + (3 + 2) * views) + 3.0 * st.get('bbox_px', 0)
+    ms_pass = sum(e0.elapsed_time(e1) for e0, e1 in ev['pass'])
+    ms_sup = sum(e0.elapsed_time(e1) for e0, e1 in ev['supcon'])
+    flops = 6.0 * B * B * 256 * a.steps
+    roof = {'kernel': 'OA-Mix device pass (every oamix.hip launch of the step: box profiles, fg union by rect scatter, saliency, '
+                      'per-box blend chains, LUT / compose steps, tile-binned object-aware mixing, normalize)',
+            'bound': 'hbm', 'achieved': round(model / (ms_pass * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(model / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), 'traffic': None,
+            'avg_launch_ms': round(ms_pass / a.steps, 3), 'launches': a.steps,
+            'algorithmic_bytes_per_launch': int(model / a.steps),
+            'bytes_model': 'SURVEY 8d: 3 H W (2 S + C + 2) per view for the S compose steps drawn + 3 w h per per-box step',
+            'ms_per_view': round(ms_pass / views, 3), 'compose_steps_per_view': round(S / views, 2),
+            'bbox_ops_per_view': round(st.get('bbox_ops', 0) / views, 2),
+            'note': 'host-bound: the pass is ~70 % host planning (4096-box plans on planner threads) - see '
+                    'profiles/r05_stress_kernel_stats.csv for the kernel split',
+            'families': [{'family': 'OA-Loss supcon forward + backward', 'kernels': ['supcon_tile_kernel'], 'bound': 'mfma-f32',
+                          'launches_per_step': 2.0, 'ms_per_step': round(ms_sup / a.steps, 3),
+                          'achieved': round(flops / (ms_sup * 1e-3) / 1e12, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                          'frac': round(flops / (ms_sup * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                          'rows': f'B = {B} (8 img x 512 RoIs x 2 views + {B - K} random), D = 256'}]}
+    res = {'metric': STRESS_METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
+           'n_gpus': a.gpus, 'rccl_ranks': (dist.get_world_size() if distributed and dist.get_backend() == 'nccl' else 1),
+           'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 (OA-Mix) / f32 (OA-Loss)', 'data': 'synthetic',
+           'config': {'workload': f'OA-Mix stress: {NB} boxes/image of 8-48 px, {a.batch} img/GPU, {H}x{W}, view 2 of every image '
+                                  f'+ Normalize/Pad; OA-Loss at B = {B} rows', 'global_batch': a.gpus * a.batch,
+                      'parallelism': f'dp{a.gpus}', 'final_loss': round(float(out['loss']), 5)},
+           'clocks': clock_summary, 'roofline': roof,
+           'cpu_baseline': None if (a.no_cpu_baseline or a.gpus != 1) else stress_cpu_baseline(H, W)}
+    print(json.dumps(res))
 
 
 def self_launch(n):
@@ -358,7 +580,10 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dev = torch.device('cuda', torch.cuda.current_device())
-    cfg = Config.fromfile(CFG)
+    if a.workload == 'oamix_stress':
+        return oamix_stress_run(a, rank, distributed, dev)
+    wl = CONFIGS[a.config]
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'oadg', wl['cfg']))
     amp = torch.bfloat16 if a.dtype == 'bf16' else None
     from oadg_amd import hip_conv
     if a.conv == 'mfma' and amp is not None:
@@ -372,7 +597,8 @@ def main():
     if a.conv == 'miopen':
         hip_conv.enable(False)               # (the engine enables the MFMA convolutions for bf16 training)
     set_random_seed(1 + rank)                # per-rank data / augmentation streams
-    ds = SyntheticCityscapes(img_shape=(a.height, a.width), num_boxes=20, num_classes=8, seed=rank, device=dev)
+    ds = SyntheticCityscapes(img_shape=(a.height, a.width), num_boxes=wl['boxes'], num_classes=wl['classes'],
+                             box_size=wl['box_size'], seed=rank, device=dev)
     pipe = DevicePipeline(cfg.data.train.pipeline, dtype=amp or torch.float32)
     nb = min(a.steps + a.warmup, 6)
     batches = [ds.batch(range(i * a.batch, (i + 1) * a.batch)) for i in range(nb)]   # resident in HBM
@@ -430,7 +656,9 @@ def main():
             return plain_step(i)
         finally:
             hip_conv.TIMERS = None
+    clocks = ClockSampler(torch.cuda.current_device()).start() if rank == 0 else None
     dt, out = timed_region(step, a, distributed, dev, torch.cuda.synchronize)
+    clock_summary = clocks.stop() if clocks is not None else None
     step = plain_step
     hip_conv.TIMERS = live
     conv_timers, hip_conv.TIMERS = hip_conv.TIMERS, None
@@ -500,30 +728,41 @@ def main():
                 'frac': None, 'traffic': None, 'note': 'library convolutions (--conv miopen / fp32): no own conv kernel timed'}
     if diag_steps:
         roof['families'] = families_table(diag_conv, diag_ops, roi_sets, diag_steps, elem,
-                                          geom=dict(n_imgs=2 * a.batch, height=a.height, width=a.width))
+                                          geom=dict(n_imgs=2 * a.batch, height=a.height, width=a.width),
+                                          roi_strides=wl['roi_strides'], roi_channels=wl['roi_channels'])
+        # the convolution launches of a step by (kernel, shape), the dozen that take the most time: which SHAPE a family's
+        # time sits in (R101-DC5: the dilated 3x3 of layer4, the 2048 -> 2048 RPN convolution, the 75-channel head)
+        shp = {}
+        for t in diag_conv:
+            e = shp.setdefault((t[4],) + tuple(t[5]), [0, 0.0, 0.0, 0.0])
+            e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]; e[3] += t[3]
+        roof['top_shapes'] = [
+            {'kernel': k_[0], 'N,H,W,C,K,R,stride': list(k_[1:8]), 'dilation': (k_[10] if len(k_) > 10 else 1),
+             'residual': bool(k_[8]), 'mask': bool(k_[9]), 'launches_per_step': round(e[0] / diag_steps, 1),
+             'ms_per_step': round(e[1] / diag_steps, 3), 'tflops': round(e[2] / e[1] / 1e9, 1), 'tbs': round(e[3] / e[1] / 1e9, 2)}
+            for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1])[:12]]
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':      # per-shape table of the conv launches (stderr)
-            shp = {}
-            for t in diag_conv:
-                e = shp.setdefault((t[4],) + t[5], [0, 0.0, 0.0, 0.0])
-                e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]; e[3] += t[3]
+            for key, blocks in (hip_conv._GROUP_TRACE or {}).items():
+                print(f'wgrad group of {len(key)} jobs, {blocks} workgroups: ' +
+                      ' '.join(f'[{n}x{h}x{w} C{c} K{k} R{r} /{sp}]' for n, h, w, c, k, r, sp in key), file=sys.stderr)
             for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1]):
                 print(f'{k_[0][5:]:30s} N{k_[1]} {k_[2]}x{k_[3]} C{k_[4]} K{k_[5]} R{k_[6]} s{k_[7]} res{int(k_[8])} mask{int(k_[9])}: '
                       f'{e[0] / diag_steps:5.1f}/step {e[1] / diag_steps:6.3f} ms/step {e[1] / e[0] * 1e3:7.1f} us {e[2] / e[1] / 1e9:7.1f} TF/s '
                       f'{e[3] / e[1] / 1e9:6.2f} TB/s', file=sys.stderr)
     res = {
-        'metric': METRIC, 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
+        'metric': wl['metric'], 'value': round(a.gpus * a.batch * a.steps / dt, 3), 'unit': 'images/s',
         'n_gpus': a.gpus, 'rccl_ranks': (dist.get_world_size() if distributed and dist.get_backend() == 'nccl' else 1),
         'world_size': dist.get_world_size() if distributed else 1, 'dist_backend': dist.get_backend() if distributed else None,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 2),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-        'config': {'workload': f'faster_rcnn_r50_fpn_1x_cityscapes_oadg: OA-Mix + Faster R-CNN R50-FPN + OA-Loss, '
-                               f'{a.batch} img/GPU x 2 views, {a.height}x{a.width}, 20 boxes/img, SGD step',
+        'config': {'workload': f'{wl["label"]}, {a.batch} img/GPU x 2 views, {a.height}x{a.width}, {wl["boxes"]} boxes/img, SGD step',
                    'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'priming_steps': priming, 'final_loss': round(loss, 4),
                    'conv': a.conv},
+        'clocks': clock_summary,
         'roofline': roof,
     }
     if a.gpus == 1 and not a.no_cpu_baseline:
-        res['cpu_baseline'] = cpu_baseline(cfg)
+        res['cpu_baseline'] = cpu_baseline(cfg, dict(wl, batch=a.batch, height=a.height, width=a.width))
     else:
         res['cpu_baseline'] = None
     print(json.dumps(res))

@@ -203,10 +203,14 @@ class FlatGradReducer:
 
     * parameters are grouped, in reverse registration order (~ the order their gradients become ready), into a few
       buckets of one flat fp32 buffer;
-    * a post-accumulate hook per parameter only counts down; the hook that completes a bucket packs its gradients
-      into the flat slice with ONE ``torch.cat(out=...)`` launch and starts an asynchronous ``all_reduce(AVG)`` on
-      it - the RoI-head FC weights (the largest tensors, first to be ready) reduce while the backbone is still in
-      its backward pass;
+    * the kernels that PRODUCE a gradient (weight-gradient consumers of the convolutions, the cast / permute passes of
+      the RoI head's linears) write it straight into the parameter's slice of the flat buffer (``hip_ops.grad_dest``):
+      ``param.grad`` is that slice before the collective starts, nothing is packed (round 4 copied all 166 MB with a
+      ``torch.cat(out=...)`` per bucket);
+    * a post-accumulate hook per parameter only counts down; the hook that completes a bucket copies the few gradients
+      that are not in place (bias vectors, anything a torch operator produced) with one multi-tensor launch and starts
+      an asynchronous ``all_reduce(AVG)`` on the bucket - the RoI-head FC weights (the largest tensors, first to be
+      ready) reduce while the backbone is still in its backward pass;
     * ``finish()`` (before ``optimizer.step()``) makes the compute stream wait for the reductions and re-points each
       ``param.grad`` at its slice of the reduced buffer.  Parameters that received no gradient contribute zeros;
       buckets are all-reduced strictly in index order, so ranks whose graphs differ still issue matching collectives.
@@ -252,6 +256,21 @@ class FlatGradReducer:
             b['pending'], b['work'] = len(b['params']), None
         self._next = 0                      # index of the next bucket to all-reduce (strict order, see _launch_in_order)
         self._hooks = [p.register_post_accumulate_grad_hook(self._ready) for p in params]
+        # gradient producers with kernels of their own write into the bucket slices directly (hip_ops.grad_dest)
+        self.in_place_bytes = self.packed_bytes = 0
+        self.pre_collective = None
+        if os.environ.get('OADG_GRAD_SINK', '1') == '1':
+            from . import hip_ops
+            hip_ops.GRAD_SINK = self.views
+
+    def close(self):
+        """detach from the module: remove the hooks and stop offering the bucket slices to the gradient producers"""
+        from . import hip_ops
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if hip_ops.GRAD_SINK is self.views:
+            hip_ops.GRAD_SINK = None
 
     @staticmethod
     def _dense(t):
@@ -296,16 +315,30 @@ class FlatGradReducer:
         from . import hip_conv
         hip_conv.flush_deferred()         # weight / bias gradients whose launches were deferred (hip_conv.DEFER_*) are read now
         flat = self.flat[b['start']:b['end']]
-        if all(p.grad is not None for p in b['params']):
-            torch.cat([self._memory_order(p.grad, p) for p in b['params']], out=flat)     # ONE packing launch
-        else:
-            # a parameter without a gradient contributes zeros (its slice of ``flat`` is the destination itself, so it
-            # cannot also be an input of ``cat``): per-parameter copies on this rare path
-            for p in b['params']:
-                if p.grad is None:
-                    self.views[p].zero_()
-                else:
-                    self.views[p].copy_(p.grad)
+        # Gradients whose producers wrote them straight into their bucket slice (hip_ops.grad_dest: convolution weights, BN
+        # scales, the RoI head's linears - all but a few hundred KB of a step's gradients) are in place already; the rest
+        # (bias / BN-shift vectors, anything a torch operator produced) are packed by ONE multi-tensor copy.  A parameter
+        # without a gradient contributes zeros.
+        dst, src = [], []
+        for p in b['params']:
+            g, v = p.grad, self.views[p]
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() == v.data_ptr() and g.stride() == v.stride() and g.dtype == v.dtype:
+                self.in_place_bytes += g.numel() * 4
+            else:
+                dst.append(v)
+                src.append(g)
+                self.packed_bytes += g.numel() * 4
+        if dst:
+            f = getattr(torch, '_foreach_copy_', None)
+            if f is not None and all(s_.shape == d_.shape for s_, d_ in zip(src, dst)):
+                f(dst, src)
+            else:
+                for d_, s_ in zip(dst, src):
+                    d_.copy_(s_)
+        if self.pre_collective is not None:        # tests: observe the bucket right before its all-reduce is issued
+            self.pre_collective(self, b)
         b['work'] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._has_avg() else dist.ReduceOp.SUM,
                                     group=self.group, async_op=True)
 

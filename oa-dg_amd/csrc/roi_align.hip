@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const flo
     const T* base = reinterpret_cast<const T*>(p.feat[g.lvl]) + (size_t)(bad_batch ? 0 : g.batch) * H * W * C;
     for (int bin = wave; bin < PH * PW; bin += 4) {
         const int ph = bin / PW, pw = bin - ph * PW;
-        for (int c0 = lane * 4; c0 < C; c0 += 256) {
+        // (channel chunks of 256 on blockIdx.y: a 2048-channel C5 map - R101-DC5 - gives every RoI eight workgroups instead
+        //  of an eight-trip loop around ~200 dependent corner loads; C <= 256: gridDim.y = 1, the loop runs once)
+        for (int c0 = blockIdx.y * 256 + lane * 4; c0 < min(C, (int)(blockIdx.y + 1) * 256); c0 += 256) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (!bad_batch) {
                 for (int iy = 0; iy < g.grid_h; ++iy) {
@@ -354,7 +356,7 @@ __device__ void axis_tile_weights(float start, float bin, int grid, int b, int s
 //    4 columns per lane in registers) run through the tile's pair list independently.
 // Deterministic (the RoIs of a tile are visited in `order`, fixed fp32 summation order), one bf16 rounding at the end.
 constexpr int TB_THREADS = 512;
-constexpr int TPW = 8;               // tiles per workgroup
+constexpr int TPW = 8;               // tiles per workgroup (at most: fewer when the maps are small, see the launcher)
 constexpr int HB = 32;               // pairs per table batch
 
 struct TileTables {
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
                                                                          const unsigned short* __restrict__ gout,
                                                                          const int* __restrict__ order,
                                                                          const int* __restrict__ range,
-                                                                         const int4* __restrict__ boxes) {
+                                                                         const int4* __restrict__ boxes, int tpw) {
     __shared__ TileTables tab[HB];
     __shared__ int hits[TB_THREADS];
     __shared__ int wcnt[TB_THREADS / 64];
@@ -406,9 +408,9 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
     while (lvl + 1 < p.levels && (int)blockIdx.x >= tg.first[lvl + 1]) ++lvl;
     const int H = p.H[lvl], W = p.W[lvl], C = p.C;
     const int per_img = tg.tx[lvl] * tg.ty[lvl];
-    const int wg_per_img = (per_img + TPW - 1) / TPW;
+    const int wg_per_img = (per_img + tpw - 1) / tpw;
     const int local = blockIdx.x - tg.first[lvl];
-    const int n = local / wg_per_img, t_first = (local - n * wg_per_img) * TPW;
+    const int n = local / wg_per_img, t_first = (local - n * wg_per_img) * tpw;
     const int r0 = range[lvl * p.N + n], r1 = range[lvl * p.N + n + 1];
     const int bins = PH * PW;
     unsigned short* dst = reinterpret_cast<unsigned short*>(const_cast<void*>(p.feat[lvl])) + (size_t)n * H * W * C;
@@ -418,10 +420,11 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
     int4 mybox = make_int4(1, 0, -1, -1);
     int myk = -1;
     if (one_chunk && r0 + tid < r1) { mybox = boxes[r0 + tid]; myk = order[r0 + tid]; }
-    for (int t = t_first; t < t_first + TPW && t < per_img; ++t) {
+    for (int t = t_first; t < t_first + tpw && t < per_img; ++t) {
         const int tyi = t / tg.tx[lvl], txi = t - tyi * tg.tx[lvl];
         const int y0 = tyi * TILE, x0 = txi * TILE;
-        for (int cb = 0; cb < C; cb += 256) {
+        // (the 256-channel chunks of a wider map - R101-DC5's 2048-channel C5 - are workgroups of their own on blockIdx.y)
+        for (int cb = blockIdx.y * 256; cb < min(C, (int)(blockIdx.y + 1) * 256); cb += 256) {
             const int cw = min(256, C - cb);
             float acc[TILE][TILE / 2];
 #pragma unroll
@@ -659,10 +662,10 @@ int oadg_roi_align_fwd(const void* const* feats, const int* heights, const int* 
     if (K == 0) return OADG_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
-        hipLaunchKernelGGL((roi_align_fwd_kernel<float>), dim3(K), dim3(256), 0, st, p, rois, K, PH, PW,
+        hipLaunchKernelGGL((roi_align_fwd_kernel<float>), dim3(K, (C + 255) / 256), dim3(256), 0, st, p, rois, K, PH, PW,
                            sampling_ratio, aligned, (float*)out);
     else
-        hipLaunchKernelGGL((roi_align_fwd_kernel<unsigned short>), dim3(K), dim3(256), 0, st, p, rois, K,
+        hipLaunchKernelGGL((roi_align_fwd_kernel<unsigned short>), dim3(K, (C + 255) / 256), dim3(256), 0, st, p, rois, K,
                            PH, PW, sampling_ratio, aligned, (unsigned short*)out);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
@@ -726,12 +729,21 @@ int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* 
     const int rc = fill_pyramid(p, (const void* const*)dmaps, nullptr, heights, widths, scales, levels, N, C, finest_scale);
     if (rc) return rc;
     TileGrid tg;
+    // tiles per workgroup: 8 on an FPN pyramid (21,760 tiles at BASELINE config 2 -> 2,720 workgroups; an empty workgroup
+    // costs ~10 us of lifetime), fewer when there are not enough tiles to fill the chip that way - R101-DC5's single
+    // 46 x 80 level has 240 tiles: at 8 per workgroup 30 workgroups looped over 8 tiles x 8 channel chunks (11.3 ms);
+    // now 240 x 8 workgroups (tile x chunk)
+    const int nchunk = (C + 255) / 256;
+    long tiles = 0;
+    for (int l = 0; l < levels; ++l) tiles += (long)N * ((widths[l] + TILE - 1) / TILE) * ((heights[l] + TILE - 1) / TILE);
+    int tpw = (int)(tiles * nchunk / 2048);
+    tpw = tpw < 1 ? 1 : (tpw > TPW ? TPW : tpw);
     int total = 0;
     for (int l = 0; l < levels; ++l) {
         tg.first[l] = total;
         tg.tx[l] = (widths[l] + TILE - 1) / TILE;
         tg.ty[l] = (heights[l] + TILE - 1) / TILE;
-        total += N * ((tg.tx[l] * tg.ty[l] + TPW - 1) / TPW);          // workgroups: TPW consecutive tiles of one image
+        total += N * ((tg.tx[l] * tg.ty[l] + tpw - 1) / tpw);          // workgroups: tpw consecutive tiles of one image
     }
     tg.first[levels] = total;
     if (K > 0) {
@@ -739,8 +751,8 @@ int oadg_roi_align_bwd_tiles(void* const* dmaps, const int* heights, const int* 
                            sampling_ratio, aligned, order, (int4*)tile_boxes);
         OADG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(roi_align_bwd_tiles_kernel, dim3(total), dim3(TB_THREADS), 0, (hipStream_t)stream, p, tg, rois, PH,
-                       PW, sampling_ratio, aligned, (const unsigned short*)grad_out, order, range, (const int4*)tile_boxes);
+    hipLaunchKernelGGL(roi_align_bwd_tiles_kernel, dim3(total, nchunk), dim3(TB_THREADS), 0, (hipStream_t)stream, p, tg, rois, PH,
+                       PW, sampling_ratio, aligned, (const unsigned short*)grad_out, order, range, (const int4*)tile_boxes, tpw);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

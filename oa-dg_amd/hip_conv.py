@@ -50,7 +50,7 @@ def _wgrad_record(name, e0, x16, gy16, K, R, S, stride, part_bytes):
     Ho, Wo = gy16.shape[2], gy16.shape[3]
     # algorithmic bytes: x and dy read once, dW (fp32) written once; the split partials are implementation traffic
     TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * S, 2.0 * (N * H * W * C + N * Ho * Wo * K) + 4.0 * K * C * R * S,
-                   name, (N, H, W, C, K, R, stride, False, False)))
+                   name, (N, H, W, C, K, R, stride, False, False, 1)))
 
 
 def _zeros(device):
@@ -273,6 +273,9 @@ class _PartsJob:
         self.prep, self.targets = None, []
 
 
+_GROUP_TRACE = {} if os.environ.get('OADG_BENCH_DIAG_CONV') == '1' else None
+
+
 def wgrad_multi(jobs, target_blocks=256):
     """[(x16, gy16, K, R, S, stride, pad, dil)] -> (workspace, [(part pointer, splits)] per job): the weight gradients of
     several layers as fp32 split partials from ONE launch (csrc oadg_conv2d_wgrad_multi)"""
@@ -296,6 +299,10 @@ def wgrad_multi(jobs, target_blocks=256):
         parts.append((ws.data_ptr() + off, int(r['splits'])))
         off += sz
     name = 'conv_wgrad256_multi_kernel' if (TIMERS is not None and _timed('wgrad256')) else None
+    if name and _GROUP_TRACE is not None:
+        key = tuple((int(r['N']), int(r['H']), int(r['W']), int(r['C']), int(r['K']), int(r['R']), int(r['splits'])) for r in tab)
+        if key not in _GROUP_TRACE:      # bench.py OADG_BENCH_DIAG_CONV: what each grouped launch is made of
+            _GROUP_TRACE[key] = int(total)
     if name:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -311,7 +318,7 @@ def wgrad_multi(jobs, target_blocks=256):
             P = N * gy16.shape[2] * gy16.shape[3]
             fl += 2.0 * P * K * C * R * S
             by += 2.0 * (N * H * W * C + P * K) + 4.0 * K * C * R * S
-        TIMERS.append((e0, e1, fl, by, name, (len(jobs), 0, 0, 0, 0, 0, 0, False, False)))
+        TIMERS.append((e0, e1, fl, by, name, (len(jobs), 0, 0, 0, 0, 0, 0, False, False, 1)))
     return ws, parts
 
 
@@ -407,7 +414,7 @@ def conv_forward(x, w, bias, residual, stride, pad, dil, relu, variant=0, mask=N
                               N * Ho * Wo * K / 16.0 * ((mask_bits is not None) + (bits_out is not None))),
                        kernel_name(v, C, K, R, S, stride, pad, residual is not None, mask is not None, mask_bits is not None,
                                    bits_out is not None),
-                       (N, H, W, C, K, R, stride, residual is not None, mask is not None)))
+                       (N, H, W, C, K, R, stride, residual is not None, mask is not None, dil)))
     if want_colsum:
         return y, _colsum(part, K)
     return y
@@ -476,7 +483,7 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
                        + N * H * W * C / 8.0 * (mask_bits is not None),
                        kernel_name(3, K, C, 2, 2, 1, 0, accumulate is not None, mask is not None, mask_bits is not None, False,
                                    scatter=True) + ' x%d (stride-2 dgrad classes)' % len(geo),
-                       (N, Ho, Wo, K, C, R, 2, accumulate is not None, mask is not None)))
+                       (N, Ho, Wo, K, C, R, 2, accumulate is not None, mask is not None, 1)))
     if want_colsum:
         return gx, _colsum(part, C)
     return gx
@@ -576,6 +583,24 @@ def relu_bias_bwd(gy, y, want_bias):
     return (g if write else gy), (db if want_bias else None)
 
 
+def _wgrad_dest(ctx, w, K, has_bn):
+    """(dW, dgamma) output tensors of a _PrepWeights.backward: the parameters' slices of the data-parallel reducer's flat
+    bucket (hip_ops.grad_dest) when this is the parameters' only use of the step and they hold no gradient yet - then
+    AccumulateGrad adopts them and the reducer packs nothing - else new tensors"""
+    from . import hip_ops
+    ent = ctx.entry
+    if hip_ops.GRAD_SINK is not None and ctx.leaf_inputs and ent is not None and ent.step == _STEP and ent.count == 1 and \
+            ent.src[0].dtype == torch.float32 and ent.src[0].stride() == w.stride():
+        dw = hip_ops.grad_dest(ent.src[0], w)
+        dgamma = None
+        if has_bn:
+            g = ent.src[1]
+            dgamma = hip_ops.grad_dest(g) if (g.dtype == torch.float32 and g.is_contiguous()) else \
+                torch.empty((K,), dtype=torch.float32, device=w.device)
+        return dw, dgamma
+    return torch.empty_like(w), (torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None)
+
+
 class _PrepWeights(torch.autograd.Function):
     """(w fp32 [K,C,R,S], optional eval-mode BN, optional bias) -> (wf bf16 KRSC, bias fp32, wt bf16 for dgrad):
     one launch (csrc/conv_mfma.hip prep_weights_kernel) instead of the ~10 element-wise ops of the unfused fold
@@ -655,8 +680,7 @@ class _PrepWeights(torch.autograd.Function):
             parts, tok.parts = tok.parts, None
         if gwf is not None and isinstance(parts, _WgradJob):
             # a small layer inside TrainEngine's backward: its weight gradient joins the current group
-            dw = torch.empty_like(w)
-            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            dw, dgamma = _wgrad_dest(ctx, w, K, has_bn)
             job = parts
             defer = ctx.leaf_inputs and ent is not None and ent.step == _STEP and ent.count == 1 and \
                 all(t.grad is None for t in ent.src) and DEFER_WGRAD
@@ -675,8 +699,7 @@ class _PrepWeights(torch.autograd.Function):
                 ent is not None and ent.step == _STEP and ent.count == 1 and all(t.grad is None for t in ent.src):
             # partials of a single-layer launch inside TrainEngine's backward: their consumer joins the group's (one launch
             # for all of them instead of one per layer - 14 launches of 9 - 22 us per step)
-            dw = torch.empty_like(w)
-            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            dw, dgamma = _wgrad_dest(ctx, w, K, has_bn)
             job = _PartsJob(parts[0], parts[1], K, C, R, S)
             job.prep = (gb_now, w, scale, mean, var, eps, int(krsc) | raw, dw.detach(),
                         dgamma.detach() if dgamma is not None else None)
@@ -685,16 +708,14 @@ class _PrepWeights(torch.autograd.Function):
                 job.targets.append((ent.src[1], job.prep[8]))
             _WQ.append(job)
         elif gwf is not None and parts is not None:        # fp32 split partials straight from the wgrad kernel
-            dw = torch.empty_like(w)                 # w's strides (channels_last parameters keep theirs)
-            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            dw, dgamma = _wgrad_dest(ctx, w, K, has_bn)      # w's strides (channels_last parameters keep theirs)
             check(L.oadg_prep_conv_weights_bwd_parts(ptr(parts[0]), parts[1], ptr(gb_now), ptr(w), ptr(scale), ptr(mean),
                                                      ptr(var), eps, K, C, R, S, ptr(dw), ptr(dgamma), int(krsc) | raw,
                                                      stream_ptr()),
                   'oadg_prep_conv_weights_bwd_parts')
         elif gwf is not None:
             gwf = gwf.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dw = torch.empty_like(w)
-            dgamma = torch.empty((K,), dtype=torch.float32, device=w.device) if has_bn else None
+            dw, dgamma = _wgrad_dest(ctx, w, K, has_bn)
             check(L.oadg_prep_conv_weights_bwd(ptr(gwf), ptr(gb_now), ptr(w), ptr(scale), ptr(mean), ptr(var), eps, K, C,
                                                R, S, ptr(dw), ptr(dgamma), int(krsc) | raw, stream_ptr()),
                   'oadg_prep_conv_weights_bwd')

@@ -272,7 +272,28 @@ def parse_losses(values, name_of, n_names, mask):
 FUSED_PARSE_LOSSES = os.environ.get('OADG_FUSED_PARSE_LOSSES', '1') == '1'
 
 
-# --------------------------------------------------------------------------------------- one cast pass for a head's parameters
+# --------------------------------------------------------------------------------------- gradients straight into DDP buckets
+# apis.FlatGradReducer sets GRAD_SINK = {parameter: its slice of the flat fp32 bucket buffer, in the parameter's layout}.  The
+# functions that PRODUCE a parameter's gradient with a kernel of their own (convolution weights / BN scales:
+# hip_conv._PrepWeights; the RoI head's linears: _CastAll / _FcWeightPermute below) then write it there instead of into a new
+# tensor: AccumulateGrad adopts a gradient it holds the only reference to, so ``param.grad`` IS the bucket slice and the
+# reducer has nothing to pack (the round-4 form copied every gradient into its bucket: 166 MB read + 166 MB written per step).
+GRAD_SINK = None
+
+
+def grad_dest(param, like=None):
+    """the tensor a producer should write ``param``'s gradient into: a fresh alias of the parameter's bucket slice when a
+    reducer is active and the parameter holds no gradient yet (a second contribution in the same step must be SUMMED by
+    autograd: it gets a tensor of its own), else a new fp32 tensor shaped and laid out like ``like`` (default: the parameter)"""
+    sink = GRAD_SINK
+    if sink is not None and param is not None and param.grad is None:
+        v = sink.get(param)
+        if v is not None:
+            return v.detach()
+    like = param if like is None else like
+    return torch.empty_like(like, dtype=torch.float32)
+
+
 def _foreach_copy(dst, src):
     f = getattr(torch, '_foreach_copy_', None)
     if f is not None:
@@ -291,12 +312,15 @@ class _CastAll(torch.autograd.Function):
     def forward(ctx, *params):
         outs = [torch.empty_like(p, dtype=torch.bfloat16) for p in params]
         _foreach_copy(outs, [p.detach() for p in params])
+        ctx.params = params if all(p.is_leaf for p in params) else None
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         live = [g for g in grads if g is not None]
-        outs = [torch.empty_like(g, dtype=torch.float32) for g in live]
+        ps = [p for p, g in zip(ctx.params, grads) if g is not None] if ctx.params is not None else [None] * len(live)
+        outs = [grad_dest(p, g) if (p is not None and g.is_contiguous()) else torch.empty_like(g, dtype=torch.float32)
+                for p, g in zip(ps, live)]
         if live:
             _foreach_copy(outs, live)
         it = iter(outs)
@@ -326,6 +350,7 @@ class _FcWeightPermute(torch.autograd.Function):
         out = torch.empty((O, P * C), dtype=torch.bfloat16, device=w.device)
         check(_lib.lib().oadg_fc_weight_permute(ptr(w), ptr(out), O, C, P, 0, stream_ptr()), 'oadg_fc_weight_permute')
         ctx.meta = (O, C, P)
+        ctx.param = w if w.is_leaf else None
         return out
 
     @staticmethod
@@ -334,7 +359,7 @@ class _FcWeightPermute(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != torch.bfloat16:
             g = g.to(torch.bfloat16)
-        out = torch.empty((O, C * P), dtype=torch.float32, device=g.device)
+        out = grad_dest(ctx.param) if ctx.param is not None else torch.empty((O, C * P), dtype=torch.float32, device=g.device)
         check(_lib.lib().oadg_fc_weight_permute(ptr(g), ptr(out), O, C, P, 1, stream_ptr()), 'oadg_fc_weight_permute')
         return out, None, None
 

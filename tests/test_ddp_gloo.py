@@ -145,6 +145,79 @@ def test_flat_reducer_parameter_without_gradient_on_one_rank():
             assert np.array_equal(red0[i], red1[i])
 
 
+def _worker_sink(rank, world, port, q):
+    """gradients produced by a function with a kernel of its own (here hip_ops.cast_all_bf16, which runs on CPU tensors
+    too) are written into the reducer's bucket slices: ``param.grad`` lies inside the flat buffer BEFORE the collective"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import torch.nn as nn
+    import torch.nn.functional as F
+    import oadg_amd  # noqa: F401
+    from oadg_amd import hip_ops
+    from oadg_amd.apis import FlatGradReducer
+    torch.manual_seed(0)
+    net = nn.ModuleList([nn.Linear(32, 64), nn.Linear(64, 16), nn.Linear(16, 4)])
+    red = FlatGradReducer(net, bucket_mb=1e-3, tail_mb=0)          # 262 floats per bucket: three buckets
+    assert hip_ops.GRAD_SINK is red.views
+    lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
+    seen = []
+
+    def pre(r, b):       # right before the bucket's all-reduce is issued
+        for p_ in b['params']:
+            seen.append((p_.grad is not None and lo <= p_.grad.data_ptr() < hi and
+                         p_.grad.data_ptr() == r.views[p_].data_ptr(), p_.grad.clone()))
+    red.pre_collective = pre
+    torch.manual_seed(100 + rank)
+    out = []
+    for step in range(2):
+        for p_ in net.parameters():
+            p_.grad = None
+        seen.clear()
+        x = torch.randn(8, 32)
+        ps = [t for m in net[:2] for t in (m.weight, m.bias)]          # layers 0 and 1 through the one-pass cast
+        c = dict(zip(ps, hip_ops.cast_all_bf16(ps)))
+        h = F.linear(x.bfloat16(), c[net[0].weight], c[net[0].bias]).relu()
+        h = F.linear(h, c[net[1].weight], c[net[1].bias]).relu()
+        y = net[2](h.float()).sum()                                      # layer 2: a torch operator produces its gradients
+        y.backward()
+        red.finish()
+        out.append(([f_ for f_, _ in seen], [g_.numpy() for _, g_ in seen],
+                    [p_.grad.clone().numpy() for b in red.buckets for p_ in b['params']],
+                    red.in_place_bytes, red.packed_bytes))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_reducer_gradients_are_written_into_the_buckets():
+    """no packing copy - the producers' gradients ARE bucket slices before the collective (4 of the 6
+    parameters here; the last layer's come from torch operators and are packed by the multi-tensor copy), and the result
+    is the mean of the two ranks' local gradients either way."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 25500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_sink, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, 240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, out0), (_, out1) = res
+    for step in range(2):
+        in0, loc0, red0, ipb0, pkb0 = out0[step]
+        in1, loc1, red1, _, _ = out1[step]
+        # bucket order = reverse registration: layer 2 (bias, weight: packed), then layers 1 and 0 (in place)
+        assert in0 == in1 == [False, False, True, True, True, True], in0
+        for a, b, r0, r1 in zip(loc0, loc1, red0, red1):
+            assert np.allclose(r0, 0.5 * (a + b), rtol=1e-6, atol=1e-7)
+            assert np.array_equal(r0, r1)
+        assert ipb0 == (step + 1) * 4 * (32 * 64 + 64 + 64 * 16 + 16) and pkb0 == (step + 1) * 4 * (16 * 4 + 4)
+
+
 _RESULTS = {}
 
 
