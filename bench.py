@@ -761,6 +761,10 @@ def main():
         'clocks': clock_summary,
         'roofline': roof,
     }
+    if engine.reducer is not None:       # gradient bytes the producers wrote straight into the buckets vs packed by a copy
+        n_ = max(engine.reducer.steps, 1)
+        res['config']['grad_mb_in_place_per_step'] = round(engine.reducer.in_place_bytes / n_ / 1e6, 1)
+        res['config']['grad_mb_packed_per_step'] = round(engine.reducer.packed_bytes / n_ / 1e6, 1)
     if a.gpus == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(cfg, dict(wl, batch=a.batch, height=a.height, width=a.width))
     else:

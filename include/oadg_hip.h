@@ -672,6 +672,32 @@ int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, i
                      float pos_weight, const float* means4, const float* stds4, float* rois, int64_t* labels,
                      float* label_weights, float* bbox_targets, float* bbox_weights, float* absolute, void* stream);
 
+int oadg_roi_targets_dev(const oadg_roi_target_entry* entries_host, int n_entries, int n_target, int n_src,
+                         const int* counts_dev, int64_t fill_label, float pos_weight, const float* means4,
+                         const float* stds4, float* rois, int64_t* labels, float* label_weights, float* bbox_targets,
+                         float* bbox_weights, float* absolute, void* stream);
+/* (the same with the positive / negative split of every sampled image read from device memory: counts_dev [n_src][2] as
+ *  written by oadg_roi_sample_device, target entry i uses row i % n_src; entry.npos = the entry's row capacity,
+ *  entry.nneg = 0, entry.pos_inds = the image's block of the sampler's `sel`) */
+
+/* RandomSampler.sample of the RoI head for up to 8 images in ONE launch, on the device, consuming ATen's CPU generator
+ * stream (bit-identical indices, bit-identical engine state afterwards)
+ *   serves BaseSampler.sample / RandomSampler._sample_pos / _sample_neg / random_choice
+ *          mmdet/core/bbox/samplers/base_sampler.py:38-103, random_sampler.py:32-82 (torch.randperm(n)[:k] on the CPU
+ *          generator: ATen randperm_cpu = forward Fisher-Yates on mt19937 outputs)
+ * images_host [B] (HOST array, device pointers inside): gt_inds [n] int64 = the image's assignment with the gts added as
+ * proposals in front (> 0 positive, 0 negative, < 0 ignored), n <= oadg_roi_sample_max_rows().  mt_state (device,
+ * in/out) [626] uint32 = at::mt19937 state words [624], left, next.  Outputs: sel [B][num] int64 = per image the sorted
+ * positive indices, then the sorted negative indices; counts [B][2] = k_pos, k_neg; flags [B]: bit 0 = fewer than num rows
+ * sampled (the fixed-capacity layout has padding rows), bit 1 = image outside the kernel's domain (nothing sampled). */
+typedef struct oadg_roi_sample_image {
+    const int64_t* gt_inds;
+    int n;
+} oadg_roi_sample_image;
+int oadg_roi_sample_max_rows(void);
+int oadg_roi_sample_device(const oadg_roi_sample_image* images_host, int B, int num, int num_pos_exp, float neg_pos_ub,
+                           uint32_t* mt_state, int64_t* sel, int* counts, int* flags, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58

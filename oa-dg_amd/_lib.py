@@ -46,6 +46,14 @@ class RoiTargetEntry(Structure):
 ROI_TARGET_MAX_ENTRIES = 32
 
 
+class RoiSampleImage(Structure):
+    """oadg_roi_sample_image (include/oadg_hip.h)"""
+    _fields_ = [('gt_inds', c_void_p), ('n', c_int)]
+
+
+ROI_SAMPLE_MAX_IMAGES = 8
+
+
 class RegionOp(Structure):
     """oadg_region_op (include/oadg_hip.h)"""
     _fields_ = [('kind', c_int), ('param', c_int), ('image', c_void_p), ('minv', c_double * 6)]
@@ -132,6 +140,9 @@ SIGNATURES = {
     'oadg_roi_assign_add_gt': (ci, [vp, ci, ci, ci, cf, cf, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t,
                                     vp, vp]),
     'oadg_roi_targets': (ci, [vp, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'oadg_roi_targets_dev': (ci, [vp, ci, ci, ci, vp, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'oadg_roi_sample_max_rows': (ci, []),
+    'oadg_roi_sample_device': (ci, [vp, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -307,6 +307,57 @@ class SamplingResult:
         return torch.cat([self.pos_bboxes, self.neg_bboxes])
 
 
+class DeviceSamplingResult:
+    """The sampled rows of one image with the positive / negative split on the DEVICE (csrc/roi_sampler.hip): ``sel`` [num]
+    holds the sorted positive indices, then the sorted negative indices; ``cnt`` [2] = (k_pos, k_neg).  The fused consumers
+    (BBoxHead.rois_and_targets, the fused losses) never need the split on the host; the SamplingResult attributes exist for
+    everything else and read the two counts back on first use (a device synchronisation)."""
+
+    def __init__(self, sel, cnt, cap, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.sel, self.cnt, self.cap = sel, cnt, int(cap)
+        self._src = (bboxes, gt_bboxes, assign_result, gt_flags)
+        self.num_gts = gt_bboxes.shape[0]
+        self._cache = {}
+        self._host = None
+
+    def _split(self):
+        if self._host is None:
+            kp, kn = (int(v) for v in self.cnt.tolist())
+            self._host = (self.sel[:kp], self.sel[kp:kp + kn])
+        return self._host
+
+    pos_inds = property(lambda self: self._split()[0])
+    neg_inds = property(lambda self: self._split()[1])
+    _get = SamplingResult._get
+    pos_bboxes = SamplingResult.pos_bboxes
+    neg_bboxes = SamplingResult.neg_bboxes
+    pos_is_gt = SamplingResult.pos_is_gt
+    pos_assigned_gt_inds = SamplingResult.pos_assigned_gt_inds
+    pos_gt_bboxes = SamplingResult.pos_gt_bboxes
+    pos_gt_labels = SamplingResult.pos_gt_labels
+    bboxes = SamplingResult.bboxes
+
+
+# Device-side RoI sampling is SPECULATIVE about one thing: that every image yields the sampler's full ``num`` rows (1000
+# proposals + gts against num = 512: always, in practice), which fixes every downstream shape without a host read.  The
+# trainer opens a record per step (begin_speculation), every device sampling appends its flag buffer + generator, and the
+# trainer checks the flags before the optimizer step - by then the copy has long landed - and repeats the step through the
+# host path if an image came up short (apis.TrainEngine._step).  Outside such a record the host path runs.
+DEVICE_SAMPLER = os.environ.get('OADG_DEVICE_SAMPLER', '1') == '1'
+_SPEC = None
+
+
+def begin_speculation():
+    global _SPEC
+    _SPEC = [] if DEVICE_SAMPLER else None
+
+
+def end_speculation():
+    global _SPEC
+    recs, _SPEC = _SPEC, None
+    return recs or []
+
+
 @BBOX_SAMPLERS.register_module()
 class RandomSampler:
     """base_sampler.py:38-103 + random_sampler.py:32-82."""
@@ -446,9 +497,54 @@ class PendingSampling:
                  sel[int(jobs[2 * i + 1]['out_off']):int(jobs[2 * i + 1]['out_off']) + plan[i][2]])
                 for i in range(len(plan))]
 
+    def _finish_device(self):
+        """RandomSampler.sample of every image in ONE launch on the device (csrc/roi_sampler.hip), the CPU generator's
+        engine state handed over and back (device_rng): no host read.  None when the inputs are outside the kernel's
+        domain (the host path then runs)."""
+        from .. import _lib, device_rng
+        sampler, B = self.sampler, len(self.prepared)
+        if not (type(sampler) is RandomSampler and 0 < B <= _lib.ROI_SAMPLE_MAX_IMAGES and 0 < sampler.num <= 512 and
+                getattr(self, '_scratch', None) is not None):
+            return None
+        L = _lib.lib()
+        images = (_lib.RoiSampleImage * B)()
+        max_rows = L.oadg_roi_sample_max_rows()
+        for i, prep in enumerate(self.prepared):
+            gi = prep[0].gt_inds
+            if not (gi.is_cuda and gi.dtype == torch.long and gi.is_contiguous() and gi.numel() <= max_rows):
+                return None
+            images[i].gt_inds, images[i].n = gi.data_ptr(), gi.numel()
+        dev = self.prepared[0][1].device
+        num = int(sampler.num)
+        sel = torch.empty((B, num), dtype=torch.long, device=dev)
+        meta = torch.empty(3 * B, dtype=torch.int32, device=dev)          # counts [B][2] | flags [B]
+        counts, flags = meta[:2 * B].view(B, 2), meta[2 * B:]
+        gen = device_rng.generator(dev)
+        if gen.pending():
+            gen.sync_host()
+        state = gen.upload()
+        _lib.check(L.oadg_roi_sample_device(ctypes.cast(images, ctypes.c_void_p), B, num, int(num * sampler.pos_fraction),
+                                            float(sampler.neg_pos_ub), _lib.ptr(state), _lib.ptr(sel), _lib.ptr(counts),
+                                            _lib.ptr(flags), _lib.stream_ptr()), 'oadg_roi_sample_device')
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'nccl':
+            # every rank must take the same decision about repeating the step (its collectives): share the flags
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        host = torch.empty(3 * B, dtype=torch.int32).pin_memory()
+        host.copy_(meta, non_blocking=True)
+        gen.download_async()                      # (its event also covers the copy above: same stream)
+        _SPEC.append(dict(meta=host, B=B, gen=gen))
+        self.results = [DeviceSamplingResult(sel[i], counts[i], num, prep[1], self.gt_bboxes_list[i], prep[0], prep[2])
+                        for i, prep in enumerate(self.prepared)]
+        return self.results
+
     def finish(self):
         if self.results is not None:
             return self.results
+        if _SPEC is not None and self.prepared and self.prepared[0][1].is_cuda:
+            res = self._finish_device()
+            if res is not None:
+                return res
         if self.event is not None:
             self.event.synchronize()
         plan = self._plan()

@@ -110,6 +110,11 @@ struct TargetArgs {
     long long fill_label;
     float pos_weight;
     float mean[4], stdv[4];
+    // device-side sample counts (oadg_roi_sample_device, csrc/roi_sampler.hip): target entry i holds `npos` = its CAPACITY
+    // of rows; its first counts[(i % n_src) * 2] rows are positives, the next counts[.. + 1] negatives (their indices follow
+    // the positives' in pos_inds), the rest - only when the image had fewer candidates than the capacity - is padding
+    const int* counts;
+    int n_src;
 };
 
 __global__ __launch_bounds__(256) void targets_fill_kernel(TargetArgs a) {
@@ -180,6 +185,11 @@ struct RoiTargetArgs {
     long long fill_label;
     float pos_weight;
     float mean[4], stdv[4];
+    // device-side sample counts (oadg_roi_sample_device, csrc/roi_sampler.hip): target entry i holds `npos` = its CAPACITY
+    // of rows; its first counts[(i % n_src) * 2] rows are positives, the next counts[.. + 1] negatives (their indices follow
+    // the positives' in pos_inds), the rest - only when the image had fewer candidates than the capacity - is padding
+    const int* counts;
+    int n_src;
 };
 
 __global__ __launch_bounds__(256) void roi_targets_kernel(const RoiTargetArgs a) {
@@ -198,8 +208,15 @@ __global__ __launch_bounds__(256) void roi_targets_kernel(const RoiTargetArgs a)
             batch = a.e[i].batch; base = a.row_off[i]; ei = i;
         }
     const int j = r - base;
+    bool pad = false;
+    if (a.counts && ei < a.n_target) {
+        const int kp = a.counts[(ei % a.n_src) * 2], kn = a.counts[(ei % a.n_src) * 2 + 1];
+        npos = kp;
+        neg = pos + kp;
+        pad = j >= kp + kn;         // (a short image: the trainer repeats the step on the host path; read nothing stale)
+    }
     const bool is_pos = j < npos;
-    const long long idx = is_pos ? pos[j] : (neg ? neg[j - npos] : (long long)(j - npos));
+    const long long idx = pad ? 0 : (is_pos ? pos[j] : (neg ? neg[j - npos] : (long long)(j - npos)));
     const float* bp = bboxes + idx * stride;
     const float4 p = make_float4(bp[0], bp[1], bp[2], bp[3]);
     float* ro = a.rois + (long)r * 5;
@@ -276,13 +293,15 @@ extern "C" int oadg_anchor_targets(const float* anchors, const float* gts, const
     return OADG_OK;
 }
 
-extern "C" int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, int n_target,
-                                int64_t fill_label, float pos_weight, const float* means4, const float* stds4,
-                                float* rois, int64_t* labels, float* label_weights, float* bbox_targets,
-                                float* bbox_weights, float* absolute, void* stream) {
+namespace {
+int roi_targets_launch(const oadg_roi_target_entry* entries_host, int n_entries, int n_target,
+                       int64_t fill_label, float pos_weight, const float* means4, const float* stds4,
+                       float* rois, int64_t* labels, float* label_weights, float* bbox_targets,
+                       float* bbox_weights, float* absolute, const int* counts_dev, int n_src, void* stream) {
     if (!entries_host || n_entries < 1 || n_entries > OADG_ROI_TARGET_MAX_ENTRIES || n_target < 0 ||
         n_target > n_entries || !rois || !means4 || !stds4)
         return OADG_EARG;
+    if (counts_dev && (n_src < 1 || n_src > n_target)) return OADG_EARG;
     if (n_target > 0 && (!labels || !label_weights || !bbox_targets || !bbox_weights)) return OADG_EARG;
     RoiTargetArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -305,9 +324,31 @@ extern "C" int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n
     a.n_entries = n_entries; a.n_target = n_target; a.target_rows = a.row_off[n_target]; a.rows = (int)rows;
     a.rois = rois; a.labels = (long long*)labels; a.label_weights = label_weights; a.bbox_targets = bbox_targets;
     a.bbox_weights = bbox_weights; a.absolute = absolute; a.fill_label = fill_label; a.pos_weight = pos_weight;
+    a.counts = counts_dev; a.n_src = counts_dev ? n_src : 1;
     for (int i = 0; i < 4; ++i) { a.mean[i] = means4[i]; a.stdv[i] = stds4[i]; }
     if (rows == 0) return OADG_OK;
     hipLaunchKernelGGL(roi_targets_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
+}
+}  // namespace
+
+extern "C" int oadg_roi_targets(const oadg_roi_target_entry* entries_host, int n_entries, int n_target,
+                                int64_t fill_label, float pos_weight, const float* means4, const float* stds4,
+                                float* rois, int64_t* labels, float* label_weights, float* bbox_targets,
+                                float* bbox_weights, float* absolute, void* stream) {
+    return roi_targets_launch(entries_host, n_entries, n_target, fill_label, pos_weight, means4, stds4, rois, labels,
+                              label_weights, bbox_targets, bbox_weights, absolute, nullptr, 0, stream);
+}
+
+// the same with the positive / negative split of every sampled image read from DEVICE memory (counts_dev [n_src][2] of
+// oadg_roi_sample_device; target entry i uses row i % n_src - the views of a batch share their sampling): entry.npos =
+// the entry's row capacity (the sampler's `num`), entry.nneg = 0, entry.pos_inds = the image's block of `sel`
+extern "C" int oadg_roi_targets_dev(const oadg_roi_target_entry* entries_host, int n_entries, int n_target, int n_src,
+                                    const int* counts_dev, int64_t fill_label, float pos_weight, const float* means4,
+                                    const float* stds4, float* rois, int64_t* labels, float* label_weights,
+                                    float* bbox_targets, float* bbox_weights, float* absolute, void* stream) {
+    if (!counts_dev) return OADG_EARG;
+    return roi_targets_launch(entries_host, n_entries, n_target, fill_label, pos_weight, means4, stds4, rois, labels,
+                              label_weights, bbox_targets, bbox_weights, absolute, counts_dev, n_src, stream);
 }

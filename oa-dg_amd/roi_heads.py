@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from . import hip_ops
 from .core import bbox2roi, multi_apply
-from .core.bbox import _pinned_to, roi_assign_sample_begin, sample_many, sample_many_begin
+from .core.bbox import DeviceSamplingResult, _pinned_to, roi_assign_sample_begin, sample_many, sample_many_begin
 from .layers import normal_init, xavier_init
 from .losses import accuracy
 from .registry import (HEADS, ROI_EXTRACTORS, ROI_LAYERS, build_assigner, build_bbox_coder, build_head,
@@ -179,11 +179,27 @@ class BBoxHead(nn.Module):
         if not self.FUSED_TARGETS or n_t == 0 or n_all > _lib.ROI_TARGET_MAX_ENTRIES:
             return None
         first = sampling_results[0]
-        if not first.pos_inds.is_cuda:
+        on_device = isinstance(first, DeviceSamplingResult)      # the positive / negative split lives on the device
+        if not on_device and not first.pos_inds.is_cuda:
             return None
-        dev = first.pos_inds.device
+        if on_device and not all(isinstance(r, DeviceSamplingResult) for r in sampling_results):
+            return None
+        dev = first.sel.device if on_device else first.pos_inds.device
         entries = (_lib.RoiTargetEntry * n_all)()
         keep, K = [], 0
+        n_src = 0
+        if on_device:
+            # the views of a batch share their sampling results (the list repeats them): n_src distinct images whose
+            # count rows are consecutive in one tensor
+            ids = []
+            for r in sampling_results:
+                if id(r) not in ids:
+                    ids.append(id(r))
+            n_src = len(ids)
+            base_cnt = first.cnt
+            if any(r is not sampling_results[i % n_src] or
+                   r.cnt.data_ptr() != base_cnt.data_ptr() + (i % n_src) * 8 for i, r in enumerate(sampling_results)):
+                return None
         for i, r in enumerate(sampling_results):
             bboxes, gtb, ar, _ = r._src
             if ar.labels is None or bboxes.dtype != torch.float32 or bboxes.dim() != 2 or bboxes.stride(1) != 1:
@@ -195,13 +211,18 @@ class BBoxHead(nn.Module):
             if gi.dtype != torch.long or lab.dtype != torch.long:
                 return None
             gi, lab = gi.contiguous(), lab.contiguous()
-            pi, ni = r.pos_inds.contiguous(), r.neg_inds.contiguous()
-            keep.extend((gtb, gi, lab, pi, ni))
             e = entries[i]
             e.bboxes, e.gt_bboxes, e.gt_inds, e.labels = bboxes.data_ptr(), gtb.data_ptr(), gi.data_ptr(), lab.data_ptr()
-            e.pos_inds, e.neg_inds, e.npos, e.nneg = pi.data_ptr(), ni.data_ptr(), pi.numel(), ni.numel()
+            if on_device:       # npos = the row capacity; the kernel reads the split from the count rows
+                keep.extend((gtb, gi, lab))
+                e.pos_inds, e.neg_inds, e.npos, e.nneg = r.sel.data_ptr(), None, r.cap, 0
+                K += r.cap
+            else:
+                pi, ni = r.pos_inds.contiguous(), r.neg_inds.contiguous()
+                keep.extend((gtb, gi, lab, pi, ni))
+                e.pos_inds, e.neg_inds, e.npos, e.nneg = pi.data_ptr(), ni.data_ptr(), pi.numel(), ni.numel()
+                K += pi.numel() + ni.numel()
             e.stride, e.batch = bboxes.stride(0), i
-            K += pi.numel() + ni.numel()
         K_all = K
         for j, b in enumerate(extra):
             if b.dtype != torch.float32 or b.dim() != 2 or b.size(1) < 4 or b.stride(1) != 1 or b.device != dev:
@@ -217,11 +238,18 @@ class BBoxHead(nn.Module):
         absolute = torch.empty((K, 4), dtype=torch.float32, device=dev)
         means = (ctypes.c_float * 4)(*[float(v) for v in self.bbox_coder.means])
         stds = (ctypes.c_float * 4)(*[float(v) for v in self.bbox_coder.stds])
-        _lib.check(_lib.lib().oadg_roi_targets(
-            ctypes.cast(entries, ctypes.c_void_p), n_all, n_t, int(self.num_classes), float(rcnn_train_cfg.pos_weight),
-            ctypes.cast(means, ctypes.c_void_p), ctypes.cast(stds, ctypes.c_void_p), _lib.ptr(rois), _lib.ptr(labels),
-            _lib.ptr(label_weights), _lib.ptr(bbox_targets), _lib.ptr(bbox_weights), _lib.ptr(absolute),
-            _lib.stream_ptr()), 'oadg_roi_targets')
+        if on_device:
+            _lib.check(_lib.lib().oadg_roi_targets_dev(
+                ctypes.cast(entries, ctypes.c_void_p), n_all, n_t, n_src, _lib.ptr(first.cnt), int(self.num_classes),
+                float(rcnn_train_cfg.pos_weight), ctypes.cast(means, ctypes.c_void_p), ctypes.cast(stds, ctypes.c_void_p),
+                _lib.ptr(rois), _lib.ptr(labels), _lib.ptr(label_weights), _lib.ptr(bbox_targets), _lib.ptr(bbox_weights),
+                _lib.ptr(absolute), _lib.stream_ptr()), 'oadg_roi_targets_dev')
+        else:
+            _lib.check(_lib.lib().oadg_roi_targets(
+                ctypes.cast(entries, ctypes.c_void_p), n_all, n_t, int(self.num_classes), float(rcnn_train_cfg.pos_weight),
+                ctypes.cast(means, ctypes.c_void_p), ctypes.cast(stds, ctypes.c_void_p), _lib.ptr(rois), _lib.ptr(labels),
+                _lib.ptr(label_weights), _lib.ptr(bbox_targets), _lib.ptr(bbox_weights), _lib.ptr(absolute),
+                _lib.stream_ptr()), 'oadg_roi_targets')
         del keep
         return rois, K, (labels, label_weights, bbox_targets, bbox_weights, absolute)
 
@@ -249,7 +277,7 @@ class BBoxHead(nn.Module):
         return multiclass_nms(bboxes, scores, cfg.score_thr, cfg.nms, cfg.max_per_img)
 
     def _cls_reg_losses(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights,
-                        avg_factor, reduction_override=None, pos_rows=None):
+                        avg_factor, reduction_override=None, pos_rows=None, view1_rows=None):
         """``cls_score`` / ``bbox_pred`` as the head produced them (bf16 under autocast): the classification loss and the
         tensor path cast to fp32 like the reference's ``loss`` does, the fused box loss reads them as they are."""
         losses = dict()
@@ -257,7 +285,8 @@ class BBoxHead(nn.Module):
         if cls_f is not None and cls_f.numel() > 0:
             losses['loss_cls'] = self.loss_cls(cls_f, labels, label_weights, avg_factor=avg_factor,
                                                reduction_override=reduction_override)
-        fused = self._fused_reg_acc(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows)
+        fused = self._fused_reg_acc(cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows,
+                                    view1_rows)
         if fused is not None:
             losses['acc'], losses['loss_bbox'] = fused[1], fused[0]         # (the reference's key order: loss_cls, acc, loss_bbox)
             return losses
@@ -293,20 +322,29 @@ class BBoxHead(nn.Module):
                 losses['loss_bbox'] = bbox_pred[pos].sum()
         return losses
 
-    def _fused_reg_acc(self, cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows):
+    def _fused_reg_acc(self, cls_score, bbox_pred, labels, bbox_targets, bbox_weights, reduction_override, pos_rows,
+                       view1_rows=None):
         """(loss_bbox, acc) from one launch of csrc/cls_loss.hip (hip_ops.roi_reg_acc) - or None: the tensor path runs.
         ``pos_rows`` (host tensor, ascending) tells which rows are positives without a device read; the fork's
-        ...LossPlus takes the leading chunk of them (view 1, smooth_l1_loss_plus.py: torch.chunk(pos_pred, num_views)[0])."""
+        ...LossPlus takes the leading chunk of them (view 1, smooth_l1_loss_plus.py: torch.chunk(pos_pred, num_views)[0]).
+        ``view1_rows`` (device-side sampling, the split is not on the host): the rows of view 1 - the views share their
+        sampling, so the leading chunk of the positives = the positives among those rows; every other row below that bound
+        is a negative, whose background label the kernel skips: the same rows take part."""
         from .losses import L1Loss, L1LossPlus, SmoothL1Loss, SmoothL1LossPlus
         lb = self.loss_bbox
+        if pos_rows is None and view1_rows is not None:
+            pos_rows = ()
         if not (hip_ops.FUSED_ROI_LOSS and pos_rows is not None and reduction_override is None and cls_score is not None
                 and bbox_pred is not None and bbox_pred.is_cuda and cls_score.numel() > 0 and bbox_pred.dim() == 2
                 and type(lb) in (L1Loss, L1LossPlus, SmoothL1Loss, SmoothL1LossPlus) and lb.reduction == 'mean'
                 and bbox_pred.dtype in (torch.float32, torch.bfloat16) and cls_score.dtype in (torch.float32, torch.bfloat16)
                 and labels.dtype == torch.long and bbox_pred.shape[1] == (4 if self.reg_class_agnostic else 4 * self.num_classes)):
             return None
-        K, P = bbox_pred.shape[0], int(pos_rows.numel())
-        if isinstance(lb, (L1LossPlus, SmoothL1LossPlus)):
+        K = bbox_pred.shape[0]
+        if view1_rows is not None and isinstance(pos_rows, tuple):
+            reg_limit = int(view1_rows) if isinstance(lb, (L1LossPlus, SmoothL1LossPlus)) else K
+        elif isinstance(lb, (L1LossPlus, SmoothL1LossPlus)):
+            P = int(pos_rows.numel())
             n1 = -(-P // lb.num_views)                          # rows of torch.chunk(pos_pred, num_views)[0]
             reg_limit = int(pos_rows[n1 - 1]) + 1 if n1 > 0 else 0
         else:
@@ -316,14 +354,14 @@ class BBoxHead(nn.Module):
                                    beta, float(max(bbox_targets.size(0), 1)), float(lb.loss_weight))
 
     def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights,
-             reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):
+             reduction_override=None, num_sampled=None, pos_rows=None, view1_rows=None, **kwargs):
         """bbox_head.py:397-...: avg_factor = #(label_weights > 0)."""
         avg = None
         if cls_score is not None:
             avg = max(float(num_sampled), 1.) if num_sampled is not None else \
                 max(torch.sum(label_weights > 0).float().item(), 1.)
         return self._cls_reg_losses(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, avg,
-                                    reduction_override, pos_rows=pos_rows)
+                                    reduction_override, pos_rows=pos_rows, view1_rows=view1_rows)
 
 
 class ConvFCBBoxHead(BBoxHead):
@@ -473,7 +511,8 @@ class Shared2FCContrastiveHead(ConvFCBBoxHead):
         return out
 
     def loss(self, cls_score, bbox_pred, cont_feats, rois, labels, label_weights, bbox_targets, bbox_weights,
-             bbox_absolute_targets=None, reduction_override=None, num_sampled=None, pos_rows=None, **kwargs):
+             bbox_absolute_targets=None, reduction_override=None, num_sampled=None, pos_rows=None, view1_rows=None,
+             **kwargs):
         """contrastive_head.py:60-138.  ``num_sampled`` / ``pos_rows`` (host-side facts about the sampling
         results) replace the reference's two device reads: every sampled row has label weight 1."""
         avg = None
@@ -481,7 +520,7 @@ class Shared2FCContrastiveHead(ConvFCBBoxHead):
             avg = max(float(num_sampled), 1.) if num_sampled is not None else \
                 max(torch.sum(label_weights > 0).float().item(), 1.)
         losses = self._cls_reg_losses(cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, avg,
-                                      reduction_override, pos_rows=pos_rows)
+                                      reduction_override, pos_rows=pos_rows, view1_rows=view1_rows)
         labels = labels.contiguous().view(-1, 1)
         if cont_feats is not None and cont_feats.numel() > 0:
             # The reference adds the key only when #foreground > min_samples (a host-side branch on device
@@ -546,12 +585,23 @@ class StandardRoIHead(BaseRoIHead):
     @staticmethod
     def _host_counts(sampling_results):
         """(#sampled rows, flat row indices of the positives) from shapes only - no device read."""
+        if sampling_results and isinstance(sampling_results[0], DeviceSamplingResult):
+            # device-side sampling: every image carries the sampler's full `num` rows (verified by the trainer before the
+            # optimizer step); which of them are positives stays on the device
+            return sum(r.cap for r in sampling_results), None
         total, rows = 0, []
         for r in sampling_results:
             npos, nneg = r.pos_inds.numel(), r.neg_inds.numel()
             rows.append(torch.arange(total, total + npos))
             total += npos + nneg
         return total, (torch.cat(rows) if rows else torch.zeros(0, dtype=torch.long))
+
+    @staticmethod
+    def _view1_rows(sampling_results, pos_rows, kwargs):
+        """rows of the first view when the sampling results keep their positive / negative split on the device"""
+        if pos_rows is not None or not sampling_results or not isinstance(sampling_results[0], DeviceSamplingResult):
+            return None
+        return sum(r.cap for r in sampling_results) // int(kwargs.get('num_views', 1))
 
     def begin_sampling(self, proposal_list, gt_bboxes, gt_labels, num_imgs, **kwargs):
         """Enqueue assignment + the asynchronous candidate-count read for the images that will be sampled; the
@@ -669,7 +719,8 @@ class StandardRoIHead(BaseRoIHead):
             targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
         num_sampled, pos_rows = self._host_counts(sampling_results)
         res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], rois, *targets,
-                                                 num_sampled=num_sampled, pos_rows=pos_rows))
+                                                 num_sampled=num_sampled, pos_rows=pos_rows,
+                                                 view1_rows=self._view1_rows(sampling_results, pos_rows, kwargs)))
         return res
 
 
@@ -715,5 +766,6 @@ class ContrastiveRoIHead(StandardRoIHead):
         with _rf('sec:roi_loss'):
             res.update(loss_bbox=self.bbox_head.loss(res['cls_score'], res['bbox_pred'], res['cont_feats'], rois,
                                                      *targets, num_sampled=num_sampled, pos_rows=pos_rows,
+                                                     view1_rows=self._view1_rows(sampling_results, pos_rows, kwargs),
                                                      **kwargs))
         return res

@@ -269,7 +269,7 @@ def test_flat_reducer_layout_helpers_and_tail_bucket(monkeypatch):
     net = nn.Sequential(nn.Conv2d(8, 8, 3), nn.Conv2d(8, 16, 3), nn.Linear(64, 4096), nn.Linear(4096, 512))
     red = R(net, bucket_mb=4, tail_mb=1)
     sizes = [b['end'] - b['start'] for b in red.buckets]
-    assert sum(sizes) == sum(q.numel() for q in net.parameters())
+    assert sum(sizes) == sum((q.numel() + R.ALIGN - 1) // R.ALIGN * R.ALIGN for q in net.parameters())
     assert red.buckets[0]['params'][0] is list(net.parameters())[-1]          # reverse registration order
     assert sizes[-1] * 4 <= (1 << 20) and red.buckets[-1]['params'][-1] is list(net.parameters())[0]
     for q in net.parameters():
@@ -323,7 +323,9 @@ def test_bucket_plan_on_the_real_parameter_sets(monkeypatch):
         plans[name] = ([round((b['end'] - b['start']) * 4 / 1e6, 1) for b in red.buckets],
                        [(names[b['params'][0]], names[b['params'][-1]]) for b in red.buckets])
         trainable = [p for p in det.parameters() if p.requires_grad]
-        assert sum(b['end'] - b['start'] for b in red.buckets) == sum(p.numel() for p in trainable) == red.flat.numel()
+        pad = lambda n: (n + red.ALIGN - 1) // red.ALIGN * red.ALIGN  # noqa: E731 (slices start on 256-byte boundaries)
+        assert sum(b['end'] - b['start'] for b in red.buckets) == sum(pad(p.numel()) for p in trainable) == red.flat.numel()
+        assert all(red.views[p].data_ptr() % 256 == red.flat.data_ptr() % 256 for p in trainable)
         assert [p for b in red.buckets for p in b['params']] == trainable[::-1]      # reverse registration order
         for p in trainable:
             assert red.views[p].shape == p.shape and red.views[p].stride() == p.stride()
