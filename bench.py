@@ -495,6 +495,24 @@ def oamix_stress_run(a, rank, distributed, dev):
     print(json.dumps(res))
 
 
+def pin_rank_to_cores(local_rank, world):
+    """N ranks share one host: every rank runs a main thread (26 ms of launch work per step), the autograd thread, the
+    pipeline worker and its planner threads.  Each rank gets its own contiguous slice of the cores this process may use
+    (os.sched_setaffinity: threads started later inherit it) and sizes torch's intra-op pool to it, so that the ranks'
+    threads do not migrate onto each other's cores (an all-reduce turns the slowest rank's jitter into everyone's step
+    time).  OADG_BENCH_NO_AFFINITY=1 or a single rank: nothing is pinned.  Returns a description for the JSON line."""
+    if world <= 1 or os.environ.get('OADG_BENCH_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // world
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(per, 16)))
+    return f'{per} of {len(cores)} cores per rank (rank {local_rank}: {mine[0]}-{mine[-1]})'
+
+
 def self_launch(n):
     """``python bench.py --gpus N`` without a launcher: re-run this command line as N ranks on this node"""
     import socket
@@ -533,7 +551,7 @@ def timed_region(step, a, distributed, dev, sync):
     return dt, out
 
 
-def plumbing_run(a, factory, rank, world, distributed):
+def plumbing_run(a, factory, rank, world, distributed, affinity=None):
     """see OADG_BENCH_STEP_FACTORY in main(): same control flow as the GPU run, CPU tensors, gloo"""
     import importlib
     mod, fn = factory.split(':')
@@ -551,7 +569,7 @@ def plumbing_run(a, factory, rank, world, distributed):
         'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'fp32', 'data': 'synthetic',
         'config': dict({'workload': 'PLUMBING RUN on CPU ranks (OADG_BENCH_STEP_FACTORY): NOT a measurement',
-                        'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}',
+                        'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'cpu_affinity': affinity,
                         'final_loss': round(float(out['loss']), 4)}, **extras),
         'roofline': None, 'cpu_baseline': None}))
 
@@ -575,8 +593,9 @@ def main():
         init_dist('pytorch', backend='gloo' if plumbing else 'nccl')
     rank = dist.get_rank() if distributed else 0
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    affinity = pin_rank_to_cores(int(os.environ.get('LOCAL_RANK', 0)), world)
     if plumbing:
-        return plumbing_run(a, plumbing, rank, world, distributed)
+        return plumbing_run(a, plumbing, rank, world, distributed, affinity)
     local = int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -757,7 +776,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': f'{wl["label"]}, {a.batch} img/GPU x 2 views, {a.height}x{a.width}, {wl["boxes"]} boxes/img, SGD step',
                    'global_batch': a.gpus * a.batch, 'parallelism': f'dp{a.gpus}', 'priming_steps': priming, 'final_loss': round(loss, 4),
-                   'conv': a.conv},
+                   'conv': a.conv, 'cpu_affinity': affinity},
         'clocks': clock_summary,
         'roofline': roof,
     }

@@ -474,6 +474,9 @@ class TrainEngine:
             torch.set_rng_state(saved[0])
             np.random.set_state(saved[1])
             loss, log_vars, n, _ = self._forward_backward(data, False)
+        elif first is not data:          # the caller's dict ends up merged, as train_step leaves it (base.py:22-48)
+            data.clear()
+            data.update(first)
         with _rf('sec:optimizer'):
             if self.grad_clip is not None:
                 params = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]

@@ -213,5 +213,7 @@ def test_bench_two_ranks_through_its_own_launch_path_on_gloo():
     assert d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
     assert d['rccl_ranks'] == 0 and 'PLUMBING' in d['config']['workload']
     assert d['config']['params_equal_across_ranks'] is True
+    ncores = len(os.sched_getaffinity(0))       # every rank pinned to its own slice of the cores (bench.pin_rank_to_cores)
+    assert d['config']['cpu_affinity'].startswith(f'{ncores // 2} of {ncores} cores per rank (rank 0: ')
     assert d['config']['param_tensors_changed'] == d['config']['param_tensors'] > 100
     assert np.isfinite(d['config']['final_loss']) and d['value'] > 0

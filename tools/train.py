@@ -106,6 +106,10 @@ def main():
     # (None when the flag is absent: ResNet.init_weights then honours OADG_ALLOW_RANDOM_INIT=1)
     model.init_weights(allow_missing_pretrained=True if a.allow_missing_pretrained else None)
     model = model.to(dev).to(memory_format=torch.channels_last).train()
+    # the log variables stay on the device and are read when a line is printed (every log_config.interval iterations) - the
+    # reference's _parse_losses reads them with .item() on every iteration (base.py:270-275), a full device synchronisation
+    # per step; the printed values are the same
+    model.log_vars_on_host = False
     resume = a.resume_from or (latest_checkpoint(work_dir) if a.auto_resume else None) or cfg.get('resume_from')
     start_iter = start_epoch = skip_batches = 0
     optimizer = build_optimizer(model, cfg.optimizer)
@@ -177,6 +181,7 @@ def main():
         torch.save(state, os.path.join(work_dir, 'latest.pth'))
 
     it, t0 = start_iter, time.time()
+    t_log, it_log = t0, start_iter          # 'time:' = mean iteration time since the previous log line (mmcv TextLoggerHook)
     # software pipeline, the analogue of the reference's DataLoader workers: a loader thread produces batch i+2 (decode +
     # pinned upload, or the synthetic generator), the pipeline worker augments batch i+1 on its side stream (own numpy
     # stream, seeded like a DataLoader worker: datasets/builder.py:194-199), the main thread trains on batch i
@@ -226,10 +231,12 @@ def main():
         it += 1
         done_in_epoch = k + 1
         if rank == 0 and it % interval == 0:
-            lv = {n: float(v) for n, v in out['log_vars'].items()}
+            lv = {n: float(v) for n, v in out['log_vars'].items()}      # (the interval's one device synchronisation)
+            now = time.time()
             print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
-                  f'time: {(time.time() - t0) / (it - start_iter):.3f} ' +
+                  f'time: {(now - t_log) / (it - it_log):.4f} ' +
                   ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
+            t_log, it_log = now, it
     if last_epoch is not None:
         save_checkpoint(last_epoch, it, inner=done_in_epoch if cut_short else None)
     loader.shutdown(wait=False, cancel_futures=True)
