@@ -18,6 +18,7 @@
 // Algorithmic HBM bytes per RoI: PH*PW*C*sizeof(T) written + the unique input footprint
 // (ceil(w_l)+1)(ceil(h_l)+1)*C*sizeof(T) read; corner re-reads (~4x) are served by L1/L2.
 #include "common.h"
+#include <stdlib.h>
 
 #define OADG_MAX_LEVELS 8
 
@@ -81,6 +82,17 @@ __device__ __forceinline__ void store4(unsigned short* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = r;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 load2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ f32x2 load2(const unsigned short* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return f32x2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ void store2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+__device__ __forceinline__ void store2(unsigned short* p, f32x2 v) {
+    *reinterpret_cast<unsigned*>(p) = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+}
+
 struct RoiGeom {
     float start_h, start_w, bin_h, bin_w;
     int grid_h, grid_w, lvl, batch;
@@ -108,13 +120,8 @@ __device__ __forceinline__ RoiGeom roi_geom(const float* roi, const Pyramid& p, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const float* __restrict__ rois,
-                                                            int K, int PH, int PW, int sampling_ratio,
-                                                            int aligned, T* __restrict__ out) {
-    const int k = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
+__device__ void roi_fwd_samples(const Pyramid& p, const RoiGeom& g, int k, int PH, int PW, T* __restrict__ out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* roi = rois + (size_t)k * 5;
-    const RoiGeom g = roi_geom(roi, p, PH, PW, sampling_ratio, aligned);
     const int H = p.H[g.lvl], W = p.W[g.lvl], C = p.C;
     const bool bad_batch = g.batch < 0 || g.batch >= p.N;
     const T* base = reinterpret_cast<const T*>(p.feat[g.lvl]) + (size_t)(bad_batch ? 0 : g.batch) * H * W * C;
@@ -142,6 +149,15 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const flo
             store4(out + ((size_t)k * PH * PW + bin) * C + c0, acc / g.count);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(Pyramid p, const float* __restrict__ rois,
+                                                            int K, int PH, int PW, int sampling_ratio,
+                                                            int aligned, T* __restrict__ out) {
+    const int k = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
+    const RoiGeom g = roi_geom(rois + (size_t)k * 5, p, PH, PW, sampling_ratio, aligned);
+    roi_fwd_samples<T>(p, g, k, PH, PW, out);
 }
 
 __device__ __forceinline__ float load1(const float* p) { return *p; }
@@ -217,6 +233,124 @@ __device__ bool axis_table(float start, float bin, int grid, int b, int size, fl
     *off = o < 0 ? 0 : o;
     *cnt = n;
     return ok;
+}
+
+// Forward by footprint rows (round 5).  The per-sample form above reads four corner rows per sample - 4 g^2 rows of C
+// channels per bin, 49 bins - and is bound by the L1 / texture path (~3.8 GB of rows per launch at BASELINE config 2).  The
+// bilinear weights factorise (see the backward pass): out[ph][pw] = (1 / count) sum_r WY[ph][r] * T_r[pw] with
+// T_r[pw] = sum_q WX[pw][q] f[r][q].  A wave owns a bin row ph (waves 0-3: ph = w and w + 4): for every footprint row r of
+// that bin row it reads each pixel of the RoI's footprint width ONCE (lane = 4 channels: 512-byte wave rows), adds it into
+// the seven column accumulators with the pixel's seven column weights (one 32-byte LDS broadcast), and adds WY * T into
+// the bin row's seven outputs: 7 (b + 2) (7 b + 1) rows per RoI instead of 196 g^2 (b = bin size in pixels, g = ceil(b)):
+// 2 - 2.6x fewer.  fp32 sums in another order than the reference's (iy-major samples): within the 1e-4 bar.  RoIs whose
+// bins span more than FR_SPAN pixels, or PH / PW > 8, take the per-sample form.
+constexpr int FR_SPAN = 32;
+constexpr int FR_WIDTH = RB_MAXP * FR_SPAN + 2;
+constexpr int FR_INFLIGHT = 4;         // pixel loads in flight per wave in the column loop
+
+__device__ bool axis_table_n(float start, float bin, int grid, int b, int size, float* w, int span, int* off, int* cnt) {
+    for (int j = 0; j < span; ++j) w[j] = 0.f;
+    int o = -1, n = 0;
+    bool ok = true;
+    for (int i = 0; i < grid; ++i) {
+        float v = start + b * bin + (i + 0.5f) * bin / (float)grid;
+        if (v < -1.0f || v > (float)size) continue;
+        if (v <= 0.f) v = 0.f;
+        int lo = (int)v, hi;
+        if (lo >= size - 1) { hi = lo = size - 1; v = (float)lo; } else { hi = lo + 1; }
+        const float l = v - lo, h = 1.0f - l;
+        if (o < 0) o = lo;
+        if (hi - o >= span) { ok = false; break; }
+        w[lo - o] += h;
+        w[hi - o] += l;
+        n = hi - o + 1;
+    }
+    *off = o < 0 ? 0 : o;
+    *cnt = n;
+    return ok;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_rows_kernel(Pyramid p, const float* __restrict__ rois,
+                                                                 int K, int PH, int PW, int sampling_ratio,
+                                                                 int aligned, T* __restrict__ out) {
+    __shared__ float wy[RB_MAXP][FR_SPAN];
+    __shared__ float wxq[FR_WIDTH + FR_INFLIGHT][8];             // [footprint column][bin column]: one 32-byte broadcast per pixel
+    __shared__ float wxb[RB_MAXP][FR_SPAN];
+    __shared__ int oy[RB_MAXP], ny[RB_MAXP], ox[RB_MAXP], nx[RB_MAXP];
+    __shared__ int overflow;
+    const int k = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const RoiGeom g = roi_geom(rois + (size_t)k * 5, p, PH, PW, sampling_ratio, aligned);
+    const int H = p.H[g.lvl], W = p.W[g.lvl], C = p.C;
+    const bool bad_batch = g.batch < 0 || g.batch >= p.N;
+    if (PH > RB_MAXP || PW > RB_MAXP || PW > 7 || bad_batch) {       // (7 column accumulators in registers)
+        roi_fwd_samples<T>(p, g, k, PH, PW, out);
+        return;
+    }
+    if (tid == 0) overflow = 0;
+    for (int i = tid; i < (FR_WIDTH + FR_INFLIGHT) * 8; i += 256) (&wxq[0][0])[i] = 0.f;
+    __syncthreads();
+    if (tid < PH) {
+        if (!axis_table_n(g.start_h, g.bin_h, g.grid_h, tid, H, wy[tid], FR_SPAN, &oy[tid], &ny[tid])) overflow = 1;
+    } else if (tid >= 64 && tid < 64 + PW) {
+        const int b = tid - 64;
+        if (!axis_table_n(g.start_w, g.bin_w, g.grid_w, b, W, wxb[b], FR_SPAN, &ox[b], &nx[b])) overflow = 1;
+    }
+    __syncthreads();
+    int X0 = 1 << 30, X1 = -1;
+    for (int b = 0; b < PW; ++b)
+        if (nx[b] > 0) { X0 = min(X0, ox[b]); X1 = max(X1, ox[b] + nx[b]); }
+    const int FW = X1 - X0;
+    if (overflow || FW > FR_WIDTH) {
+        roi_fwd_samples<T>(p, g, k, PH, PW, out);
+        return;
+    }
+    if (tid >= 64 && tid < 64 + PW) {
+        const int b = tid - 64;
+        for (int j = 0; j < nx[b]; ++j) wxq[ox[b] - X0 + j][b] = wxb[b][j];
+    }
+    __syncthreads();
+    const T* base = reinterpret_cast<const T*>(p.feat[g.lvl]) + (size_t)g.batch * H * W * C;
+    const float inv = 1.0f / g.count;
+    // a wave owns bin rows ph = w, w + 4; lane = 4 channels.  The column loop keeps FR_INFLIGHT pixel loads in flight (one load per
+    // trip left the wave waiting a full L2 latency per pixel: ~900 cycles per trip at 16 waves per CU)
+    for (int ph = wave; ph < PH; ph += 4) {
+        const int r0 = oy[ph], nr = ny[ph];
+        for (int c0 = blockIdx.y * 256 + lane * 4; c0 < min(C, (int)(blockIdx.y + 1) * 256); c0 += 256) {
+            f32x4 acc[7];
+#pragma unroll
+            for (int b = 0; b < 7; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int jr = 0; jr < nr; ++jr) {
+                const float wyv = wy[ph][jr];
+                if (wyv == 0.f) continue;
+                f32x4 t[7];
+#pragma unroll
+                for (int b = 0; b < 7; ++b) t[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const T* row = base + ((size_t)(r0 + jr) * W + X0) * C + c0;
+                for (int q0 = 0; q0 < FW; q0 += FR_INFLIGHT) {
+                    f32x4 v[FR_INFLIGHT];
+#pragma unroll
+                    for (int u = 0; u < FR_INFLIGHT; ++u)       // (columns past the footprint: re-read the last one, its weights are zero)
+                        v[u] = load4(row + (size_t)min(q0 + u, FW - 1) * C);
+#pragma unroll
+                    for (int u = 0; u < FR_INFLIGHT; ++u) {
+                        const int q = q0 + u;     // wxq has FR_WIDTH + FR_INFLIGHT rows: rows >= FW are zero
+                        const f32x4 wa = *reinterpret_cast<const f32x4*>(&wxq[q][0]);
+                        const f32x4 wb = *reinterpret_cast<const f32x4*>(&wxq[q][4]);
+                        t[0] += wa[0] * v[u]; t[1] += wa[1] * v[u]; t[2] += wa[2] * v[u]; t[3] += wa[3] * v[u];
+                        t[4] += wb[0] * v[u]; t[5] += wb[1] * v[u]; t[6] += wb[2] * v[u];
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 7; ++b) acc[b] += wyv * t[b];
+            }
+#pragma unroll
+            for (int b = 0; b < 7; ++b)
+                if (b < PW) store4(out + ((size_t)k * PH * PW + ph * PW + b) * C + c0, acc[b] * inv);
+        }
+    }
 }
 
 template <typename T>
@@ -529,8 +663,9 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
                                            __builtin_amdgcn_readfirstlane(tn.qlo), __builtin_amdgcn_readfirstlane(tn.qhi));
                             }
                             if (plo >= phi || qlo >= qhi) continue;
-                            // lane j of WY / WX holds table entry j ([bin][row / column], 8 x 8 floats each)
-                            const float WY = (&tb.wy[0][0])[lane], WX = (&tb.wx[0][0])[lane];
+                            // (round 5: the weights come as 16-byte LDS broadcasts - 4 column weights / 8 row weights per read -
+                            //  instead of one v_readlane per weight: 96 -> 24 weight fetches per 4 x 4 bin block, off the
+                            //  VALU; same values, same order of operations: bit-identical gradients)
                             for (int pb = plo; pb < phi; pb += 4)
                                 for (int qb = qlo; qb < qhi; qb += 4) {
                                     if (pb != plo || qb != qlo) load_block(cur, kk, pb, phi, qb, qhi);    // (rare: > 4 bins on a tile)
@@ -541,15 +676,17 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
 #pragma unroll
                                         for (int j = 0; j < 4; ++j) {
                                             if (qb + j >= qhi) continue;
+                                            const f32x4 wxv = *reinterpret_cast<const f32x4*>(&tb.wx[qb + j][xh * 4]);
 #pragma unroll
-                                            for (int x = 0; x < TILE / 2; ++x)
-                                                T[x] += lane_f(WX, (qb + j) * TILE + xh * 4 + x) * cur[i][j];
+                                            for (int x = 0; x < TILE / 2; ++x) T[x] += wxv[x] * cur[i][j];
                                         }
 #pragma unroll
-                                        for (int y = 0; y < TILE; ++y) {
-                                            const float wyv = lane_f(WY, (pb + i) * TILE + y);
+                                        for (int yh = 0; yh < 2; ++yh) {
+                                            const f32x4 wyv = *reinterpret_cast<const f32x4*>(&tb.wy[pb + i][yh * 4]);
 #pragma unroll
-                                            for (int x = 0; x < TILE / 2; ++x) acc[y][x] += wyv * T[x];
+                                            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                                                for (int x = 0; x < TILE / 2; ++x) acc[yh * 4 + y][x] += wyv[y] * T[x];
                                         }
                                     }
                                 }
@@ -661,11 +798,19 @@ int oadg_roi_align_fwd(const void* const* feats, const int* heights, const int* 
     p.order = order;
     if (K == 0) return OADG_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0)
-        hipLaunchKernelGGL((roi_align_fwd_kernel<float>), dim3(K, (C + 255) / 256), dim3(256), 0, st, p, rois, K, PH, PW,
+    static const bool rows = !(getenv("OADG_ROI_FWD_ROWS") && getenv("OADG_ROI_FWD_ROWS")[0] == '0');     // (A/B probes)
+    const dim3 grid(K, (C + 255) / 256);
+    if (rows && dtype == 0)
+        hipLaunchKernelGGL((roi_align_fwd_rows_kernel<float>), grid, dim3(256), 0, st, p, rois, K, PH, PW, sampling_ratio,
+                           aligned, (float*)out);
+    else if (rows)
+        hipLaunchKernelGGL((roi_align_fwd_rows_kernel<unsigned short>), grid, dim3(256), 0, st, p, rois, K, PH, PW,
+                           sampling_ratio, aligned, (unsigned short*)out);
+    else if (dtype == 0)
+        hipLaunchKernelGGL((roi_align_fwd_kernel<float>), grid, dim3(256), 0, st, p, rois, K, PH, PW,
                            sampling_ratio, aligned, (float*)out);
     else
-        hipLaunchKernelGGL((roi_align_fwd_kernel<unsigned short>), dim3(K, (C + 255) / 256), dim3(256), 0, st, p, rois, K,
+        hipLaunchKernelGGL((roi_align_fwd_kernel<unsigned short>), grid, dim3(256), 0, st, p, rois, K,
                            PH, PW, sampling_ratio, aligned, (unsigned short*)out);
     OADG_LAUNCH_CHECK();
     return OADG_OK;

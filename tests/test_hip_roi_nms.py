@@ -45,6 +45,28 @@ def test_roi_align_fpn_fwd_bwd_fp32(dev, C):
         assert e <= 1e-4 * bg.abs().max().item() + 1e-6, e
 
 
+@pytest.mark.parametrize('C', [64, 256, 512])
+def test_roi_align_forward_by_rows_and_its_per_sample_fallback(dev, C):
+    """the footprint-row forward kernel (round 5) against the oracle on one stride-1 level where some RoIs have bins wider
+    than its 32-pixel weight tables (those workgroups take the per-sample form), RoIs hanging over every border, tiny RoIs
+    (several bins per pixel) and a 512-channel map (two channel chunks on blockIdx.y) - fp32, 1e-4"""
+    from oadg_amd import hip_ops
+    rs = np.random.RandomState(C)
+    H, W = 300, 420
+    f = torch.tensor(rs.standard_normal((2, C, H, W)).astype(np.float32))
+    rois = np.array([[0, 10, 10, 410, 290],          # 57 x 40 pixel bins: fallback
+                     [1, 5, 5, 250, 120],            # 35-pixel bin columns: fallback (columns only)
+                     [0, 20, 30, 200, 190],          # 25-pixel bins: table path
+                     [1, 100.3, 50.7, 103.1, 52.2],  # tiny: several bins per pixel
+                     [0, -40, -30, 60, 50], [1, 380, 260, 470, 340], [0, -3, 100, 2, 180],
+                     [1, 50, 60, 50, 60], [0, 419, 299, 419.5, 299.5]], np.float32)
+    rois = np.concatenate([rois, _rand_rois(rs, 24, 2, W, H, big=True)])
+    oc = ORA.roi_align(f, torch.tensor(rois), 7, 1.0)
+    og = hip_ops.roi_align_fpn([f.to(dev)], torch.tensor(rois, device=dev), 7, [1.0])
+    err = (og.cpu() - oc).abs().max().item()
+    assert err <= 1e-4 * oc.abs().max().item(), err
+
+
 def test_roi_align_single_level_bf16(dev):
     from oadg_amd import hip_ops
     rs = np.random.RandomState(5)
