@@ -429,13 +429,28 @@ class TrainEngine:
             t.record_stream(caller)
         return out
 
+    def _foreign_grad_hooks(self):
+        """Deferred weight gradients / column sums hand AccumulateGrad tensors that are FILLED LATER (hip_conv.flush_deferred):
+        a tensor hook or post-accumulate hook of someone else's would read them too early.  With such a hook on
+        any parameter the step runs its gradient launches immediately; the data-parallel reducer's own hooks flush first."""
+        ours = set(id(h) for h in ())
+        if self.reducer is not None:
+            ours = {h.id for h in self.reducer._hooks}
+        for p in self.module.parameters():
+            if p._backward_hooks:
+                return True
+            post = getattr(p, '_post_accumulate_grad_hooks', None)
+            if post and any(k not in ours for k in post):
+                return True
+        return False
+
     def _forward_backward(self, data, speculate):
         """zero_grad + forward + backward (+ gradient average); returns (loss, log_vars, n, speculation records)"""
         from . import hip_conv
         from .core import bbox as _bbox
         self.optimizer.zero_grad(set_to_none=True)
         # (torch DDP copies gradients into its buckets from autograd hooks: nothing may be pending there)
-        hip_conv.begin_step(defer=self.amp_dtype is torch.bfloat16 and self.ddp is None)
+        hip_conv.begin_step(defer=self.amp_dtype is torch.bfloat16 and self.ddp is None and not self._foreign_grad_hooks())
         if speculate:
             _bbox.begin_speculation()
         try:

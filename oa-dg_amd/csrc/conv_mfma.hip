@@ -1010,7 +1010,12 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
                                (hipStream_t)stream, a);
     } else {
         const long m_tiles = (a.M + BM - 1) / BM;
-        const int tbn = K % BN == 0 ? BN : 64;
+        // 128 x 64 tiles also where 128 x 128 tiles would leave compute units without a workgroup (R101-DC5's 46 x 80 maps:
+        // 115 pixel tiles x K / 128 = 230 workgroups of one wave per SIMD each; P5 / P6 of the FPN): twice the workgroups, the
+        // same products in the same order (bit-identical).  OADG_CONV_TBN64_MAX (A/B probes): the largest 128-tile
+        // workgroup count that still takes the narrow tile (default 256; 0 = off).
+        static const long tbn64_max = getenv("OADG_CONV_TBN64_MAX") ? atol(getenv("OADG_CONV_TBN64_MAX")) : 256;
+        const int tbn = (K % BN == 0 && m_tiles * (K / BN) > tbn64_max) ? BN : 64;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / tbn);     // 8 equal XCD ranges (the kernel drops the padding)
         if (blocks > 0x7fffffffL) return OADG_EARG;
         const bool one = variant == 3;

@@ -227,7 +227,14 @@ class _TableStage:
             st = self.dev[device] = ([torch.empty(n, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)],
                                      [torch.empty(n, dtype=torch.uint8, device=device) for _ in range(self.SLOTS)], [0],
                                      [None] * self.SLOTS)
-        k = st[2][0] = (st[2][0] + 1) % self.SLOTS
+        k = st[2][0] = (st[2][0] + 1) % len(st[0])
+        if st[3][k] is not None and not st[3][k].query():
+            # the copy issued from this slot one lap ago is still queued (behind the backward kernels of THIS pass): take a
+            # new slot instead of stalling the host's run-ahead on it
+            n = st[0][0].numel()
+            st[0].insert(k, torch.empty(n, dtype=torch.uint8).pin_memory())
+            st[1].insert(k, torch.empty(n, dtype=torch.uint8, device=device))
+            st[3].insert(k, None)
         pin, tdev = st[0][k], st[1][k]
         if st[3][k] is not None:
             st[3][k].synchronize()
@@ -1263,6 +1270,10 @@ def frozen_bottleneck(x, block):
         if c.bias is not None or st != (1, 1) or dl != (1, 1) or pd != ((1, 1) if c is c2 else (0, 0)):
             return None
     if any(bn.training for bn in bns) or any(p.requires_grad for m in convs + bns for p in m.parameters()):
+        return None
+    # the fused launch bypasses the inner modules' forward(): a block whose convolutions / norms carry forward hooks
+    # (feature taps, quantisation observers) runs them one by one.  OADG_FUSED_FROZEN_BLOCK=0: never fused.
+    if any(m._forward_hooks or m._forward_pre_hooks for m in convs + bns + [block.relu]):
         return None
     prep = [prepared(c.weight, bn, None, 0, c) for c, bn in zip(convs, bns)]
     x16 = _nhwc_bf16(x)

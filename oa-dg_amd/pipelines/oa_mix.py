@@ -437,7 +437,13 @@ class OAMix:
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
                      luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
                      gray=torch.empty((1,), dtype=torch.int64, device=dev))
-            while len(self._bufs) >= 16:         # per-sample multi-scale: a new shape per image; keep the latest few
+            # bounded by BYTES: a set is 30 bytes per pixel (six uint8 images + the fp32 accumulator = 63 MB at
+            # 1024 x 2048); per-sample multi-scale brings a new shape per image, so the oldest sets go once the cache
+            # holds more than OADG_OAMIX_CACHE_MB (default 768: twelve full-size sets - the lockstep pass of a batch of
+            # eight plus headroom).  A set still referenced by recorded commands stays alive through their closures.
+            b['bytes'] = 30 * H * W
+            limit = int(os.environ.get('OADG_OAMIX_CACHE_MB', 768)) << 20
+            while self._bufs and sum(v['bytes'] for v in self._bufs.values()) + b['bytes'] > limit:
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[key] = b
         return b

@@ -285,7 +285,7 @@ def test_r101_dc5_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypat
     (loss_cls: 2 of 2048 sampled RoIs flip), acc 5.7e-4, gradient norms <= 2.1e-2, labels 99.9 %."""
     # (round 4: with the frozen stage-1 blocks fused into one launch the bf16 rounding pattern of their outputs changed and
     #  `acc` - an argmax over near-tied random-init logits, see the R50 test above - moved from 5.7e-4 to 1.0e-2)
-    tol = (5e-2, 5e-2, 6e-2, 0.998) if bf16 else (1e-4, 1e-3, 3e-4, 0.999)
+    tol = (5e-2, 2e-2, 6e-2, 0.998) if bf16 else (1e-4, 1e-3, 3e-4, 0.999)       # (acc gate 2e-2 for a measured 1.0e-2: ADVICE r4)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_dc5_384x768.npz', DC5_CFG, bf16, *tol, monkeypatch)
 
 
