@@ -92,15 +92,41 @@ def end_backward():
     """TrainEngine: the backward pass has been enqueued - run what was deferred, stop deferring"""
     global DEFER_COLSUM, DEFER_WGRAD
     DEFER_COLSUM = DEFER_WGRAD = False
-    return flush_deferred()
+    return flush_deferred(final=True)
 
 
-def flush_deferred():
+def flush_deferred(final=False):
     """everything a backward pass has deferred so far, on the current stream: the grouped weight gradients first (their
     consumer leaves raw BN-scale dot products that the column-sum launch finishes), then the column sums.  Called at the
-    end of the backward pass and before a data-parallel gradient bucket is packed."""
+    end of the backward pass (``final``) and before a data-parallel gradient bucket is packed."""
+    if final and _SHARED_OPEN:
+        _close_shared_leftovers()
     n = flush_wgrads()
     return n + flush_colsums()
+
+
+def _close_shared_leftovers():
+    """a shared weight some of whose expected uses never reached _PrepWeights.backward (a level without a gradient): the
+    jobs that did arrive returned no gradient, so their sum is added to the parameter's gradient here"""
+    global _WQ_WORK
+    for ent in list(_SHARED_OPEN):
+        jobs, ent.shared = ent.shared, []
+        if not jobs:
+            continue
+        w = ent.src[0]
+        leader = jobs[0]
+        K, C, R, S = leader.geo[4], leader.geo[3], leader.geo[5], leader.geo[6]
+        wd = w.detach()
+        krsc = int(R * S > 1 and not wd.is_contiguous() and wd.is_contiguous(memory_format=torch.channels_last))
+        dw = torch.empty_like(wd)
+        leader.prep = (None, wd, None, None, None, 0.0, krsc, dw, None)
+        leader.members = len(jobs)
+        for j in jobs:
+            _WQ.append(j)
+            _WQ_WORK += j.work
+        flush_wgrads()
+        w.grad = dw if w.grad is None else w.grad + dw
+    _SHARED_OPEN.clear()
 
 
 _CS_JOB = np.dtype([('part', np.uint64), ('out', np.uint64), ('dgamma', np.uint64), ('mean', np.uint64),
@@ -201,6 +227,8 @@ WGRAD_SMALL = int(os.environ.get('OADG_WGRAD_SMALL', 40000))        # weight til
 WGRAD_GROUP = int(os.environ.get('OADG_WGRAD_GROUP', 65536))        # ... and the sum at which a group is launched
 _WQ = []
 _WQ_WORK = 0
+SHARED_GROUP = os.environ.get('OADG_WGRAD_SHARED', '1') == '1'      # the uses of a shared weight as ONE grouped launch
+_SHARED_OPEN = set()        # bank entries holding jobs of a shared weight whose last use has not arrived yet
 _WG_JOB = np.dtype([('x', 'u8'), ('dy', 'u8'), ('part', 'u8'), ('P', 'i8'), ('N', 'i4'), ('H', 'i4'), ('W', 'i4'),
                     ('C', 'i4'), ('K', 'i4'), ('R', 'i4'), ('S', 'i4'), ('stride', 'i4'), ('pad', 'i4'), ('dil', 'i4'),
                     ('Ho', 'i4'), ('Wo', 'i4'), ('splits', 'i4'), ('cps', 'i4'), ('first_block', 'i4'),
@@ -258,7 +286,7 @@ def wgrad_work(N, Ho, Wo, C, K, R, S):
 class _WgradJob:
     """one deferred weight gradient: the operands (kept alive), its geometry and - once _PrepWeights.backward has run -
     the consumer's operands and the aliases of the tensors that went up the graph"""
-    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets')
+    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets', 'members')
 
     def __init__(self, x16, gy16, K, R, S, stride, pad, dil):
         N, C, H, W = x16.shape
@@ -266,18 +294,20 @@ class _WgradJob:
         self.geo = (N, H, W, C, K, R, S, stride, pad, dil)
         self.work = wgrad_work(N, gy16.shape[2], gy16.shape[3], C, K, R, S)
         self.prep, self.targets = None, []
+        self.members = 1            # > 1: the leader of a shared-weight set - the next members - 1 jobs of the queue are uses
+                                    # of the same weight whose partials its consumer sums with its own (prep None on them)
 
 
 class _PartsJob:
     """a weight gradient whose split partials already exist (a single-layer launch): only its CONSUMER (BN-fold chain rule,
     layout change, sum over the splits) waits for the group's consumer launch"""
-    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets', 'parts', 'splits')
+    __slots__ = ('x', 'gy', 'geo', 'work', 'prep', 'targets', 'parts', 'splits', 'members')
 
     def __init__(self, parts, splits, K, C, R, S):
         self.x = self.gy = None
         self.geo = (0, 0, 0, C, K, R, S, 1, 0, 1)
         self.work, self.parts, self.splits = 0, parts, int(splits)
-        self.prep, self.targets = None, []
+        self.prep, self.targets, self.members = None, [], 1
 
 
 _GROUP_TRACE = {} if os.environ.get('OADG_BENCH_DIAG_CONV') == '1' else None
@@ -336,15 +366,26 @@ def flush_wgrads():
     if not jobs:
         return 0
     L = _lib.lib()
-    dev = jobs[0].prep[1].device
+    dev = next(j.prep[1].device for j in jobs if j.prep is not None)
     launch = [j for j in jobs if j.x is not None]
     ws, parts = wgrad_multi([(j.x, j.gy) + j.geo[4:] for j in launch]) if launch else (None, [])
     parts = iter(parts)
     parts = [next(parts) if j.x is not None else (j.parts.data_ptr(), j.splits) for j in jobs]
-    tab = np.zeros(len(jobs), dtype=_PB_JOB)
+    # consumer jobs: one per queue entry that has consumer operands; the leader of a shared-weight set takes the partials of
+    # its members too (they follow it in the queue, hence in the workspace: one array of sum(splits) tiles)
+    cons = []
+    for i, j in enumerate(jobs):
+        if j.prep is None:
+            continue
+        pp, splits = parts[i]
+        for m in range(1, j.members):
+            assert jobs[i + m].prep is None and jobs[i + m].geo[3:7] == j.geo[3:7]
+            splits += parts[i + m][1]
+        cons.append((j, pp, splits))
+    tab = np.zeros(len(cons), dtype=_PB_JOB)
     first, max_crs = 0, 0
     p_ = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
-    for r, j, (pp, splits) in zip(tab, jobs, parts):
+    for r, (j, pp, splits) in zip(tab, cons):
         gb, w, scale, mean, var, eps, flags, dw, dgamma = j.prep
         K, C, R, S = j.geo[4], j.geo[3], j.geo[5], j.geo[6]
         r['part'], r['gbias'], r['w'], r['scale'], r['mean'], r['var'] = pp, p_(gb), p_(w), p_(scale), p_(mean), p_(var)
@@ -353,7 +394,7 @@ def flush_wgrads():
         first += K
         max_crs = max(max_crs, C * R * S)
     tdev = _TABLES.upload(tab, dev)
-    check(L.oadg_prep_conv_weights_bwd_parts_multi(ptr(tdev), len(jobs), first, max_crs, stream_ptr()),
+    check(L.oadg_prep_conv_weights_bwd_parts_multi(ptr(tdev), len(cons), first, max_crs, stream_ptr()),
           'oadg_prep_conv_weights_bwd_parts_multi')
     for j in jobs:
         for prm, alias in j.targets:
@@ -542,11 +583,12 @@ class WeightGradToken:
     """Hand-off of a weight gradient from the convolution's backward to the backward of its weight preparation
     (one prepared weight <-> one convolution call; weights used by several calls, e.g. the RPN conv shared by the
     pyramid levels, take the reduced path because autograd has to add their gradients)."""
-    __slots__ = ('uses', 'parts', 'deferrable')
+    __slots__ = ('uses', 'parts', 'deferrable', 'entry')
 
     def __init__(self):
         self.uses, self.parts = 0, None
         self.deferrable = False      # the gradients of this preparation go straight to AccumulateGrad of bank parameters
+        self.entry = None            # the bank entry of the prepared weight (shared-weight groups, _PrepWeights.backward)
 
 
 _ZERO_SCALARS = {}
@@ -665,6 +707,7 @@ class _PrepWeights(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gwf, gbias, _gwt):
+        global _WQ_WORK
         w, scale, mean, var = ctx.saved_tensors
         eps, has_bn, has_bias_in, K, C, R, S, krsc = ctx.cfg
         L = _lib.lib()
@@ -685,7 +728,35 @@ class _PrepWeights(torch.autograd.Function):
         parts = None
         if tok is not None and tok.parts is not None:
             parts, tok.parts = tok.parts, None
-        if gwf is not None and isinstance(parts, _WgradJob):
+        if gwf is not None and isinstance(parts, _WgradJob) and ent is not None and ent.count > 1 and SHARED_GROUP and \
+                DEFER_WGRAD and ctx.leaf_inputs and not has_bn and ent.step == _STEP and ent.expect_step == _STEP and \
+                ent.expect_jobs > 1 and len(ent.shared) < ent.expect_jobs:
+            # Round 5: a weight SHARED by several convolutions of the step (the RPN convolution: one weight, five pyramid
+            # levels).  Its uses were launched one by one - autograd has to add their gradients - as single-job groups of a
+            # few K-tiles per workgroup (4 launches, 0.49 ms at 845 TFLOP/s, + 4 consumer launches + 4 accumulation adds).
+            # Now the uses' jobs wait on the bank entry; the LAST one puts them into the queue side by side: they run inside
+            # one grouped launch, their split partials lie back to back in the group's workspace - the same [K][R*S][C] tiles
+            # at the same stride - so ONE consumer job sums them as the splits of a single layer and returns the weight's
+            # whole small-map gradient; the earlier uses return no gradient at all.  (The P2 use is a launch of its own,
+            # its gradient is added by autograd as before.)
+            job = parts
+            ent.shared.append(job)
+            if len(ent.shared) < ent.expect_jobs:
+                job.prep = None                      # a member: launched and consumed with the group's last job
+                _SHARED_OPEN.add(ent)
+            else:
+                dw = torch.empty_like(w)
+                leader = ent.shared[0]
+                job.prep = None
+                leader.prep = (None, w, scale, mean, var, eps, int(krsc) | raw, dw.detach(), None)
+                leader.members = len(ent.shared)
+                for j_ in ent.shared:
+                    _WQ.append(j_)
+                    _WQ_WORK += j_.work
+                ent.shared = []
+                _SHARED_OPEN.discard(ent)
+                flush_wgrads()       # now: autograd ADDS this gradient to the other uses' (it is read right away)
+        elif gwf is not None and isinstance(parts, _WgradJob):
             # a small layer inside TrainEngine's backward: its weight gradient joins the current group
             dw, dgamma = _wgrad_dest(ctx, w, K, has_bn)
             job = parts
@@ -697,7 +768,6 @@ class _PrepWeights(torch.autograd.Function):
                 job.targets.append((ent.src[0], job.prep[7]))
                 if dgamma is not None:
                     job.targets.append((ent.src[1], job.prep[8]))
-            global _WQ_WORK
             _WQ.append(job)
             _WQ_WORK += job.work
             if not defer or _WQ_WORK >= WGRAD_GROUP:
@@ -760,12 +830,13 @@ class _BankEntry:
     """The prepared tensors of one trainable convolution, kept across steps (weights change only in optimizer.step()):
     ``valid`` while the version counters of the source parameters are the ones the tensors were prepared from."""
     __slots__ = ('src', 'versions', 'args', 'wf', 'wt', 'bias', 'scale', 'mean', 'var', 'want_wt', 'step', 'count',
-                 '__weakref__')
+                 'expect_jobs', 'expect_step', 'shared', '__weakref__')
 
     def __init__(self, src, want_wt):
         self.src, self.want_wt = src, int(want_wt)           # src: the tensors whose versions define validity
         self.versions = None
         self.step, self.count = -1, 0
+        self.expect_jobs, self.expect_step, self.shared = 0, -1, []     # shared-weight weight-gradient group (below)
         self.wf = self.wt = self.bias = self.scale = self.mean = self.var = self.args = None
 
     def current_versions(self):
@@ -888,6 +959,7 @@ def prepared(conv_weight, bn, bias_in, want_wt, cache_on=None):
             cache_on._oadg_prep_entry = entry
     if tok is not None:
         tok.deferrable = entry is not None
+        tok.entry = entry
     if bn is not None:
         out = _PrepWeights.apply(conv_weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, None,
                                  want_wt, tok, entry)
@@ -964,6 +1036,17 @@ class _Conv2dMFMA(torch.autograd.Function):
         ctx.wtoken = getattr(wf, '_oadg_wtoken', None)
         if ctx.wtoken is not None:
             ctx.wtoken.uses += 1
+            ent = ctx.wtoken.entry
+            if ent is not None and DEFER_WGRAD and SHARED_GROUP:
+                # (a weight used by several convolutions of a step - the RPN convolution on every pyramid level: how many of
+                #  its uses will hand a deferred job to _PrepWeights.backward; the predicate of _Conv2dMFMA.backward)
+                K_, C_, R_, S_ = wf.shape
+                work = wgrad_work(y.shape[0], y.shape[2], y.shape[3], C_, K_, R_, S_)
+                if ent.expect_step != _STEP:
+                    ent.expect_step, ent.expect_jobs, ent.shared = _STEP, 0, []
+                if ctx.wtoken.deferrable and 0 < work < WGRAD_SMALL and C_ * R_ * S_ <= 36000 and x16.numel() < 2 ** 32 and \
+                        _hip_wgrad(K_, C_, R_, y.shape[0] * y.shape[2] * y.shape[3]):
+                    ent.expect_jobs += 1
         return y
 
     @staticmethod

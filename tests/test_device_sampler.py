@@ -206,3 +206,47 @@ def test_a_short_image_repeats_the_step_on_the_host_path(dev, monkeypatch):
             assert torch.equal(x, y)
     finally:
         hip_conv.enable(False)
+
+
+@pytest.mark.gpu
+def test_shared_rpn_convolution_weight_gradient_as_one_group(dev, monkeypatch):
+    """hip_conv.SHARED_GROUP (round 5): the weight gradients of the RPN convolution on P3 ... P6 - one weight, one use per
+    pyramid level - run as ONE grouped launch whose consumer sums all their split partials, instead of four single-job
+    launches added by autograd.  Same gradient to fp32 rounding (another summation order), same training step."""
+    import copy
+    from oadg_amd import hip_conv
+    from oadg_amd.apis import set_random_seed
+    from oadg_amd.pipelines import DevicePipeline, SyntheticCityscapes
+    cfg, det, eng = _engine(dev)
+    try:
+        ds = SyntheticCityscapes(img_shape=(512, 1024), num_boxes=12, num_classes=8, box_size=(16, 200), seed=0, device=dev)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.bfloat16)
+        set_random_seed(5)
+        batch = pipe(*ds.batch([0, 1]))
+        state0 = copy.deepcopy(det.state_dict())
+        opt0 = copy.deepcopy(eng.optimizer.state_dict())
+        grads, groups = {}, {}
+        orig = hip_conv.wgrad_multi
+        for mode in (True, False):
+            det.load_state_dict(state0)
+            eng.optimizer.load_state_dict(copy.deepcopy(opt0))
+            hip_conv.refresh_prepared()
+            monkeypatch.setattr(hip_conv, 'SHARED_GROUP', mode)
+            sizes = []
+            monkeypatch.setattr(hip_conv, 'wgrad_multi', lambda jobs, *a, **k: (sizes.append(len(jobs)), orig(jobs, *a, **k))[1])
+            set_random_seed(11)
+            captured = {}
+            h = det.rpn_head.rpn_conv.weight.register_hook(lambda g: None)      # (a tensor hook would switch deferral off:
+            h.remove()                                                          #  make sure none is left)
+            eng.step({k: (list(v) if isinstance(v, list) else v) for k, v in batch.items()})
+            torch.cuda.synchronize()
+            grads[mode] = {n: p.grad.detach().float().clone() for n, p in det.rpn_head.named_parameters()}
+            grads[mode]['layer3'] = det.backbone.layer3[0].conv1.weight.grad.detach().float().clone()
+            groups[mode] = sizes
+        assert len(groups[True]) < len(groups[False]), (groups[True], groups[False])       # fewer grouped launches
+        assert sum(groups[True]) == sum(groups[False])                                      # the same jobs
+        for n in grads[True]:
+            a, b = grads[True][n], grads[False][n]
+            assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-9, n
+    finally:
+        hip_conv.enable(False)
