@@ -699,6 +699,23 @@ int oadg_roi_sample_device(const oadg_roi_sample_image* images_host, int B, int 
                            uint32_t* mt_state, int64_t* sel, int* counts, int* flags, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fp32 convolution on the fp32 matrix cores (exact fp32 FMA chains) - the fp32 PARITY path (csrc/conv_f32.hip)
+ *   serves the cuDNN convolutions of mmdet/models/backbones/resnet.py:263-302, necks/fpn.py:112-129,
+ *          dense_heads/rpn_head.py:54-68 when the model runs in fp32 (the reference's training precision)
+ * x [N][H][W][C] fp32 NHWC, C % 4 == 0; w [K][R][S][C]; bias [K] or NULL; y [N][Ho][Wo][K].  transposed = 0: the forward
+ * convolution (out_h / out_w ignored).  transposed = 1: the data gradient of a convolution with this stride / pad / dil -
+ * x is dy [N][H][W][C] (C = the forward convolution's output channels), w is [K][R][S][C] with K = the forward
+ * convolution's INPUT channels (= the forward weight [C][R][S][K] transposed), y = dx [N][out_h][out_w][K]. */
+int oadg_conv2d_f32(const float* x, const float* w, const float* bias, float* y, const void* zeros16, int N, int H, int W,
+                    int C, int K, int R, int S, int stride, int pad, int dil, int transposed, int out_h, int out_w,
+                    void* stream);
+/* dw [K][R][S][C] fp32 = sum over output pixels of dy[p][k] * x[p @ tap][c]; workspace: oadg_conv2d_wgrad_f32_splits(...)
+ * * K*R*S*C floats (fp32 split partials summed in split order: deterministic).  Any C, K. */
+int oadg_conv2d_wgrad_f32_splits(int N, int Ho, int Wo, int C, int K, int R, int S);
+int oadg_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* workspace, size_t workspace_bytes, int N, int H,
+                          int W, int C, int K, int R, int S, int stride, int pad, int dil, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host helper (no device work): first k entries of ATen's CPU randperm(n) replayed on the MT19937 state
  *   serves RandomSampler.random_choice   mmdet/core/bbox/samplers/random_sampler.py:58
  * state624/left/next are the generator's engine words (in/out); out [k] int64.

@@ -143,6 +143,9 @@ SIGNATURES = {
     'oadg_roi_targets_dev': (ci, [vp, ci, ci, ci, vp, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_roi_sample_max_rows': (ci, []),
     'oadg_roi_sample_device': (ci, [vp, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
+    'oadg_conv2d_f32': (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
+    'oadg_conv2d_wgrad_f32_splits': (ci, [ci, ci, ci, ci, ci, ci, ci]),
+    'oadg_conv2d_wgrad_f32': (ci, [vp, vp, vp, vp, cs, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),

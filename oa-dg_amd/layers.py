@@ -24,7 +24,13 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1, relu=False, re
         y = _CONV_IMPL(x, weight, bias, stride, padding, dilation, relu, residual, **tokens)
         if y is not None:
             return y
-    y = F.conv2d(x, weight, bias, stride, padding, dilation)
+    y = None
+    if x.is_cuda and x.dtype == torch.float32:
+        # the fp32 parity path: csrc/conv_f32.hip (fp32 MFMA) - no library convolution on either path (round 5)
+        from .hip_conv_f32 import conv2d_f32
+        y = conv2d_f32(x, weight, bias, stride, padding, dilation)
+    if y is None:
+        y = F.conv2d(x, weight, bias, stride, padding, dilation)
     if residual is not None:
         y = y + residual
     return F.relu(y, inplace=True) if relu else y
