@@ -217,3 +217,26 @@ def test_bench_two_ranks_through_its_own_launch_path_on_gloo():
     assert d['config']['cpu_affinity'].startswith(f'{ncores // 2} of {ncores} cores per rank (rank 0: ')
     assert d['config']['param_tensors_changed'] == d['config']['param_tensors'] > 100
     assert np.isfinite(d['config']['final_loss']) and d['value'] > 0
+
+
+def test_bench_workloads_and_clock_sampler_without_a_gpu(monkeypatch):
+    """bench.py's --config / --workload table names BASELINE configs 2, 4 and 5 with their per-GPU sizes, and the clock
+    sampler degrades to {'available': False} (never an exception) where amdsmi cannot reach a device"""
+    spec = importlib.util.spec_from_file_location('oadg_bench2', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.CONFIGS) == {'r50_fpn', 'r101_dc5'}
+    for k, c in bench.CONFIGS.items():
+        assert os.path.exists(os.path.join(ROOT, 'configs', 'oadg', c['cfg'])), k
+    assert (bench.CONFIGS['r50_fpn']['batch'], bench.CONFIGS['r50_fpn']['height'], bench.CONFIGS['r50_fpn']['width']) == (4, 1024, 2048)
+    assert (bench.CONFIGS['r101_dc5']['batch'], bench.CONFIGS['r101_dc5']['height'], bench.CONFIGS['r101_dc5']['width']) == (2, 736, 1280)
+    assert bench.CONFIGS['r101_dc5']['roi_strides'] == [16] and bench.CONFIGS['r101_dc5']['roi_channels'] == 2048
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'oamix_stress'])
+    a = bench.parse()
+    assert (a.batch, a.height, a.width) == (8, 1024, 2048)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'r101_dc5'])
+    a = bench.parse()
+    assert (a.batch, a.height, a.width, a.workload) == (2, 736, 1280, 'train')
+    s = bench.ClockSampler(0).start().stop()
+    assert s['available'] in (True, False) and ('sclk_mhz' in s or 'note' in s)
+    assert bench.pin_rank_to_cores(0, 1) is None
