@@ -286,7 +286,7 @@ def families_table(conv_timers, op_timers, roi_sets, steps, elem, geom=None, roi
         if rows and rois_bytes[key]:
             ms = sum(r[0] for r in rows)
             by = sum(rois_bytes[key]) / len(rois_bytes[key]) * len(rows)
-            kname = bwd_kernel if key == 'roi_align_bwd' else key + '_kernel'
+            kname = bwd_kernel if key == 'roi_align_bwd' else 'roi_align_fwd_rows_kernel'
             e = {'family': title, 'kernels': [kname], 'bound': 'hbm', 'launches_per_step': round(len(rows) / steps, 1),
                  'ms_per_step': round(ms / steps, 3), 'achieved': round(by / ms / 1e6, 1), 'peak': HBM_PEAK_GBS,
                  'unit': 'GB/s', 'frac': round(by / ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -744,7 +744,9 @@ def main():
         roof.update(pmc_traffic(name))
     else:
         roof = {'kernel': None, 'bound': 'mfma', 'achieved': None, 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': None, 'traffic': None, 'note': 'library convolutions (--conv miopen / fp32): no own conv kernel timed'}
+                'frac': None, 'traffic': None,
+                'note': ('fp32 parity path: convolutions on csrc/conv_f32.hip (fp32 MFMA, written for exactness): no family timed'
+                         if amp is None else 'library convolutions (--conv miopen): no own conv kernel timed')}
     if diag_steps:
         roof['families'] = families_table(diag_conv, diag_ops, roi_sets, diag_steps, elem,
                                           geom=dict(n_imgs=2 * a.batch, height=a.height, width=a.width),
