@@ -69,9 +69,13 @@ def rocprof_name(timer_name):
     return timer_name.split(' x')[0].replace('+reduce', '')
 
 
+PMC_PREFIX = ''      # '' for the default workload; 'dc5_' ... for the others (profiles/<tag>_<prefix>pmc_*.json)
+
+
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of ``kernel`` from the committed rocprofv3 PMC summary of this same command
-    (profiles/<tag>_pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter).  Counters are in
+    (profiles/<tag>_<workload prefix>pmc_*.json, written by tools/collect_profiles.sh: one --pmc pass per counter; a
+    workload without its own summary reports null - another workload's launches have other shapes).  Counters are in
     KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 wide coalesced reads; WRITE_SIZE is
     taken as reported (uncalibrated).  PMC counters cannot be collected from inside the timed run, so the value is the
     committed measurement of the NEWEST round only (a kernel that is not in it - renamed, new - reports null rather than
@@ -82,12 +86,12 @@ def pmc_traffic(kernel):
     try:
         tot = 0.0
         for c, mul in (('FETCH_SIZE', 2.0), ('WRITE_SIZE', 1.0)):
-            rows = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_{c}.json')))
+            rows = json.load(open(os.path.join(ROOT, 'profiles', f'{tag}_{PMC_PREFIX}pmc_{c}.json')))
             tot += mul * 1024.0 * next(r['per_dispatch'] for r in rows if r['kernel'] == kernel)
         return {'traffic': int(tot), 'traffic_unit': 'bytes/launch',
-                'traffic_source': f'profiles/{tag}_pmc_FETCH_SIZE.json x2 + {tag}_pmc_WRITE_SIZE.json'}
+                'traffic_source': f'profiles/{tag}_{PMC_PREFIX}pmc_FETCH_SIZE.json x2 + {tag}_{PMC_PREFIX}pmc_WRITE_SIZE.json'}
     except (OSError, StopIteration, KeyError, ValueError):
-        return {'traffic': None, 'traffic_note': f'{kernel} is not in profiles/{tag}_pmc_*.json'}
+        return {'traffic': None, 'traffic_note': f'{kernel} is not in profiles/{tag}_{PMC_PREFIX}pmc_*.json'}
 
 
 def parse():
@@ -602,6 +606,8 @@ def main():
     if a.workload == 'oamix_stress':
         return oamix_stress_run(a, rank, distributed, dev)
     wl = CONFIGS[a.config]
+    global PMC_PREFIX
+    PMC_PREFIX = '' if a.config == 'r50_fpn' else 'dc5_'
     cfg = Config.fromfile(os.path.join(ROOT, 'configs', 'oadg', wl['cfg']))
     amp = torch.bfloat16 if a.dtype == 'bf16' else None
     from oadg_amd import hip_conv
@@ -737,7 +743,9 @@ def main():
                 e[0] += 1; e[1] += t[0].elapsed_time(t[1]); e[2] += t[2]
         if shp_:
             k_, e = max(shp_.items(), key=lambda kv: kv[1][1])
-            roof['heaviest_shape'] = {'N,H,W,C,K,R,stride': list(k_[:7]), 'launches_per_step': round(e[0] / n_s, 1),
+            roof['heaviest_shape'] = {**({'N,H,W,C,K,R,stride': list(k_[:7])} if k_[1] else
+                                         {'grouped_launch': f'{k_[0]} layers\' weight gradients in one launch'}),
+                                      'launches_per_step': round(e[0] / n_s, 1),
                                       'avg_launch_ms': round(e[1] / e[0], 4),
                                       'achieved': round(e[2] / e[1] / 1e9, 1),
                                       'frac': round(e[2] / e[1] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}

@@ -7,18 +7,21 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD="python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline"
+# CONFIG=r101_dc5 PREFIX=dc5_ collects the same summaries for the other bench configuration (files <PREFIX>kernel_stats.csv ...)
+CONFIG=${CONFIG:-r50_fpn}
+PREFIX=${PREFIX:-}
+CMD="python bench.py --config $CONFIG --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline"
 if [ "${SKIP_STATS:-0}" != "1" ]; then
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o b -- $CMD > $OUT/bench_under_rocprof.log 2>&1
-cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-grep '"metric"' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_${PREFIX}stats -o b -- $CMD > $OUT/${PREFIX}bench_under_rocprof.log 2>&1
+cp $(find /tmp/p_${PREFIX}stats -name "*kernel_stats.csv" | head -1) $OUT/${PREFIX}kernel_stats.csv
+grep '"metric"' $OUT/${PREFIX}bench_under_rocprof.log | tail -1 > $OUT/${PREFIX}bench_under_rocprof.json
 fi
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_$C -o b -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
-  python - "$C" "$OUT" <<'PY'
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/p_${PREFIX}$C -o b -- python bench.py --config $CONFIG --steps 4 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  python - "$C" "$OUT/$PREFIX" "$PREFIX" <<'PY'
 import csv, glob, json, sys, collections
-c, out = sys.argv[1], sys.argv[2]
-f = glob.glob(f'/tmp/p_{c}/**/*counter_collection.csv', recursive=True)[0]
+c, out, pre = sys.argv[1], sys.argv[2], sys.argv[3]
+f = glob.glob(f'/tmp/p_{pre}{c}/**/*counter_collection.csv', recursive=True)[0]
 agg = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(f)):
     if r['Counter_Name'] != c:
@@ -30,7 +33,7 @@ for r in csv.DictReader(open(f)):
     agg[k][0] += float(r['Counter_Value']); agg[k][1] += 1
 rows = sorted(((k, v[0], v[1]) for k, v in agg.items()), key=lambda t: -t[1])[:60]
 json.dump([dict(kernel=k, counter=c, total=t, dispatches=n, per_dispatch=t / max(n, 1)) for k, t, n in rows],
-          open(f'{out}/pmc_{c}.json', 'w'), indent=1)
+          open(f'{out}pmc_{c}.json', 'w'), indent=1)
 PY
 done
 ls -la $OUT
