@@ -639,7 +639,22 @@ def main():
     reuse = os.environ.get('OADG_BENCH_DIAG_REUSE_BATCH') == '1'   # diagnostic only: how much does the concurrent
     fixed = state['next'].get() if reuse else None                  # pipeline cost the step?  (INVALID as a result)
 
+    # OADG_BENCH_STEP_TRACE=1 (diagnostic): host clock at every step's start + an event behind every step on the main
+    # stream (no synchronisation): the warm-up curve, host enqueue time and device time step by step -> `step_trace`
+    trace = [] if os.environ.get('OADG_BENCH_STEP_TRACE') == '1' else None
+
     def step(i):
+        if trace is not None:
+            t_host = time.perf_counter()
+            try:
+                return _step(i)
+            finally:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                trace.append((t_host, time.perf_counter(), ev))
+        return _step(i)
+
+    def _step(i):
         if reuse:
             return engine.step(fixed)
         data = state['next'].get()
@@ -769,7 +784,7 @@ def main():
             {'kernel': k_[0], 'N,H,W,C,K,R,stride': list(k_[1:8]), 'dilation': (k_[10] if len(k_) > 10 else 1),
              'residual': bool(k_[8]), 'mask': bool(k_[9]), 'launches_per_step': round(e[0] / diag_steps, 1),
              'ms_per_step': round(e[1] / diag_steps, 3), 'tflops': round(e[2] / e[1] / 1e9, 1), 'tbs': round(e[3] / e[1] / 1e9, 2)}
-            for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1])[:12]]
+            for k_, e in sorted(shp.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('OADG_BENCH_TOP_SHAPES', '12'))]]
         if os.environ.get('OADG_BENCH_DIAG_CONV') == '1':      # per-shape table of the conv launches (stderr)
             for key, blocks in (hip_conv._GROUP_TRACE or {}).items():
                 print(f'wgrad group of {len(key)} jobs, {blocks} workgroups: ' +
@@ -790,6 +805,14 @@ def main():
         'clocks': clock_summary,
         'roofline': roof,
     }
+    if trace:
+        torch.cuda.synchronize()
+        res['step_trace'] = {
+            'note': 'warm-up + timed + families steps in order; host_ms = time inside step() on the host, host_gap_ms = host time '
+                    'between consecutive step starts, device_ms = main-stream time between the events behind consecutive steps',
+            'host_ms': [round((t[1] - t[0]) * 1e3, 2) for t in trace],
+            'host_gap_ms': [round((b[0] - a_[0]) * 1e3, 2) for a_, b in zip(trace, trace[1:])],
+            'device_ms': [round(a_[2].elapsed_time(b[2]), 2) for a_, b in zip(trace, trace[1:])]}
     if engine.reducer is not None:       # gradient bytes the producers wrote straight into the buckets vs packed by a copy
         n_ = max(engine.reducer.steps, 1)
         res['config']['grad_mb_in_place_per_step'] = round(engine.reducer.in_place_bytes / n_ / 1e6, 1)

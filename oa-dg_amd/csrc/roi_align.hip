@@ -526,6 +526,15 @@ __device__ __forceinline__ float lane_f(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// Round 5: the tiles of a workgroup are processed as ONE batch.  Measured before (tools/probe/roi_bwd_probe.py: 36 k (tile, RoI)
+// pairs on 21,760 tiles - 1.7 per tile, 14 per workgroup of 8 tiles; 128 VGPRs = 2 workgroups per CU): 117 us per workgroup
+// = 14.6 us per TILE, almost none of it arithmetic - every tile paid its own chain of hit test -> 2 barriers -> tables of
+// its 1-2 pairs (16 of 512 threads busy) -> barrier -> first slab load at full memory latency -> store.  Now the hit tests
+// of all tiles happen at once (8 ballots, one prefix scan over the 64 (tile, wave) counts), the (tile, RoI) pairs of the
+// whole workgroup form one list in tile-major position order - the SAME summation order per tile as before: bit-identical
+// gradients - whose tables are built 32 pairs at a time by all threads, and every wave walks the list with the next pair's
+// slab block in flight ACROSS tile boundaries, writing a tile's 8 x 4 pixels when the list moves on to the next tile.
+// A (level, image) group of more than 512 RoIs takes the same walk tile by tile, 512 RoIs at a time.
 __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyramid p, TileGrid tg, const float* __restrict__ rois,
                                                                          int PH, int PW, int sampling_ratio, int aligned,
                                                                          const unsigned short* __restrict__ gout,
@@ -533,51 +542,206 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
                                                                          const int* __restrict__ range,
                                                                          const int4* __restrict__ boxes, int tpw) {
     __shared__ TileTables tab[HB];
-    __shared__ int hits[TB_THREADS];
-    __shared__ int wcnt[TB_THREADS / 64];
+    __shared__ int hits[TB_THREADS * TPW];              // RoI | tile-of-the-workgroup << 24, tile-major, position order
+    __shared__ int wcnt[TPW * 8], wbase[TPW * 8 + 1];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int chunk = wave & 3, xh = wave >> 2;         // channel chunk of 64, column half (tile columns 4 xh .. 4 xh + 3)
     int lvl = 0;
     while (lvl + 1 < p.levels && (int)blockIdx.x >= tg.first[lvl + 1]) ++lvl;
     const int H = p.H[lvl], W = p.W[lvl], C = p.C;
-    const int per_img = tg.tx[lvl] * tg.ty[lvl];
+    const int txl = tg.tx[lvl];
+    const int per_img = txl * tg.ty[lvl];
     const int wg_per_img = (per_img + tpw - 1) / tpw;
     const int local = blockIdx.x - tg.first[lvl];
     const int n = local / wg_per_img, t_first = (local - n * wg_per_img) * tpw;
+    const int n_t = min(tpw, per_img - t_first);        // tiles of this workgroup
     const int r0 = range[lvl * p.N + n], r1 = range[lvl * p.N + n + 1];
     const int bins = PH * PW;
     unsigned short* dst = reinterpret_cast<unsigned short*>(const_cast<void*>(p.feat[lvl])) + (size_t)n * H * W * C;
+    // (the 256-channel chunks of a wider map - R101-DC5's 2048-channel C5 - are workgroups of their own on blockIdx.y)
+    const int cb = blockIdx.y * 256;
+    const int cw = min(256, C - cb);
+    const bool chan_ok = chunk * 64 + lane < cw;
+    const unsigned short* gcol = gout + cb + chunk * 64 + lane;        // this lane's channel of g[k][bin][.]
 
-    // the common case - a group of at most 512 RoIs: every thread keeps ITS RoI's tile rectangle for all tiles of the workgroup
-    const bool one_chunk = r1 - r0 <= TB_THREADS;
-    int4 mybox = make_int4(1, 0, -1, -1);
-    int myk = -1;
-    if (one_chunk && r0 + tid < r1) { mybox = boxes[r0 + tid]; myk = order[r0 + tid]; }
-    for (int t = t_first; t < t_first + tpw && t < per_img; ++t) {
-        const int tyi = t / tg.tx[lvl], txi = t - tyi * tg.tx[lvl];
+    float acc[TILE][TILE / 2];
+#pragma unroll
+    for (int y = 0; y < TILE; ++y)
+#pragma unroll
+        for (int x = 0; x < TILE / 2; ++x) acc[y][x] = 0.f;
+    int cur_t = 0;                                      // the tile (of the workgroup) the accumulators belong to
+
+    // a tile is complete: its 8 x 4 pixels of this wave's 64 channels, one bf16 rounding; the accumulators start over
+    auto flush = [&](int tt) {
+        const int t = t_first + tt;
+        const int tyi = t / txl, txi = t - tyi * txl;
         const int y0 = tyi * TILE, x0 = txi * TILE;
-        // (the 256-channel chunks of a wider map - R101-DC5's 2048-channel C5 - are workgroups of their own on blockIdx.y)
-        for (int cb = blockIdx.y * 256; cb < min(C, (int)(blockIdx.y + 1) * 256); cb += 256) {
-            const int cw = min(256, C - cb);
-            float acc[TILE][TILE / 2];
 #pragma unroll
-            for (int y = 0; y < TILE; ++y)
+        for (int y = 0; y < TILE; ++y)
 #pragma unroll
-                for (int x = 0; x < TILE / 2; ++x) acc[y][x] = 0.f;
-            const bool chan_ok = chunk * 64 + lane < cw;
-            const unsigned short* gcol = gout + cb + chunk * 64 + lane;        // this lane's channel of g[k][bin][.]
+            for (int x = 0; x < TILE / 2; ++x) {
+                const int py = y0 + y, px = x0 + xh * 4 + x;
+                if (py < H && px < W) dst[((size_t)py * W + px) * C + cb + chunk * 64 + lane] = f32_to_bf16(acc[y][x]);
+                acc[y][x] = 0.f;
+            }
+    };
+    // 4 x 4 bins from (pb, qb); bins beyond the RoI's last row / column are CLAMPED, not skipped (no branches in the load
+    // stream): their weights on this tile are zero by construction of the ranges
+    auto load_block = [&](float (&v)[4][4], int kk, int pb, int qb) {
+        const unsigned short* gk = gcol + (size_t)kk * bins * C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pr = min(pb + i, PH - 1) * PW;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = bf16_to_f32(gk[(size_t)(pr + min(qb + j, PW - 1)) * C]);
+        }
+    };
+    // hits[0 .. nh) hold (tile, RoI) pairs in tile-major order: tables 32 pairs at a time, then every wave walks them
+    auto process = [&](int nh) {
+        for (int hb = 0; hb < nh; hb += HB) {
+            __syncthreads();                           // hits written / the previous table batch consumed
+            // ---- tables of pairs hb .. hb+31: 16 lanes per pair (0-7: bin rows, 8-15: bin columns)
+            {
+                const int hi_ = hb + (tid >> 4), sub = tid & 15;
+                const bool rows = sub < 8;
+                const int bin = sub & 7, nb = rows ? PH : PW;
+                bool nz = false;
+                if (hi_ < nh) {
+                    TileTables& tb = tab[tid >> 4];
+                    float* w = rows ? tb.wy[bin] : tb.wx[bin];
+                    if (bin < nb) {
+                        const int hv = hits[hi_];
+                        const int t = t_first + (hv >> 24);
+                        const int tyi = t / txl, txi = t - tyi * txl;
+                        const RoiGeom g = roi_geom(rois + (size_t)(hv & 0xffffff) * 5, p, PH, PW, sampling_ratio, aligned);
+                        if (rows) axis_tile_weights(g.start_h, g.bin_h, g.grid_h, bin, H, tyi * TILE, w);
+                        else axis_tile_weights(g.start_w, g.bin_w, g.grid_w, bin, W, txi * TILE, w);
+                        const float inv = rows ? 1.0f / g.count : 1.0f;
+#pragma unroll
+                        for (int j = 0; j < TILE; ++j) {
+                            const float v = w[j];
+                            nz = nz || v != 0.f;
+                            if (rows) w[j] = v * inv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TILE; ++j) w[j] = 0.f;             // bins beyond PH / PW: zeros
+                    }
+                }
+                const unsigned mm = (unsigned)(__ballot(nz) >> ((lane >> 4) * 16)) & 0xffffu;
+                if (hi_ < nh && (sub == 0 || sub == 8)) {
+                    const unsigned f = (sub ? mm >> 8 : mm) & 0xffu;
+                    const int lo = f ? __ffs((int)f) - 1 : nb, hi2 = f ? 32 - __clz((int)f) : 0;
+                    TileTables& tb = tab[tid >> 4];
+                    if (sub == 0) { tb.plo = lo; tb.phi = hi2; } else { tb.qlo = lo; tb.qhi = hi2; }
+                }
+            }
+            __syncthreads();
+            // ---- every wave walks the batch's pairs on its own: first 4 x 4 bin block of pair i+1 in flight
+            const int nb_ = min(HB, nh - hb);
+            if (chan_ok) {
+                float nxt[4][4];
+                load_block(nxt, hits[hb] & 0xffffff, __builtin_amdgcn_readfirstlane(tab[0].plo),
+                           __builtin_amdgcn_readfirstlane(tab[0].qlo));
+                for (int i2 = 0; i2 < nb_; ++i2) {
+                    const TileTables& tb = tab[i2];
+                    const int hv = __builtin_amdgcn_readfirstlane(hits[hb + i2]);
+                    const int kk = hv & 0xffffff, tp = hv >> 24;
+                    const int plo = __builtin_amdgcn_readfirstlane(tb.plo), phi = __builtin_amdgcn_readfirstlane(tb.phi);
+                    const int qlo = __builtin_amdgcn_readfirstlane(tb.qlo), qhi = __builtin_amdgcn_readfirstlane(tb.qhi);
+                    float cur[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) cur[i][j] = nxt[i][j];
+                    if (i2 + 1 < nb_) {
+                        const TileTables& tn = tab[i2 + 1];
+                        load_block(nxt, hits[hb + i2 + 1] & 0xffffff, __builtin_amdgcn_readfirstlane(tn.plo),
+                                   __builtin_amdgcn_readfirstlane(tn.qlo));
+                    }
+                    while (cur_t < tp) { flush(cur_t); ++cur_t; }              // the list moved on: earlier tiles are complete
+                    if (plo >= phi || qlo >= qhi) continue;
+                    // (the weights come as 16-byte LDS broadcasts - 4 column weights / 8 row weights per read - instead of
+                    //  one v_readlane per weight: 96 -> 24 weight fetches per 4 x 4 bin block, off the VALU)
+                    for (int pb = plo; pb < phi; pb += 4)
+                        for (int qb = qlo; qb < qhi; qb += 4) {
+                            if (pb != plo || qb != qlo) load_block(cur, kk, pb, qb);    // (rare: > 4 bins on a tile)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (pb + i >= phi) continue;
+                                float T[TILE / 2] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    if (qb + j >= qhi) continue;
+                                    const f32x4 wxv = *reinterpret_cast<const f32x4*>(&tb.wx[qb + j][xh * 4]);
+#pragma unroll
+                                    for (int x = 0; x < TILE / 2; ++x) T[x] += wxv[x] * cur[i][j];
+                                }
+#pragma unroll
+                                for (int yh = 0; yh < 2; ++yh) {
+                                    const f32x4 wyv = *reinterpret_cast<const f32x4*>(&tb.wy[pb + i][yh * 4]);
+#pragma unroll
+                                    for (int y = 0; y < 4; ++y)
+#pragma unroll
+                                        for (int x = 0; x < TILE / 2; ++x) acc[yh * 4 + y][x] += wyv[y] * T[x];
+                                }
+                            }
+                        }
+                }
+            }
+        }
+    };
+
+    if (r1 - r0 <= TB_THREADS) {
+        // ---- the common case: every thread tests ITS RoI's tile rectangle against all tiles of the workgroup at once
+        int4 b = make_int4(1, 0, -1, -1);
+        int myk = 0;
+        const bool have = r0 + tid < r1;
+        if (have) { b = boxes[r0 + tid]; myk = order[r0 + tid]; }
+        const bool mine = have && b.z == lvl && b.w == n;
+        unsigned long long mm[TPW];
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt) {
+            const int t = t_first + tt;
+            const int tyi = t / txl, txi = t - tyi * txl;
+            const bool hit = mine && tt < n_t && txi >= (b.x & 0xffff) && txi <= (b.x >> 16) && tyi >= (b.y & 0xffff) &&
+                             tyi <= (b.y >> 16);
+            mm[tt] = __ballot(hit);
+            if (lane == 0) wcnt[tt * 8 + wave] = __popcll(mm[tt]);
+        }
+        __syncthreads();
+        if (wave == 0) {                                 // exclusive prefix over the 64 (tile, wave) counts
+            const int v = wcnt[lane];
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            wbase[lane] = incl - v;
+            if (lane == 63) wbase[64] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < TPW; ++tt)
+            if ((mm[tt] >> lane) & 1ull)
+                hits[wbase[tt * 8 + wave] + __popcll(mm[tt] & ((1ull << lane) - 1ull))] = myk | (tt << 24);
+        process(wbase[64]);
+    } else {
+        // ---- a group of more than 512 RoIs: tile by tile, 512 RoIs at a time (the order per tile is the position order)
+        for (int tt = 0; tt < n_t; ++tt) {
+            const int t = t_first + tt;
+            const int tyi = t / txl, txi = t - tyi * txl;
             for (int rb = r0; rb < r1; rb += TB_THREADS) {
-                // which of the next 512 RoIs of this (level, image) reach the tile?
                 bool hit = false;
                 int k = -1;
                 if (rb + tid < r1) {
-                    const int4 b = one_chunk ? mybox : boxes[rb + tid];
+                    const int4 b = boxes[rb + tid];
                     hit = b.z == lvl && b.w == n && txi >= (b.x & 0xffff) && txi <= (b.x >> 16) &&
                           tyi >= (b.y & 0xffff) && tyi <= (b.y >> 16);
-                    if (hit) k = one_chunk ? myk : order[rb + tid];
+                    if (hit) k = order[rb + tid];
                 }
-                // compact in position order (a fixed summation order): ballot + prefix over the waves
                 const unsigned long long m = __ballot(hit);
                 __syncthreads();                               // the previous batch's hits / tables are no longer read
                 if (lane == 0) wcnt[wave] = __popcll(m);
@@ -588,124 +752,13 @@ __global__ __launch_bounds__(TB_THREADS, 4) void roi_align_bwd_tiles_kernel(Pyra
                     if (w2 < wave) base += wcnt[w2];
                     nh += wcnt[w2];
                 }
-                if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
-                for (int hb = 0; hb < nh; hb += HB) {
-                    __syncthreads();                           // hits written / the previous table batch consumed
-                    // ---- tables of pairs hb .. hb+31: 16 lanes per pair (0-7: bin rows, 8-15: bin columns)
-                    {
-                        const int hi_ = hb + (tid >> 4), sub = tid & 15;
-                        const bool rows = sub < 8;
-                        const int bin = sub & 7, nb = rows ? PH : PW;
-                        bool nz = false;
-                        if (hi_ < nh) {
-                            TileTables& tb = tab[tid >> 4];
-                            if (bin < nb) {
-                                const RoiGeom g = roi_geom(rois + (size_t)hits[hi_] * 5, p, PH, PW, sampling_ratio, aligned);
-                                float* w = rows ? tb.wy[bin] : tb.wx[bin];
-                                if (rows) axis_tile_weights(g.start_h, g.bin_h, g.grid_h, bin, H, y0, w);
-                                else axis_tile_weights(g.start_w, g.bin_w, g.grid_w, bin, W, x0, w);
-                                const float inv = rows ? 1.0f / g.count : 1.0f;
-#pragma unroll
-                                for (int j = 0; j < TILE; ++j) {
-                                    const float v = w[j];
-                                    nz = nz || v != 0.f;
-                                    if (rows) w[j] = v * inv;
-                                }
-                            } else {
-                                float* w = rows ? tb.wy[bin] : tb.wx[bin];        // bins beyond PH / PW: zeros
-#pragma unroll
-                                for (int j = 0; j < TILE; ++j) w[j] = 0.f;
-                            }
-                        }
-                        const unsigned mm = (unsigned)(__ballot(nz) >> ((lane >> 4) * 16)) & 0xffffu;
-                        if (hi_ < nh && (sub == 0 || sub == 8)) {
-                            const unsigned f = (sub ? mm >> 8 : mm) & 0xffu;
-                            const int lo = f ? __ffs((int)f) - 1 : nb, hi2 = f ? 32 - __clz((int)f) : 0;
-                            TileTables& tb = tab[tid >> 4];
-                            if (sub == 0) { tb.plo = lo; tb.phi = hi2; } else { tb.qlo = lo; tb.qhi = hi2; }
-                        }
-                    }
-                    __syncthreads();
-                    // ---- every wave walks the batch's pairs on its own: first 4 x 4 bin block of pair i+1 in flight
-                    const int nb_ = min(HB, nh - hb);
-                    if (chan_ok) {
-                        float nxt[4][4];
-                        // 4 x 4 bins from (pb, qb); bins beyond the RoI's last row / column are CLAMPED, not skipped (no
-                        // branches in the load stream): their weights on this tile are zero by construction of the ranges
-                        auto load_block = [&](float (&v)[4][4], int kk, int pb, int phi, int qb, int qhi) {
-                            const unsigned short* gk = gcol + (size_t)kk * bins * C;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const int pr = min(pb + i, PH - 1) * PW;
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    v[i][j] = bf16_to_f32(gk[(size_t)(pr + min(qb + j, PW - 1)) * C]);
-                            }
-                        };
-                        {
-                            const TileTables& t0 = tab[0];
-                            load_block(nxt, hits[hb], __builtin_amdgcn_readfirstlane(t0.plo), __builtin_amdgcn_readfirstlane(t0.phi),
-                                       __builtin_amdgcn_readfirstlane(t0.qlo), __builtin_amdgcn_readfirstlane(t0.qhi));
-                        }
-                        for (int i2 = 0; i2 < nb_; ++i2) {
-                            const TileTables& tb = tab[i2];
-                            const int kk = hits[hb + i2];
-                            const int plo = __builtin_amdgcn_readfirstlane(tb.plo), phi = __builtin_amdgcn_readfirstlane(tb.phi);
-                            const int qlo = __builtin_amdgcn_readfirstlane(tb.qlo), qhi = __builtin_amdgcn_readfirstlane(tb.qhi);
-                            float cur[4][4];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) cur[i][j] = nxt[i][j];
-                            if (i2 + 1 < nb_) {
-                                const TileTables& tn = tab[i2 + 1];
-                                load_block(nxt, hits[hb + i2 + 1], __builtin_amdgcn_readfirstlane(tn.plo), __builtin_amdgcn_readfirstlane(tn.phi),
-                                           __builtin_amdgcn_readfirstlane(tn.qlo), __builtin_amdgcn_readfirstlane(tn.qhi));
-                            }
-                            if (plo >= phi || qlo >= qhi) continue;
-                            // (round 5: the weights come as 16-byte LDS broadcasts - 4 column weights / 8 row weights per read -
-                            //  instead of one v_readlane per weight: 96 -> 24 weight fetches per 4 x 4 bin block, off the
-                            //  VALU; same values, same order of operations: bit-identical gradients)
-                            for (int pb = plo; pb < phi; pb += 4)
-                                for (int qb = qlo; qb < qhi; qb += 4) {
-                                    if (pb != plo || qb != qlo) load_block(cur, kk, pb, phi, qb, qhi);    // (rare: > 4 bins on a tile)
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) {
-                                        if (pb + i >= phi) continue;
-                                        float T[TILE / 2] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                                        for (int j = 0; j < 4; ++j) {
-                                            if (qb + j >= qhi) continue;
-                                            const f32x4 wxv = *reinterpret_cast<const f32x4*>(&tb.wx[qb + j][xh * 4]);
-#pragma unroll
-                                            for (int x = 0; x < TILE / 2; ++x) T[x] += wxv[x] * cur[i][j];
-                                        }
-#pragma unroll
-                                        for (int yh = 0; yh < 2; ++yh) {
-                                            const f32x4 wyv = *reinterpret_cast<const f32x4*>(&tb.wy[pb + i][yh * 4]);
-#pragma unroll
-                                            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                                                for (int x = 0; x < TILE / 2; ++x) acc[yh * 4 + y][x] += wyv[y] * T[x];
-                                        }
-                                    }
-                                }
-                        }
-                    }
-                }
-            }
-            if (chan_ok) {
-#pragma unroll
-                for (int y = 0; y < TILE; ++y)
-#pragma unroll
-                    for (int x = 0; x < TILE / 2; ++x) {
-                        const int py = y0 + y, px = x0 + xh * 4 + x;
-                        if (py >= H || px >= W) continue;
-                        dst[((size_t)py * W + px) * C + cb + chunk * 64 + lane] = f32_to_bf16(acc[y][x]);
-                    }
+                if (hit) hits[base + __popcll(m & ((1ull << lane) - 1ull))] = k | (tt << 24);
+                process(nh);
             }
         }
     }
+    if (chan_ok)
+        while (cur_t < n_t) { flush(cur_t); ++cur_t; }
 }
 
 // sort key of a RoI for the processing order of the two kernels above: (pyramid level, image, 16-feature-pixel cell

@@ -157,12 +157,13 @@ def test_nms_12000_through_the_split_thr_branch(dev, n_ids):
     assert torch.equal(mine, keep)
 
 
-@pytest.mark.parametrize('C,K', [(256, 300), (64, 37), (512, 900)])
+@pytest.mark.parametrize('C,K', [(256, 300), (64, 37), (512, 900), (64, 2000)])
 def test_roi_align_bf16_backward_by_tiles(dev, C, K, monkeypatch):
     """The bf16 backward organised by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no atomics) against the
     oracle's fp32 backward on the same bf16-rounded operands (bf16 output rounding: 2^-8 relative) and against the
     atomic path; map sizes that are not multiples of the 8 x 8 tile, degenerate and out-of-image RoIs, empty levels;
-    two runs are bit-identical (fixed summation order)."""
+    two runs are bit-identical (fixed summation order).  K = 2000: ~670 RoIs per image on level 0 - more than the 512 a
+    workgroup tests at once (the tile-by-tile form of the kernel)."""
     from oadg_amd import hip_ops
     rs = np.random.RandomState(C + K)
     strides = [4, 8, 16, 32]

@@ -36,6 +36,32 @@ def real_rois(dev):
     return rois
 
 
+def pair_histogram(rois, lvl, strides, tpw=8):
+    """(tile, RoI) pairs per 8 x 8 tile and per workgroup of `tpw` consecutive tiles: how uneven is the kernel's work?"""
+    import math
+    r = rois.cpu()
+    lv = lvl.cpu().long()
+    for li, s in enumerate(strides):
+        H, W = 1024 // s, 2048 // s
+        ty, tx = (H + 7) // 8, (W + 7) // 8
+        cnt = torch.zeros(8, ty, tx, dtype=torch.int32)
+        for row in r[lv == li]:
+            n = int(row[0])
+            x0, y0, x1, y1 = [float(v) / s - 0.5 for v in row[1:]]
+            xl, xh = max(math.floor(x0) - 1, 0), min(math.ceil(x1) + 1, W - 1)
+            yl, yh = max(math.floor(y0) - 1, 0), min(math.ceil(y1) + 1, H - 1)
+            if xh < 0 or yh < 0 or xl >= W or yl >= H:
+                continue
+            cnt[n, yl // 8:yh // 8 + 1, xl // 8:xh // 8 + 1] += 1
+        flat = cnt.reshape(8, -1)
+        pad = (-flat.shape[1]) % tpw
+        wg = torch.nn.functional.pad(flat, (0, pad)).reshape(8, -1, tpw).sum(-1).flatten()
+        f = flat.flatten().float()
+        print(f'level {li}: tiles {f.numel()}, pairs {int(f.sum())}, empty {float((f == 0).float().mean()):.2f}, per tile mean {float(f.mean()):.2f} '
+              f'p99 {float(f.quantile(0.99)):.0f} max {int(f.max())}; per workgroup of {tpw}: mean {float(wg.float().mean()):.1f} '
+              f'p99 {float(wg.float().quantile(0.99)):.0f} max {int(wg.max())}')
+
+
 def main():
     dev = torch.device('cuda:0')
     rois = real_rois(dev)
@@ -44,6 +70,7 @@ def main():
     lvl = torch.floor(torch.log2(torch.sqrt(w.clamp(min=0) * h.clamp(min=0)) / 56 + 1e-6)).clamp(0, 3)
     print('K', K, 'per level', [int((lvl == i).sum()) for i in range(4)], 'mean side px', float(torch.sqrt(w * h).mean()))
     strides = [4, 8, 16, 32]
+    pair_histogram(rois, lvl, strides)
     feats = [torch.randn(8, 256, 1024 // s, 2048 // s, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
              for s in strides]
     gout = torch.randn(K, 256, 7, 7, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
