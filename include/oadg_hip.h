@@ -723,6 +723,16 @@ int oadg_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, void* work
 int oadg_host_randperm_prefix(uint64_t* state624, int* left, uint64_t* next, int64_t n, int64_t k,
                               int64_t* out);
 
+/* Host helper (no device work): OA-DG's random proposal boxes drawn in place from numpy's legacy MT19937 state
+ *   replaces generate_random_bboxes_xy   mmdet/models/detectors/two_stage.py:389-419 (the trial loop of one image)
+ * mt = numpy's `mt19937_state*` (np.random.mtrand._rand._bit_generator.ctypes.state_address): the same draws in the same
+ * order (randint(0, width), randint(0, height), uniform(scales), uniform(ratios) per trial), the IoU test of
+ * mmdet/core/evaluation/bbox_overlaps.py in fp32 against gts [n_gt][4] (n_gt < 0: no test; n_gt == 0 returns -2: the
+ * reference raises there); out [num][5] doubles.  Returns the number of boxes written (<= num), < 0 on an error. */
+int oadg_np_random_bboxes(void* mt, int img_width, int img_height, int num, const float* gts, int n_gt, double scale_lo,
+                          double scale_hi, double ratio_lo, double ratio_hi, int max_iters, double iou_max, double iou_min,
+                          double* out);
+
 /* ------------------------------------------------------------------------------------------------
  * A frozen ResNet bottleneck block (identity shortcut, 256 -> 64 -> 64 -> 256, stride 1) as one launch:
  *   mmdet/models/backbones/resnet.py:263-302 Bottleneck.forward with the BatchNorms folded (eval mode, frozen_stages).

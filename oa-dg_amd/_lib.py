@@ -147,6 +147,7 @@ SIGNATURES = {
     'oadg_conv2d_wgrad_f32_splits': (ci, [ci, ci, ci, ci, ci, ci, ci]),
     'oadg_conv2d_wgrad_f32': (ci, [vp, vp, vp, vp, cs, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_host_randperm_prefix': (ci, [vp, POINTER(ci), POINTER(ctypes.c_uint64), c_int64, c_int64, vp]),
+    'oadg_np_random_bboxes': (ci, [vp, ci, ci, ci, vp, ci, cd, cd, cd, cd, ci, cd, cd, vp]),
     'oadg_oamix_box_profiles': (ci, [vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union': (ci, [vp, vp, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_fg_union_rects': (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -86,14 +86,23 @@ class FusedSGD(torch.optim.SGD):
         if group['momentum'] <= 0 or group['dampening'] != 0 or group['nesterov'] or group.get('maximize', False):
             return None
         ps = [p for p in group['params'] if p.grad is not None]
+        f32 = torch.float32
         for p in ps:
             g = p.grad
-            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse and
-                    g.device == p.device and g.shape == p.shape and _same_layout(g, p)):
+            if g.dtype is not f32 or g.is_sparse or g.shape != p.shape or g.device != p.device or \
+                    not (g.stride() == p.stride() or _same_layout(g, p)):
                 return None
-            b = self.state[p].get('momentum_buffer') if p in self.state else None
-            if b is not None and not (b.dtype == torch.float32 and b.device == p.device and b.shape == p.shape and
-                                      _same_layout(b, p)):
+            st = self.state.get(p)
+            b = st.get('momentum_buffer') if st is not None else None
+            # what does not change from step to step - the parameter's own properties, its momentum buffer's layout - is
+            # checked once per (parameter, buffer): 160 parameters x 12 attribute reads were 0.4 ms of every step
+            if b is not None and not (b.stride() == p.stride() or _same_layout(b, p)):
+                return None
+            if getattr(p, '_oadg_sgd_checked', None) == (0 if b is None else id(b)):
+                continue
+            if not (p.is_cuda and p.dtype is f32):
+                return None
+            if b is not None and not (b.dtype is f32 and b.device == p.device and b.shape == p.shape):
                 return None
             dense = getattr(p, '_oadg_dense', None)
             if dense is None:
@@ -101,6 +110,7 @@ class FusedSGD(torch.optim.SGD):
                 dense = p._oadg_dense = bool(is_non_overlapping_and_dense(p))
             if not dense:
                 return None
+            p._oadg_sgd_checked = 0 if b is None else id(b)
         return ps
 
     @torch.no_grad()
@@ -436,7 +446,10 @@ class TrainEngine:
         ours = set(id(h) for h in ())
         if self.reducer is not None:
             ours = {h.id for h in self.reducer._hooks}
-        for p in self.module.parameters():
+        params = getattr(self, '_param_list', None)
+        if params is None:          # (the traversal of the module tree costs 0.3 ms per step; the tree is fixed while training)
+            params = self._param_list = list(self.module.parameters())
+        for p in params:
             if p._backward_hooks:
                 return True
             post = getattr(p, '_post_accumulate_grad_hooks', None)

@@ -640,13 +640,17 @@ struct TapState {
     int t, r, s, rs, c0;
 };
 
-template <bool POST>
+// NW = 2: 256 x 256 tile.  NW = 1 (round 5): 256 pixels x 128 channels for the layers with K = 128 (ResNet layer2's 3x3
+// and its data gradient: 1024 pixel tiles of 18 K-tiles each, which the 128-tile kernel ran at 440 - 650 TFLOP/s) - the same
+// buffers and schedule with the W1 half-tile left out: 16 MFMAs per phase, 64 accumulator registers.
+template <bool POST, int NW>
 __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
+    constexpr int TNW = NW * 128;                       // channels of the tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const int n_tiles = a.K / TN;
+    const int n_tiles = a.K / TNW;
     const long m_tiles = (a.M + TM - 1) / TM;
     const long bid = blockIdx.x;
     long mt;
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
         if (j / n_tiles >= per || mt >= m_tiles) return;
     }
     const long m0 = mt * TM;
-    const int k0 = nt * TN;
+    const int k0 = nt * TNW;
     const int nk = a.R * a.S * (a.C / BK);
 
     // ---- loader geometry: piece q = i*512 + tid of a half-tile -> row = q >> 3 (0..127), 16-byte slot q & 7
@@ -687,7 +691,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
                 hi0[h * 2 + i] = -(1 << 28);            // fails every bounds test -> zero line
                 wi0[h * 2 + i] = 0;
             }
-            wb[h * 2 + i] = a.w + (size_t)(k0 + h * 128 + row) * a.R * a.S * a.C + lslot * 8;
+            wb[h * 2 + i] = a.w + (size_t)(k0 + (h & (NW - 1)) * 128 + row) * a.R * a.S * a.C + lslot * 8;
         }
 
     // K-tile order: CHANNEL CHUNK major, taps inner.  A 64-channel chunk of a pixel is one 128-byte line; the R*S taps
@@ -743,9 +747,9 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
             woff[jt][ks] = row * 128 + (((ks * 4 + fq) ^ ((row >> 1) & 7)) << 4);
         }
 
-    f32x4v acc[2][2][2][4];        // [w half][w tile][p half][p tile]
+    f32x4v acc[NW][2][2][4];       // [w half][w tile][p half][p tile]
 #pragma unroll
-    for (int x0 = 0; x0 < 2; ++x0)
+    for (int x0 = 0; x0 < NW; ++x0)
 #pragma unroll
         for (int x1 = 0; x1 < 2; ++x1)
 #pragma unroll
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 #pragma unroll
                 for (int x3 = 0; x3 < 4; ++x3) acc[x0][x1][x2][x3] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 pf[4][2], wf[2][2][2];
+    bf16x8 pf[4][2], wf[NW][2][2];
     auto read_pix = [&](int h, int buf) {
         const unsigned char* base = smem + buf * BUF_BYTES + h * HALF_BYTES;
 #pragma unroll
@@ -774,12 +778,13 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
         asm volatile("s_barrier" ::: "memory");                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         __builtin_amdgcn_s_setprio(1);                                                                       \
-        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh)                                                     \
+        _Pragma("unroll") for (int hh = 0; hh < NW; ++hh)                                                    \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                 \
                 _Pragma("unroll") for (int jt = 0; jt < 2; ++jt)                                             \
                     _Pragma("unroll") for (int it = 0; it < 4; ++it)                                         \
-                        acc[hh ^ W_FIRST][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(            \
-                            wf[hh ^ W_FIRST][jt][ks], pf[it][ks], acc[hh ^ W_FIRST][jt][PH_][it], 0, 0, 0);  \
+                        acc[(hh ^ W_FIRST) & (NW - 1)][jt][PH_][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(   \
+                            wf[(hh ^ W_FIRST) & (NW - 1)][jt][ks], pf[it][ks],                               \
+                            acc[(hh ^ W_FIRST) & (NW - 1)][jt][PH_][it], 0, 0, 0);                           \
         __builtin_amdgcn_s_setprio(0);                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         asm volatile("s_barrier" ::: "memory");                                                              \
@@ -789,7 +794,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     TapState s1{0, 0, 0, 0, 0};
     stage_pix(0, s1, 0);
     stage_wgt(0, s1, 0);
-    stage_wgt(1, s1, 0);
+    if (NW == 2) stage_wgt(1, s1, 0);
     stage_pix(1, s1, 0);
     advance(s1);                     // s1 = tile 1
     stage_pix(0, s1, 1);
@@ -804,9 +809,9 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
         const int buf = t & 1;
         // phase A
         read_wgt(0, buf);
-        read_wgt(1, buf);
+        if (NW == 2) read_wgt(1, buf);
         read_pix(0, buf);
-        stage_wgt(1, s1, buf ^ 1);
+        if (NW == 2) stage_wgt(1, s1, buf ^ 1);
         stage_pix(1, s1, buf ^ 1);
         OADG_MFMA32(0, 0);
         // phase B
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
     {
         const int cq = lane >> 4;
 #pragma unroll
-        for (int wh = 0; wh < 2; ++wh)
+        for (int wh = 0; wh < NW; ++wh)
 #pragma unroll
             for (int jt = 0; jt < 2; ++jt) {
                 const int ch = wh * 128 + wc * 32 + jt * 16 + 4 * cq;
@@ -852,21 +857,21 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
                         uint2 pk;
                         pk.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
                         pk.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
-                        *reinterpret_cast<uint2*>(smem + p * 512 + ((((ch >> 3) ^ (p & 15))) << 4) + ((ch >> 2) & 1) * 8) = pk;
+                        *reinterpret_cast<uint2*>(smem + p * (TNW * 2) + ((((ch >> 3) ^ (p & 15))) << 4) + ((ch >> 2) & 1) * 8) = pk;
                     }
             }
     }
     // residual / mask pieces requested before the barrier, all 16 (x2) loads of the thread in flight together: the
     // 128 accumulator registers are dead once the C image is written
-    constexpr int NPIECE = (TM * TN / 8) / 512;
+    constexpr int NPIECE = (TM * TNW / 8) / 512, SL = TNW / 8;      // 16-byte slots per pixel row
     bf16x8 rv[POST ? NPIECE : 1], mv[POST ? NPIECE : 1];
     unsigned mb[POST ? NPIECE : 1];
     if (POST) {
 #pragma unroll
         for (int it = 0; it < NPIECE; ++it) {
             const int q = it * 512 + tid;
-            const long m = m0 + (q >> 5);
-            const size_t off = (size_t)m * a.K + k0 + (q & 31) * 8;
+            const long m = m0 + q / SL;
+            const size_t off = (size_t)m * a.K + k0 + (q % SL) * 8;
             rv[it] = (a.res && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.res + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mv[it] = (a.mask && m < a.M) ? *reinterpret_cast<const bf16x8*>(a.mask + off) : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             mb[it] = (a.bits_in && m < a.M) ? a.bits_in[off >> 3] : 0xffu;
@@ -880,23 +885,23 @@ __global__ __launch_bounds__(512) void conv_igemm256_kernel(ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < NPIECE; ++it) {
         const int q = it * 512 + tid;
-        const int p = q >> 5, sg = q & 31;             // sg = tid & 31 for every piece of this thread
+        const int p = q / SL, sg = q % SL;             // sg = tid % SL for every piece of this thread
         const long m = m0 + p;
         if (m >= a.M) continue;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * 512 + ((sg ^ (p & 15)) << 4));
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + p * (TNW * 2) + ((sg ^ (p & 15)) << 4));
         const size_t off = (size_t)m * a.K + k0 + sg * 8;
         *reinterpret_cast<bf16x8*>(a.y + off) = finish_piece<POST>(a, v, rv[POST ? it : 0], mv[POST ? it : 0], csum,
                                                                    mb[POST ? it : 0], off);
     }
-    if (a.colsum) {       // 16 threads share a channel slot: combine through the 16 KiB behind the C image
-        float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [16][256]
+    if (a.colsum) {       // 512 / SL threads share a channel slot: combine through the 16 KiB behind the C image
+        float* red = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);    // [512 / SL][TNW]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid >> 5) * TN + (tid & 31) * 8 + e] = csum[e];
+        for (int e = 0; e < 8; ++e) red[(tid / SL) * TNW + (tid % SL) * 8 + e] = csum[e];
         __syncthreads();
-        if (tid < TN) {
+        if (tid < TNW) {
             float t = 0.f;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) t += red[g * TN + tid];
+            for (int g = 0; g < 512 / SL; ++g) t += red[g * TNW + tid];
             a.colsum[(size_t)mt * a.K + k0 + tid] = t;
         }
     }
@@ -914,8 +919,13 @@ namespace {
 //  - pointwise launches with C <= 256 and K a multiple of 256 (ResNet conv3 / the data gradient of conv1, P2 lateral):
 //    the streaming kernel (variant 4), 1.1-1.2x the 128-tile kernel there (4.2-5.3 TB/s of HBM traffic).
 int auto_variant(long M, int H, int W, int C, int K, int nchunks, int R = 0, int S = 0, int stride = 0, int pad = 0) {
-    const long big = ((M + TM - 1) / TM) * (K / TN);
-    const bool ok256 = K % TN == 0 && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
+    // (K = 128: the 256 x 128 instantiation exists - explicit variant 2, or OADG_CONV_256X128=1 - but is NOT chosen: measured
+    //  on ResNet layer2's 3x3 (8 x 128 x 256 px, C = K = 128) 555 - 650 TFLOP/s against the 128-tile kernel's 650 - 715: its
+    //  phases are 16 MFMAs between barriers, the interval this kernel's own ablation found too short)
+    static const bool narrow256 = getenv("OADG_CONV_256X128") && atoi(getenv("OADG_CONV_256X128")) == 1;
+    const int tnw = K % TN == 0 ? TN : 128;
+    const long big = ((M + TM - 1) / TM) * (K / tnw);
+    const bool ok256 = (K % TN == 0 || (K == 128 && narrow256)) && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
     if (ok256 && nchunks >= 12) return 2;
     if (pw_stream_ranges(M, C, K, R, S, stride, pad) > 0) return 4;
     if (ok256 && nchunks >= 8) return 2;      // (512-channel 1x1 / stride 2: no streaming kernel; 97 / 108 us cold)
@@ -937,7 +947,7 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (!x || !w || !y || !zeros16) return OADG_EARG;
     if (N < 1 || H < 1 || W < 1 || R < 1 || S < 1 || stride < 1 || dil < 1 || pad < 0) return OADG_EARG;
     if (C % BK != 0 || K % 64 != 0) return OADG_EARG;   // other shapes stay on the library path
-    if (variant < 0 || variant > 4 || (variant == 2 && K % TN != 0)) return OADG_EARG;
+    if (variant < 0 || variant > 4 || (variant == 2 && K % 128 != 0)) return OADG_EARG;
     ConvArgs a;
     a.x = (const unsigned short*)x; a.w = (const unsigned short*)w; a.bias = bias;
     a.res = (const unsigned short*)residual; a.y = (unsigned short*)y; a.zeros = (const unsigned short*)zeros16;
@@ -991,23 +1001,23 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
     if (variant == 2) {
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)conv_igemm256_kernel<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)conv_igemm256_kernel<true>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
-            if (e != hipSuccess) return (int)e;
+            const void* fns[4] = {(const void*)conv_igemm256_kernel<false, 2>, (const void*)conv_igemm256_kernel<true, 2>,
+                                  (const void*)conv_igemm256_kernel<false, 1>, (const void*)conv_igemm256_kernel<true, 1>};
+            for (const void* f : fns) {
+                hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_BYTES + 16384);
+                if (e != hipSuccess) return (int)e;
+            }
             attr_set = true;
         }
+        const int nw = K % TN == 0 ? 2 : 1;
         const long m_tiles = (a.M + TM - 1) / TM;
-        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / TN);
+        const long blocks = ((m_tiles + 7) / 8) * 8 * (K / (nw * 128));
         if (blocks > 0x7fffffffL) return OADG_EARG;
-        if (post)
-            hipLaunchKernelGGL(conv_igemm256_kernel<true>, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
-                               (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(conv_igemm256_kernel<false>, dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384,
-                               (hipStream_t)stream, a);
+#define OADG_L256(PO, NW_) \
+    hipLaunchKernelGGL((conv_igemm256_kernel<PO, NW_>), dim3((unsigned)blocks), dim3(512), 2 * BUF_BYTES + 16384, (hipStream_t)stream, a)
+        if (nw == 2) { if (post) OADG_L256(true, 2); else OADG_L256(false, 2); }
+        else { if (post) OADG_L256(true, 1); else OADG_L256(false, 1); }
+#undef OADG_L256
     } else {
         const long m_tiles = (a.M + BM - 1) / BM;
         // 128 x 64 tiles also where 128 x 128 tiles would leave compute units without a workgroup (R101-DC5's 46 x 80 maps:

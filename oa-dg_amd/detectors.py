@@ -1,4 +1,5 @@
 """Detectors (mmdet/models/detectors/{base,two_stage,faster_rcnn}.py)."""
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -68,12 +69,50 @@ def integrate_data(data, train_cfg):
     return data
 
 
+_NP_F32_COMPARE = not bool(np.float32(0.1) > 0.1)     # numpy >= 2 compares a float32 with a python float in float32
+NATIVE_RANDOM_BBOXES = os.environ.get('OADG_NATIVE_RANDOM_BBOXES', '1') == '1'
+
+
+def _random_bboxes_native(img_width, img_height, num_bboxes, bboxes_xy, scales, ratios, max_iters, iou_max, iou_min):
+    """the trial loop below in csrc/host_rng.hip (oadg_np_random_bboxes), drawing IN PLACE from numpy's global generator:
+    the same boxes and the same generator state afterwards (tests/test_random_bboxes_native.py), ~50x less interpreter
+    time on the training thread.  None when the case is not covered (another bit generator, no gt boxes)."""
+    from . import _lib
+    rs = np.random.mtrand._rand
+    bg = rs._bit_generator
+    if type(bg).__name__ != 'MT19937' or (bboxes_xy is not None and len(bboxes_xy) == 0) or num_bboxes < 0:
+        return None
+    try:
+        L = _lib.lib()
+    except Exception:            # (the library is not built: CPU-only unit tests of the host logic)
+        return None
+    if bboxes_xy is None:
+        gts, n_gt = None, -1
+    else:
+        gts = np.ascontiguousarray(np.asarray(bboxes_xy)[:, :4], dtype=np.float32)
+        n_gt = gts.shape[0]
+    thr = (lambda v: float(np.float32(v))) if _NP_F32_COMPARE else float
+    out = np.zeros((num_bboxes, 5))
+    with bg.lock:
+        n = L.oadg_np_random_bboxes(bg.ctypes.state_address, int(img_width), int(img_height), int(num_bboxes),
+                                    gts.ctypes.data if gts is not None else None, n_gt, float(scales[0]), float(scales[1]),
+                                    float(ratios[0]), float(ratios[1]), int(max_iters), thr(iou_max), thr(iou_min),
+                                    out.ctypes.data)
+    if n < 0:
+        raise RuntimeError(f'oadg_np_random_bboxes failed ({n})')
+    return out[:n, :]
+
+
 def generate_random_bboxes_xy(img_size, num_bboxes, bboxes_xy=None, scales=(0.01, 0.2), ratios=(0.3, 1 / 0.3),
                               max_iters=500, iou_max=1.0, iou_min=0.0, **kwargs):
     """two_stage.py:389-419 (global numpy RNG, same draw order: x1, y1, scale, ratio per trial)."""
     if isinstance(num_bboxes, (tuple, list)):
         num_bboxes = np.random.randint(num_bboxes[0], num_bboxes[1] + 1)
     img_width, img_height = img_size
+    if NATIVE_RANDOM_BBOXES:
+        out = _random_bboxes_native(img_width, img_height, num_bboxes, bboxes_xy, scales, ratios, max_iters, iou_max, iou_min)
+        if out is not None:
+            return out
     out = np.zeros((num_bboxes, 5))
     total = 0
     for _ in range(max_iters):

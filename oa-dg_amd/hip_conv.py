@@ -474,7 +474,7 @@ def kernel_name(v, C, K, R, S, stride, pad, res, mask, bits_in, bits_out, scatte
     b = lambda f: 'true' if f else 'false'  # noqa: E731
     post = res or mask or bits_in
     if v == 2:
-        return 'conv_igemm256_kernel<%s>' % b(post)
+        return 'conv_igemm256_kernel<%s, %d>' % (b(post), 2 if K % 256 == 0 else 1)      # (256 x 128 tiles for K = 128)
     if v == 4:
         return 'conv_pw_stream_kernel<%d, %s, %s, %s>' % (C, b(res), b(bits_in), b(bits_out))
     pw = v == 3 and R == 1 and S == 1 and stride == 1 and pad == 0 and not scatter

@@ -94,6 +94,13 @@ class Compose:
         return data
 
 
+def _side_stream(device):
+    """the pipeline's HIP stream.  (Round 5 tried a CU-masked stream here - hipExtStreamCreateWithCUMask, 16 / 32 / 64 of the
+    256 compute units, so that OA-Mix's ~400 small launches stop taking compute units from under the training stream's
+    one-workgroup-per-CU kernels: the pipeline itself became the bottleneck, 27.6 -> 42 - 62 ms per step)"""
+    return torch.cuda.Stream(device=device, priority=int(os.environ.get('OADG_PIPE_PRIO', '0')))
+
+
 class DevicePipeline:
     """Batched device execution of [OAMix,] Normalize, Pad, DefaultFormatBundle, Collect."""
 
@@ -191,7 +198,7 @@ class DevicePipeline:
         private numpy stream - so it also overlaps the step's host work; None keeps it in the caller's thread on
         the global numpy stream (bit-reproducible against the oracle with a single ``np.random.seed``)."""
         if getattr(self, '_stream', None) is None:
-            self._stream = torch.cuda.Stream(device=imgs_u8.device, priority=int(os.environ.get('OADG_PIPE_PRIO', '0')))
+            self._stream = _side_stream(imgs_u8.device)
             self._stream.wait_stream(torch.cuda.current_stream())
         if worker_seed is None:
             return _Prefetched(*self._run_on_side_stream(imgs_u8, gt_bboxes, gt_labels, ready))

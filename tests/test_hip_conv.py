@@ -56,6 +56,9 @@ def test_conv_forward_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad,
     (1, 512, 16, 16, 512, 3, 1, 2, 2),      # dilated (DC5)
     (1, 128, 64, 96, 256, 3, 2, 1, 1),      # stride 2, full tiles
     (2, 64, 48, 80, 256, 3, 1, 1, 1),       # one chunk per tap, 30 tiles
+    (2, 128, 40, 56, 128, 3, 1, 1, 1),      # K = 128: the 256 x 128 instantiation (ResNet layer2's 3x3)
+    (1, 128, 37, 29, 128, 3, 2, 1, 1),      # ... stride 2, ragged pixel tail
+    (1, 64, 24, 24, 384, 1, 1, 0, 1),       # ... three 128-channel column tiles
 ])
 def test_conv_256_tile_variant_matches_fp32_reference(dev, N, C, H, W, K, R, stride, pad, dil):
     """the phase-pipelined 256x256 kernel (variant 2) on its own: same contract, same tolerance; repeated to
@@ -301,7 +304,7 @@ def test_conv_dgrad_epilogue_mask_and_colsum(dev):
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(2)
     for variant, (N, C, H, W, K) in ((1, (2, 128, 20, 28, 128)), (2, (2, 128, 40, 56, 256)), (2, (1, 64, 19, 23, 512)),
-                                      (2, (2, 128, 32, 48, 256)),
+                                      (2, (2, 128, 32, 48, 256)), (2, (2, 128, 33, 47, 128)),
                                       (1, (2, 128, 21, 27, 64)), (3, (2, 128, 20, 28, 128)), (3, (2, 256, 21, 27, 64))):
         x = torch.randn(N, C, H, W, device=dev, generator=g).bfloat16().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(K, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5).bfloat16().contiguous(
