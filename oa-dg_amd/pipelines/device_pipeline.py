@@ -220,6 +220,11 @@ class DevicePipeline:
             out = self(imgs_u8, gt_bboxes, gt_labels)
             evt = torch.cuda.Event()
             evt.record()
+        if imgs_u8.is_cuda:
+            # the source images were allocated on their producer's stream and are read HERE: without this their memory could
+            # be handed to a new tensor of that stream as soon as the caller drops them (a streaming loader does, right after
+            # this call returns) - while this stream's kernels are still reading
+            imgs_u8.record_stream(self._stream)
         return out, evt
 
     def __call__(self, imgs_u8, gt_bboxes, gt_labels):

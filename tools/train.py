@@ -195,11 +195,14 @@ def main():
                     continue                              # trained before the run was interrupted inside this epoch
                 yield epoch, k, idx
 
+    loader_stream = torch.cuda.Stream(device=dev)     # decode / upload / synthetic generation beside the training stream
+
     def load(item):
         torch.cuda.set_device(dev)
-        batch = ds.batch(item[2])
-        ready = torch.cuda.Event()
-        ready.record()
+        with torch.cuda.stream(loader_stream):
+            batch = ds.batch(item[2])
+            ready = torch.cuda.Event()
+            ready.record()
         return item, batch, ready
     loader = ThreadPoolExecutor(1, thread_name_prefix='oadg-loader')
     wseed = seed + rank + 1000
@@ -236,6 +239,11 @@ def main():
             print(f'Epoch [{epoch + 1}][{k + 1}/{iters_per_epoch}] lr: {optimizer.param_groups[0]["lr"]:.3e} '
                   f'time: {(now - t_log) / (it - it_log):.4f} ' +
                   ', '.join(f'{n}: {v:.4f}' for n, v in lv.items()), flush=True)
+            if os.environ.get('OADG_TRAIN_TRACE') == '1':      # diagnostic: what an interval's outliers consist of
+                ms = torch.cuda.memory_stats()
+                print(f'  trace: repeated steps {getattr(engine, "respeculated", 0)}, device segments allocated '
+                      f'{ms["segment.all.allocated"]}, reserved {ms["reserved_bytes.all.current"] >> 20} MB, '
+                      f'alloc retries {ms["num_alloc_retries"]}', flush=True)
             t_log, it_log = now, it
     if last_epoch is not None:
         save_checkpoint(last_epoch, it, inner=done_in_epoch if cut_short else None)
