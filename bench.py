@@ -332,7 +332,7 @@ def cpu_baseline(cfg, wl=None, seconds_budget=30.0):
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from inputs import lowpass_image, synthetic_boxes
     prev_threads = torch.get_num_threads()
-    threads = min(prev_threads, 32)      # many-core hosts: small CPU ops do not scale past a few dozen threads
+    threads = min(baseline_cores(), 32)  # many-core hosts: small CPU ops do not scale past a few dozen threads
     torch.set_num_threads(threads)
     wl = wl or CONFIGS['r50_fpn']
     H, W, nbox = wl['height'], wl['width'], wl['boxes']
@@ -388,7 +388,7 @@ def stress_cpu_baseline(H, W, n_boxes_sample=6):
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     from inputs import lowpass_image, supcon_inputs, synthetic_boxes
     prev_threads = torch.get_num_threads()
-    threads = min(prev_threads, 32)
+    threads = min(baseline_cores(), 32)
     torch.set_num_threads(threads)
     rs = np.random.RandomState(0)
     img = lowpass_image(rs, H, W)
@@ -411,7 +411,7 @@ def stress_cpu_baseline(H, W, n_boxes_sample=6):
                        f'charged to the image), torch {threads} threads, nproc={os.cpu_count()}')
 
 
-def oamix_stress_run(a, rank, distributed, dev):
+def oamix_stress_run(a, rank, distributed, dev, affinity=None):
     """BASELINE configs[4]: the augmentation + OA-Loss kernels in isolation.  One step = the device pipeline pass (OA-Mix
     of every image + Normalize / Pad) over ``--batch`` (8) images of 1024 x 2048 with 4096 boxes of 8 - 48 px each, then the
     OA-Loss (supcon forward + backward) at the contrastive batch 8 x 512 RoIs x 2 views + the random RoIs.  Inputs are
@@ -493,28 +493,35 @@ def oamix_stress_run(a, rank, distributed, dev):
            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8 (OA-Mix) / f32 (OA-Loss)', 'data': 'synthetic',
            'config': {'workload': f'OA-Mix stress: {NB} boxes/image of 8-48 px, {a.batch} img/GPU, {H}x{W}, view 2 of every image '
                                   f'+ Normalize/Pad; OA-Loss at B = {B} rows', 'global_batch': a.gpus * a.batch,
-                      'parallelism': f'dp{a.gpus}', 'final_loss': round(float(out['loss']), 5)},
+                      'parallelism': f'dp{a.gpus}', 'final_loss': round(float(out['loss'].detach()), 5), 'cpu_affinity': affinity},
            'clocks': clock_summary, 'roofline': roof,
            'cpu_baseline': None if (a.no_cpu_baseline or a.gpus != 1) else stress_cpu_baseline(H, W)}
     print(json.dumps(res))
 
 
+_FULL_AFFINITY = None        # the CPUs this process could use before pin_rank_to_cores() narrowed them
+
+
+def baseline_cores():
+    """the CPU baseline leg runs on the host's cores, not on the GPU run's compact set: widen the affinity again (rank 0, N = 1
+    only: nobody else is measuring) and return how many CPUs there are"""
+    if _FULL_AFFINITY is not None and hasattr(os, 'sched_setaffinity'):
+        os.sched_setaffinity(0, _FULL_AFFINITY)
+    return len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+
 def pin_rank_to_cores(local_rank, world):
-    """N ranks share one host: every rank runs a main thread (26 ms of launch work per step), the autograd thread, the
-    pipeline worker and its planner threads.  Each rank gets its own contiguous slice of the cores this process may use
-    (os.sched_setaffinity: threads started later inherit it) and sizes torch's intra-op pool to it, so that the ranks'
-    threads do not migrate onto each other's cores (an all-reduce turns the slowest rank's jitter into everyone's step
-    time).  OADG_BENCH_NO_AFFINITY=1 or a single rank: nothing is pinned.  Returns a description for the JSON line."""
-    if world <= 1 or os.environ.get('OADG_BENCH_NO_AFFINITY') == '1' or not hasattr(os, 'sched_setaffinity'):
+    """oadg_amd.apis.pin_rank_to_cores (a compact set of physical cores per rank: its docstring has the measurements); keeps
+    the full CPU set for the CPU-baseline leg.  OADG_BENCH_NO_AFFINITY=1: nothing is pinned."""
+    if os.environ.get('OADG_BENCH_NO_AFFINITY') == '1':
         return None
-    cores = sorted(os.sched_getaffinity(0))
-    per = len(cores) // world
-    if per < 1:
-        return None
-    mine = cores[local_rank * per:(local_rank + 1) * per]
-    os.sched_setaffinity(0, mine)
-    torch.set_num_threads(max(1, min(per, 16)))
-    return f'{per} of {len(cores)} cores per rank (rank {local_rank}: {mine[0]}-{mine[-1]})'
+    from oadg_amd.apis import pin_rank_to_cores as pin
+    global _FULL_AFFINITY
+    full = set(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+    desc = pin(local_rank, world, int(os.environ.get('OADG_BENCH_CORES_PER_RANK', 8)))
+    if desc is not None:
+        _FULL_AFFINITY = full
+    return desc
 
 
 def self_launch(n):
@@ -604,7 +611,7 @@ def main():
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dev = torch.device('cuda', torch.cuda.current_device())
     if a.workload == 'oamix_stress':
-        return oamix_stress_run(a, rank, distributed, dev)
+        return oamix_stress_run(a, rank, distributed, dev, affinity)
     wl = CONFIGS[a.config]
     global PMC_PREFIX
     PMC_PREFIX = '' if a.config == 'r50_fpn' else 'dc5_'

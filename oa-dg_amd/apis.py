@@ -57,6 +57,53 @@ def set_random_seed(seed, deterministic=False):
         torch.backends.cudnn.benchmark = False
 
 
+def physical_cores(cpus):
+    """one logical CPU per physical core of ``cpus`` (the lowest-numbered hardware thread of each sibling set, from sysfs;
+    without sysfs: every CPU), sorted - a rank's threads should not share a core's two hardware threads with each other or,
+    worse, with another rank (EPYC numbers the second threads of cores 0 .. n-1 as CPUs n .. 2n-1)"""
+    cpus = sorted(cpus)
+    first = {}
+    for c in cpus:
+        try:
+            with open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list') as f:
+                txt = f.read().strip()
+            sib = []
+            for part in txt.split(','):
+                lo, _, hi = part.partition('-')
+                sib += list(range(int(lo), int(hi or lo) + 1))
+            key = min(sib)
+        except (OSError, ValueError):
+            key = c
+        first.setdefault(key, c)
+    return sorted(first.values())
+
+
+def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
+    """Every rank runs a main thread (~20 ms of launch work per step), the autograd thread, the pipeline worker and its
+    planner threads.  Left to the scheduler on a 2 x 64-core host they wander over both sockets: the SAME binary needed
+    18 - 27 ms of host time per step from process to process and the first step after a synchronisation 31 - 35 ms
+    (round 5, five boxes: most of the run-to-run spread of this benchmark).  Pinned to a compact set of cores - one CCD's
+    worth, ``cores_per_rank`` = 8 physical cores, first hardware thread only - it needs 15 - 18 ms every time and the
+    measured step is 27.0 - 27.25 ms instead of 27.1 - 27.6 (29 on some boxes).  The host's physical cores are split into
+    ``world`` contiguous slices (ranks never share a core; on a two-socket node ranks 0 .. N/2-1 stay on socket 0) and a rank
+    takes the first cores of its slice (os.sched_setaffinity: threads started later inherit it); torch's intra-op pool is
+    sized to it.  Used by bench.py and tools/train.py (``--no-cpu-affinity`` / OADG_BENCH_NO_AFFINITY=1: nothing is pinned).
+    Returns a description, or None when nothing was pinned."""
+    if not hasattr(os, 'sched_setaffinity'):
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    phys = physical_cores(cores)
+    per = len(phys) // max(world, 1)
+    if per < 1:
+        return None
+    want = max(1, int(cores_per_rank))
+    mine = phys[local_rank * per:(local_rank + 1) * per][:want]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(len(mine), 16)))
+    return (f'{len(mine)} of {len(phys)} physical cores ({len(cores)} CPUs) per rank, slices of {per} '
+            f'(rank {local_rank}: CPUs {mine[0]}-{mine[-1]})')
+
+
 _SGD_TENSOR = np.dtype([('param', np.uint64), ('grad', np.uint64), ('momentum', np.uint64), ('numel', np.int64),
                         ('first_block', np.int64), ('first_step', np.int32), ('pad', np.int32)])      # oadg_sgd_tensor
 

@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -213,8 +214,12 @@ def test_bench_two_ranks_through_its_own_launch_path_on_gloo():
     assert d['scaling'] == 'weak' and d['config']['global_batch'] == 2 and d['config']['parallelism'] == 'dp2'
     assert d['rccl_ranks'] == 0 and 'PLUMBING' in d['config']['workload']
     assert d['config']['params_equal_across_ranks'] is True
-    ncores = len(os.sched_getaffinity(0))       # every rank pinned to its own slice of the cores (bench.pin_rank_to_cores)
-    assert d['config']['cpu_affinity'].startswith(f'{ncores // 2} of {ncores} cores per rank (rank 0: ')
+    # every rank pinned to a compact set of physical cores inside its own slice of the host (oadg_amd.apis.pin_rank_to_cores)
+    from oadg_amd.apis import physical_cores
+    phys = physical_cores(os.sched_getaffinity(0))
+    mine = phys[:len(phys) // 2][:8]
+    assert d['config']['cpu_affinity'].startswith(f'{len(mine)} of {len(phys)} physical cores ')
+    assert d['config']['cpu_affinity'].endswith(f'slices of {len(phys) // 2} (rank 0: CPUs {mine[0]}-{mine[-1]})')
     assert d['config']['param_tensors_changed'] == d['config']['param_tensors'] > 100
     assert np.isfinite(d['config']['final_loss']) and d['value'] > 0
 
@@ -239,4 +244,16 @@ def test_bench_workloads_and_clock_sampler_without_a_gpu(monkeypatch):
     assert (a.batch, a.height, a.width, a.workload) == (2, 736, 1280, 'train')
     s = bench.ClockSampler(0).start().stop()
     assert s['available'] in (True, False) and ('sclk_mhz' in s or 'note' in s)
-    assert bench.pin_rank_to_cores(0, 1) is None
+    # a single rank is pinned too (a compact set of physical cores: the run-to-run spread of the host time), the CPU-baseline
+    # leg gets every CPU back, and OADG_BENCH_NO_AFFINITY=1 switches it off
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.setenv('OADG_BENCH_NO_AFFINITY', '1')
+        assert bench.pin_rank_to_cores(0, 1) is None and os.sched_getaffinity(0) == before
+        monkeypatch.delenv('OADG_BENCH_NO_AFFINITY')
+        desc = bench.pin_rank_to_cores(0, 1)
+        assert 'physical cores' in desc and len(os.sched_getaffinity(0)) <= 8 and os.sched_getaffinity(0) <= before
+        assert bench.baseline_cores() == len(before) and os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(max(1, min(len(before), 16)))

@@ -58,6 +58,8 @@ def parse_args():
     p.add_argument('--allow-missing-pretrained', action='store_true',
                    help='train from random weights (with a warning) when a configured pretrained / load_from '
                         'checkpoint is not available locally, instead of stopping')
+    p.add_argument('--no-cpu-affinity', action='store_true',
+                   help='do not pin this rank\'s threads to a compact set of physical cores (oadg_amd.apis.pin_rank_to_cores)')
     a = p.parse_args()
     if 'LOCAL_RANK' not in os.environ:
         os.environ['LOCAL_RANK'] = str(a.local_rank)
@@ -95,6 +97,12 @@ def main():
     if distributed:
         init_dist(a.launcher, **cfg.get('dist_params', dict(backend='nccl')))
     rank, world = get_dist_info()
+    if not a.no_cpu_affinity and os.environ.get('OADG_BENCH_NO_AFFINITY') != '1':
+        # a rank's threads on one CCD's worth of cores of its own (local ranks = LOCAL_WORLD_SIZE under torch.distributed.run)
+        from oadg_amd.apis import pin_rank_to_cores
+        aff = pin_rank_to_cores(int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('LOCAL_WORLD_SIZE', 1)))
+        if rank == 0 and aff:
+            print(f'cpu affinity: {aff}', flush=True)
     torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)) % torch.cuda.device_count())
     dev = torch.device('cuda', torch.cuda.current_device())
     os.makedirs(work_dir, exist_ok=True)
