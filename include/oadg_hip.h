@@ -401,8 +401,9 @@ int oadg_prep_conv_weights_bwd_parts(const float* part, int splits, const float*
 /* The weight gradients of SEVERAL layers in one launch (round 4): the small maps of the backbone / neck cannot fill the
  * chip with long workgroups one layer at a time, so a trainer defers them and issues groups.  Host: fill x, dy, N, H, W,
  * C, K, R, S, stride, pad, dil of every job (K % 256 == 0, C % 256 == 0), call oadg_conv2d_wgrad_multi_plan - it fills
- * the remaining fields and returns the length of the workgroup list (<= target_blocks when the group's weight tiles fit;
- * negative = -OADG_E*) -, point part at splits * K * R * S * C floats per job, copy the table to the device, launch.
+ * the remaining fields and returns the length of the workgroup list (target_blocks = the workgroups of one round, i.e. the
+ * compute units; the plan takes a list of 1 - 3 rounds, whichever its simulation of the dispatch finds shortest, or one
+ * workgroup per weight tile when those alone are more; negative = -OADG_E*) -, point part at splits * K * R * S * C floats per job, copy the table to the device, launch.
  * part has the layout of oadg_conv2d_wgrad_parts_nhwc_bf16's workspace; oadg_prep_conv_weights_bwd_parts_multi is the
  * matching consumer (one launch for the group: splits summed in fp32 in a fixed order, BN-fold chain rule, layout
  * change; w_krsc bits as in oadg_prep_conv_weights_bwd_parts; first_block = sum of K over the jobs before). */

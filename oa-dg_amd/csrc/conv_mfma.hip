@@ -15,6 +15,7 @@
 // seg ^ ((row >> 1) & 7) of its 128-byte row, which makes every ds_read_b128 lane group hit 16 distinct
 // 16-byte bank slots.  Algorithmic work: 2*M*K*R*S*C FLOP; HBM bytes: M*C*2 (input, taps re-read from L2) +
 // M*K*2 (output) + K*R*S*C*2 (weights).
+#include <vector>
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -1864,46 +1865,97 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
         const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
         work += (double)tiles * (double)nchunks;
     }
-    // K-tiles per workgroup if the list had exactly target_blocks entries; every job starts with the split count that
-    // stays at or above it, then the job with the longest workgroups takes one more split while the list has room
-    const double per = work / target_blocks;
-    long total = 0;
-    for (int i = 0; i < n; ++i) {
-        oadg_wgrad_job& j = jobs[i];
-        const long nchunks = (j.P + WP - 1) / WP;
-        long sp = per > 0.0 ? (long)((double)nchunks / per) : 1;
-        if (sp < 1) sp = 1;
-        if (sp > nchunks) sp = nchunks;
-        j.splits = (int)sp;
-        total += (long)(j.K / 256) * (j.C / 256) * j.R * j.S * sp;
-    }
-    while (total > target_blocks) {           // (jobs rounded up to one split pushed the list over: take splits back where
-        int best = -1;                        //  the workgroups are shortest)
-        double shortest = 1e300;
+    // Split counts for a list of (about) `target` entries: K-tiles per workgroup if the list had exactly `target` entries;
+    // every job starts with the split count that stays at or above it, then the job with the longest workgroups takes one
+    // more split while the list has room.
+    auto assign = [&](long target, int* sp_out) -> long {
+        const double per = work / (double)target;
+        long total = 0;
         for (int i = 0; i < n; ++i) {
             const oadg_wgrad_job& j = jobs[i];
-            if (j.splits <= 1) continue;
-            const double len = (double)((j.P + WP - 1) / WP) / j.splits;
-            if (len < shortest) { shortest = len; best = i; }
+            const long nchunks = (j.P + WP - 1) / WP;
+            long sp = per > 0.0 ? (long)((double)nchunks / per) : 1;
+            if (sp < 1) sp = 1;
+            if (sp > nchunks) sp = nchunks;
+            sp_out[i] = (int)sp;
+            total += (long)(j.K / 256) * (j.C / 256) * j.R * j.S * sp;
         }
-        if (best < 0) break;
-        jobs[best].splits -= 1;
-        total -= (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
-    }
-    for (;;) {
-        int best = -1;
-        double longest = 0.0;
+        while (total > target) {              // (jobs rounded up to one split pushed the list over: take splits back where
+            int best = -1;                    //  the workgroups are shortest)
+            double shortest = 1e300;
+            for (int i = 0; i < n; ++i) {
+                const oadg_wgrad_job& j = jobs[i];
+                if (sp_out[i] <= 1) continue;
+                const double len = (double)((j.P + WP - 1) / WP) / sp_out[i];
+                if (len < shortest) { shortest = len; best = i; }
+            }
+            if (best < 0) break;
+            sp_out[best] -= 1;
+            total -= (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
+        }
+        for (;;) {
+            int best = -1;
+            double longest = 0.0;
+            for (int i = 0; i < n; ++i) {
+                const oadg_wgrad_job& j = jobs[i];
+                const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
+                if (sp_out[i] >= nchunks || total + tiles > target) continue;
+                const double len = (double)nchunks / sp_out[i];
+                if (len > longest) { longest = len; best = i; }
+            }
+            if (best < 0) break;
+            sp_out[best] += 1;
+            total += (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
+        }
+        return total;
+    };
+    // Round 5: ONE round of <= target_blocks workgroups is not always the shortest launch.  A group with many weight tiles
+    // of few K-tiles each (layer4: 228 tiles of 256 K-tiles + two layers of 1024) has no room to split its long jobs - the
+    // list was 228 entries of 256 K-tiles, 12 of 341 and 16 of 512: the launch lasted 512 K-tiles at an average of 276
+    // (0.95 ms at 622 TFLOP/s where the kernel runs 1100).  So the planner now also tries lists of 1.5 - 3 rounds and keeps
+    // the one whose SIMULATED launch is shortest: the kernel's dispatch replayed on the host - eight XCD slices of the list,
+    // 32 compute units each, a free unit takes the slice's next entry - with an entry costing its K-tiles + 11 (prologue +
+    // partial-tile epilogue, ~20 us at 1.86 us per K-tile) and 0.1 K-tile per entry for the consumer's extra partial tile.
+    // OADG_WGRAD_PLAN_ROUNDS=1: one round only (A/B probes).
+    std::vector<int> sp_best(n), sp_try(n);
+    double best_cost = 1e300;
+    static const bool one_round = getenv("OADG_WGRAD_PLAN_ROUNDS") && atoi(getenv("OADG_WGRAD_PLAN_ROUNDS")) == 1;
+    const int cus_per_xcd = target_blocks >= 8 ? target_blocks / 8 : 1;
+    const double halves[5] = {2, 3, 4, 5, 6};                  // list lengths in half rounds
+    for (int c = 0; c < (one_round ? 1 : 5); ++c) {
+        const long target = (long)(target_blocks * halves[c] / 2);
+        const long total = assign(target, sp_try.data());
+        std::vector<double> len;
+        len.reserve((size_t)total);
         for (int i = 0; i < n; ++i) {
             const oadg_wgrad_job& j = jobs[i];
             const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
-            if (j.splits >= nchunks || total + tiles > target_blocks) continue;
-            const double len = (double)nchunks / j.splits;
-            if (len > longest) { longest = len; best = i; }
+            const long cps = (nchunks + sp_try[i] - 1) / sp_try[i], eff = (nchunks + cps - 1) / cps;
+            for (long sidx = 0; sidx < eff; ++sidx) {
+                const long mine = nchunks - sidx * cps < cps ? nchunks - sidx * cps : cps;
+                for (long t = 0; t < tiles; ++t) len.push_back((double)mine + 11.0);
+            }
         }
-        if (best < 0) break;
-        jobs[best].splits += 1;
-        total += (long)(jobs[best].K / 256) * (jobs[best].C / 256) * jobs[best].R * jobs[best].S;
+        const long cnt = (long)len.size(), per_x = (cnt + 7) / 8;
+        double makespan = 0.0;
+        for (int x = 0; x < 8; ++x) {
+            std::vector<double> cu((size_t)cus_per_xcd, 0.0);
+            for (long w = x * per_x; w < (x + 1) * per_x && w < cnt; ++w) {
+                size_t m = 0;
+                for (size_t u = 1; u < cu.size(); ++u)
+                    if (cu[u] < cu[m]) m = u;
+                cu[m] += len[(size_t)w];
+                if (cu[m] > makespan) makespan = cu[m];
+            }
+        }
+        const double cost = makespan + 0.1 * (double)cnt;
+        if (cost < best_cost * 0.97) {                          // (a longer list has to pay: 3 % at least)
+            best_cost = cost;
+            sp_best = sp_try;
+        }
+        if (total < target) break;                              // every job is split as far as it goes already
     }
+    for (int i = 0; i < n; ++i) jobs[i].splits = sp_best[i];
     long first = 0;
     for (int i = 0; i < n; ++i) {
         oadg_wgrad_job& j = jobs[i];

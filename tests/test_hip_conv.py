@@ -922,7 +922,7 @@ def test_grouped_weight_gradient_launch_matches_single_layer_launches(dev, targe
     """oadg_conv2d_wgrad_multi: the weight gradients of several layers (3x3 / 1x1, stride 2, dilation, maps smaller than
     one 64-pixel K-tile chunk row, a ragged last chunk) from ONE launch, every job with its own split count from
     oadg_conv2d_wgrad_multi_plan.  The summed partials equal the single-layer kernel's result to fp32 rounding and the
-    fp32 reference (same bf16 operands) to 2e-3; ``target`` = the length of the workgroup list the plan aims at (7: fewer
+    fp32 reference (same bf16 operands) to 2e-3; ``target`` = the number of workgroups of ONE round the plan aims at (7: fewer
     than the group's weight tiles - one workgroup per tile)."""
     from oadg_amd import hip_conv
     g = torch.Generator(device=dev).manual_seed(5)
@@ -940,7 +940,7 @@ def test_grouped_weight_gradient_launch_matches_single_layer_launches(dev, targe
     base = ws.data_ptr()
     total = sum((K // 256) * (C // 256) * R * R * sp for (N, C, H, W, K, R, *_), (_, sp) in zip(_WG_SHAPES, parts))
     tiles = sum((K // 256) * (C // 256) * R * R for (N, C, H, W, K, R, *_) in _WG_SHAPES)
-    assert total <= max(target, tiles)
+    assert total <= max(3 * target, tiles)       # (round 5: the plan may take a list of up to three rounds when its simulated launch is shorter)
     if target >= 256:
         assert max(sp for _, sp in parts) > 1
     for (N, C, H, W, K, R, *_), (pp, sp), ref, single in zip(_WG_SHAPES, parts, refs, singles):
