@@ -416,8 +416,11 @@ typedef struct oadg_wgrad_job {
     int Ho, Wo, splits, chunks_per_split, first_block, blocks;      /* plan */
     int strip_rows, pad_;      /* plan: > 0 = a split is this many whole output rows, swept in 64-column strips */
 } oadg_wgrad_job;
-long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs_host, int n, int target_blocks);
-int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const void* zeros16, void* stream);
+/* xcd_first (host, 9 ints, may be NULL): the plan's eight contiguous slices of the list, equal in WORK - XCD x runs the
+ * entries [xcd_first[x], xcd_first[x + 1]); the launch takes the same array (NULL: slices of equal length) */
+long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs_host, int n, int target_blocks, int* xcd_first);
+int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const int* xcd_first, const void* zeros16,
+                            void* stream);
 typedef struct oadg_prep_bwd_job {
     const float *part, *gbias, *w, *scale, *mean, *var;
     float *dw, *dgamma;

@@ -128,8 +128,8 @@ SIGNATURES = {
     'oadg_conv1x1_n16_wgrad_splits': (cl, [cl]),
     'oadg_conv1x1_n16_wgrad_rows': (cl, [cl]),
     'oadg_conv1x1_n16_wgrad': (ci, [vp, vp, vp, vp, vp, cl, ci, vp]),
-    'oadg_conv2d_wgrad_multi_plan': (ctypes.c_long, [vp, ci, ci]),
-    'oadg_conv2d_wgrad_multi': (ci, [vp, ci, ci, vp, vp]),
+    'oadg_conv2d_wgrad_multi_plan': (ctypes.c_long, [vp, ci, ci, vp]),
+    'oadg_conv2d_wgrad_multi': (ci, [vp, ci, ci, vp, vp, vp]),
     'oadg_prep_conv_weights_bwd_parts_multi': (ci, [vp, ci, ci, ci, vp]),
     'oadg_sgd_blocks': (ctypes.c_longlong, [ctypes.c_longlong]),
     'oadg_sgd_step_multi': (ci, [vp, ci, ctypes.c_longlong, cf, cf, cf, vp]),

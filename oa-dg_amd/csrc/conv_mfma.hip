@@ -15,6 +15,7 @@
 // seg ^ ((row >> 1) & 7) of its 128-byte row, which makes every ds_read_b128 lane group hit 16 distinct
 // 16-byte bank slots.  Algorithmic work: 2*M*K*R*S*C FLOP; HBM bytes: M*C*2 (input, taps re-read from L2) +
 // M*K*2 (output) + K*R*S*C*2 (weights).
+#include <algorithm>
 #include <vector>
 #include "common.h"
 #include <type_traits>
@@ -1671,14 +1672,18 @@ __global__ __launch_bounds__(512) void conv_wgrad256_kernel(WgradArgs a) {
 // GROUP as one launch: job j owns the workgroups [first_block_j, first_block_j + tiles_j * splits_j) of one list,
 // splits_j chosen by oadg_conv2d_wgrad_multi_plan so that the list has <= 256 entries of about equal length (>= 64
 // K-tiles each when the group is large enough) - fewer, longer splits: 4-8 partials per weight tile instead of 28-64.
-// XCD x takes the contiguous slice x of the list (as in the single-layer kernel), so the tiles of a pixel range meet in
-// one L2.  The job table lives in device memory; a workgroup finds its job by binary search on first_block (uniform).
+// XCD x takes a contiguous slice of the list (as in the single-layer kernel), so the tiles of a pixel range meet in
+// one L2; the slices hold equal WORK, not equal counts (round 5: a list of several rounds whose long entries sat in one
+// slice kept that XCD busy 40 % longer than the others).  The job table lives in device memory; a workgroup finds its job by binary search on first_block (uniform).
+struct XcdSlices {
+    int first[9];        // XCD x runs the list entries [first[x], first[x + 1])
+};
+
 __global__ __launch_bounds__(512) void conv_wgrad256_multi_kernel(const oadg_wgrad_job* __restrict__ jobs, int n_jobs,
-                                                                  int total, const unsigned short* zeros) {
+                                                                  XcdSlices xs, const unsigned short* zeros) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int per = (total + 7) >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, w = xcd * per + slot;
-    if (slot >= per || w >= total) return;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, w = xs.first[xcd] + slot;
+    if (w >= xs.first[xcd + 1]) return;
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -1850,7 +1855,7 @@ extern "C" int oadg_conv2d_wgrad_parts_nhwc_bf16(const void* x, const void* dy, 
 // length of the workgroup list (<= target_blocks whenever the group's weight tiles fit, else one workgroup per tile), or
 // a negative OADG_E* code.  The caller then points part at splits * K * R * S * C floats per job, copies the table to the
 // device and launches.  Every job must be a shape the 256-tile kernel covers (K % 256 == 0, C % 256 == 0).
-extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int target_blocks) {
+extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int target_blocks, int* xcd_first) {
     if (!jobs || n < 1 || target_blocks < 1) return -(long)OADG_EARG;
     double work = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -1917,10 +1922,45 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
     // 32 compute units each, a free unit takes the slice's next entry - with an entry costing its K-tiles + 11 (prologue +
     // partial-tile epilogue, ~20 us at 1.86 us per K-tile) and 0.1 K-tile per entry for the consumer's extra partial tile.
     // OADG_WGRAD_PLAN_ROUNDS=1: one round only (A/B probes).
+    // Eight contiguous slices of the list, one per XCD (its compute units take the slice's entries in order, a free unit
+    // the next one): the partition with the shortest simulated launch - greedy filling is optimal for a contiguous
+    // partition under a time limit, the limit is found by bisection.  Returns that launch length (in K-tiles).
+    const int cus_per_xcd = target_blocks >= 8 ? target_blocks / 8 : 1;
+    auto slices = [cus_per_xcd](const std::vector<double>& len, long* fx) -> double {
+        const long cnt = (long)len.size();
+        auto fill = [&](double limit, long* out) -> bool {
+            long w = 0;
+            std::vector<double> cu((size_t)cus_per_xcd);
+            for (int x = 0; x < 8; ++x) {
+                out[x] = w;
+                std::fill(cu.begin(), cu.end(), 0.0);
+                while (w < cnt) {
+                    size_t m = 0;
+                    for (size_t u = 1; u < cu.size(); ++u)
+                        if (cu[u] < cu[m]) m = u;
+                    if (cu[m] + len[(size_t)w] > limit) break;
+                    cu[m] += len[(size_t)w++];
+                }
+            }
+            out[8] = w;
+            return w == cnt;
+        };
+        double lo = 0.0, hi = 0.0, tot = 0.0;
+        for (double v : len) { tot += v; lo = v > lo ? v : lo; }
+        hi = tot + 1.0;                                   // (one unit running everything: always feasible)
+        lo = lo > tot / (8.0 * cus_per_xcd) ? lo : tot / (8.0 * cus_per_xcd);
+        long tmp[9];
+        if (fill(lo, tmp)) hi = lo;
+        for (int it = 0; it < 40 && hi - lo > 0.5; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (fill(mid, tmp)) hi = mid; else lo = mid;
+        }
+        fill(hi, fx);
+        return hi;
+    };
     std::vector<int> sp_best(n), sp_try(n);
     double best_cost = 1e300;
     static const bool one_round = getenv("OADG_WGRAD_PLAN_ROUNDS") && atoi(getenv("OADG_WGRAD_PLAN_ROUNDS")) == 1;
-    const int cus_per_xcd = target_blocks >= 8 ? target_blocks / 8 : 1;
     const double halves[5] = {2, 3, 4, 5, 6};                  // list lengths in half rounds
     for (int c = 0; c < (one_round ? 1 : 5); ++c) {
         const long target = (long)(target_blocks * halves[c] / 2);
@@ -1936,19 +1976,11 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
                 for (long t = 0; t < tiles; ++t) len.push_back((double)mine + 11.0);
             }
         }
-        const long cnt = (long)len.size(), per_x = (cnt + 7) / 8;
-        double makespan = 0.0;
-        for (int x = 0; x < 8; ++x) {
-            std::vector<double> cu((size_t)cus_per_xcd, 0.0);
-            for (long w = x * per_x; w < (x + 1) * per_x && w < cnt; ++w) {
-                size_t m = 0;
-                for (size_t u = 1; u < cu.size(); ++u)
-                    if (cu[u] < cu[m]) m = u;
-                cu[m] += len[(size_t)w];
-                if (cu[m] > makespan) makespan = cu[m];
-            }
-        }
+        const long cnt = (long)len.size();
+        long fx[9];
+        const double makespan = slices(len, fx);
         const double cost = makespan + 0.1 * (double)cnt;
+        if (getenv("OADG_WGRAD_PLAN_DEBUG")) fprintf(stderr, "plan: target %ld entries %ld makespan %.0f cost %.0f\n", target, cnt, makespan, cost);
         if (cost < best_cost * 0.97) {                          // (a longer list has to pay: 3 % at least)
             best_cost = cost;
             sp_best = sp_try;
@@ -1969,11 +2001,27 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
         first += j.blocks;
         if (first > 0x3fffffffL) return -(long)OADG_EARG;
     }
+    if (xcd_first) {
+        std::vector<double> len;
+        len.reserve((size_t)first);
+        for (int i = 0; i < n; ++i) {
+            const oadg_wgrad_job& j = jobs[i];
+            const long tiles = (long)(j.K / 256) * (j.C / 256) * j.R * j.S, nchunks = (j.P + WP - 1) / WP;
+            for (long sidx = 0; sidx < j.splits; ++sidx) {
+                const long mine = nchunks - sidx * j.chunks_per_split < j.chunks_per_split ? nchunks - sidx * j.chunks_per_split
+                                                                                             : j.chunks_per_split;
+                for (long t = 0; t < tiles; ++t) len.push_back((double)mine + 11.0);
+            }
+        }
+        long fx[9];
+        slices(len, fx);
+        for (int x = 0; x < 9; ++x) xcd_first[x] = (int)fx[x];
+    }
     return first;
 }
 
-extern "C" int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const void* zeros16,
-                                       void* stream) {
+extern "C" int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, int total_blocks, const int* xcd_first,
+                                       const void* zeros16, void* stream) {
     if (!jobs_dev || n < 1 || total_blocks < 1 || !zeros16) return OADG_EARG;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1982,9 +2030,19 @@ extern "C" int oadg_conv2d_wgrad_multi(const oadg_wgrad_job* jobs_dev, int n, in
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const unsigned blocks = (unsigned)(((total_blocks + 7) / 8) * 8);         // eight equal XCD slices
-    hipLaunchKernelGGL(conv_wgrad256_multi_kernel, dim3(blocks), dim3(512), 2 * BUF_BYTES, (hipStream_t)stream, jobs_dev, n,
-                       total_blocks, (const unsigned short*)zeros16);
+    XcdSlices xs;
+    int longest = 0;
+    for (int x = 0; x <= 8; ++x) {
+        // (host array from the plan; NULL: eight slices of equal length)
+        xs.first[x] = xcd_first ? xcd_first[x] : (int)((long)((total_blocks + 7) / 8) * x < total_blocks ? ((total_blocks + 7) / 8) * x : total_blocks);
+        if (x > 0) {
+            if (xs.first[x] < xs.first[x - 1]) return OADG_EARG;
+            longest = xs.first[x] - xs.first[x - 1] > longest ? xs.first[x] - xs.first[x - 1] : longest;
+        }
+    }
+    if (xs.first[0] != 0 || xs.first[8] != total_blocks) return OADG_EARG;
+    hipLaunchKernelGGL(conv_wgrad256_multi_kernel, dim3((unsigned)longest * 8), dim3(512), 2 * BUF_BYTES, (hipStream_t)stream,
+                       jobs_dev, n, xs, (const unsigned short*)zeros16);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

@@ -324,7 +324,8 @@ def wgrad_multi(jobs, target_blocks=256):
         r['x'], r['dy'] = x16.data_ptr(), gy16.data_ptr()
         r['N'], r['H'], r['W'], r['C'], r['K'], r['R'], r['S'] = N, H, W, C, K, R, S
         r['stride'], r['pad'], r['dil'] = stride, pad, dil
-    total = L.oadg_conv2d_wgrad_multi_plan(tab.ctypes.data_as(ctypes.c_void_p), len(jobs), int(target_blocks))
+    xcd_first = (ctypes.c_int * 9)()        # the list's eight XCD slices (equal work)
+    total = L.oadg_conv2d_wgrad_multi_plan(tab.ctypes.data_as(ctypes.c_void_p), len(jobs), int(target_blocks), xcd_first)
     if total <= 0:
         raise RuntimeError(f'oadg_conv2d_wgrad_multi_plan failed (code {-total})')
     sizes = [int(r['splits']) * int(r['K']) * int(r['R']) * int(r['S']) * int(r['C']) * 4 for r in tab]
@@ -344,7 +345,7 @@ def wgrad_multi(jobs, target_blocks=256):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     tdev = _TABLES.upload(tab, dev)
-    check(L.oadg_conv2d_wgrad_multi(ptr(tdev), len(jobs), int(total), ptr(_zeros(dev)), stream_ptr()),
+    check(L.oadg_conv2d_wgrad_multi(ptr(tdev), len(jobs), int(total), xcd_first, ptr(_zeros(dev)), stream_ptr()),
           'oadg_conv2d_wgrad_multi')
     if name:
         e1 = torch.cuda.Event(enable_timing=True)
