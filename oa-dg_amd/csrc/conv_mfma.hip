@@ -1928,19 +1928,27 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
     const int cus_per_xcd = target_blocks >= 8 ? target_blocks / 8 : 1;
     auto slices = [cus_per_xcd](const std::vector<double>& len, long* fx) -> double {
         const long cnt = (long)len.size();
-        auto fill = [&](double limit, long* out) -> bool {
+        // even = true: an XCD also stops at its share of the work that is left (same limit, later XCDs not left idle)
+        auto fill = [&](double limit, long* out, bool even) -> bool {
             long w = 0;
+            double left = 0.0;
+            for (double v : len) left += v;
             std::vector<double> cu((size_t)cus_per_xcd);
             for (int x = 0; x < 8; ++x) {
                 out[x] = w;
                 std::fill(cu.begin(), cu.end(), 0.0);
+                const double share = left / (8 - x);
+                double mine = 0.0;
                 while (w < cnt) {
+                    if (even && mine >= share) break;
                     size_t m = 0;
                     for (size_t u = 1; u < cu.size(); ++u)
                         if (cu[u] < cu[m]) m = u;
                     if (cu[m] + len[(size_t)w] > limit) break;
-                    cu[m] += len[(size_t)w++];
+                    cu[m] += len[(size_t)w];
+                    mine += len[(size_t)w++];
                 }
+                left -= mine;
             }
             out[8] = w;
             return w == cnt;
@@ -1950,12 +1958,12 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
         hi = tot + 1.0;                                   // (one unit running everything: always feasible)
         lo = lo > tot / (8.0 * cus_per_xcd) ? lo : tot / (8.0 * cus_per_xcd);
         long tmp[9];
-        if (fill(lo, tmp)) hi = lo;
+        if (fill(lo, tmp, false)) hi = lo;
         for (int it = 0; it < 40 && hi - lo > 0.5; ++it) {
             const double mid = 0.5 * (lo + hi);
-            if (fill(mid, tmp)) hi = mid; else lo = mid;
+            if (fill(mid, tmp, false)) hi = mid; else lo = mid;
         }
-        fill(hi, fx);
+        if (!fill(hi, fx, true)) fill(hi, fx, false);
         return hi;
     };
     std::vector<int> sp_best(n), sp_try(n);
@@ -1985,7 +1993,9 @@ extern "C" long oadg_conv2d_wgrad_multi_plan(oadg_wgrad_job* jobs, int n, int ta
             best_cost = cost;
             sp_best = sp_try;
         }
-        if (total < target) break;                              // every job is split as far as it goes already
+        bool saturated = true;                                  // every job is split as far as it goes already
+        for (int i = 0; i < n; ++i) saturated = saturated && sp_try[i] >= (jobs[i].P + WP - 1) / WP;
+        if (saturated) break;
     }
     for (int i = 0; i < n; ++i) jobs[i].splits = sp_best[i];
     long first = 0;
