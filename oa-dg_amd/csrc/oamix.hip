@@ -326,13 +326,25 @@ __global__ void rect_copy_kernel(uint8_t* __restrict__ img, int W, int rx0, int 
 // or vice versa), so all boxes of one level may be blended concurrently and the reference's sequential result is kept
 // bit for bit.  Workgroup b of a level's launch owns 256 consecutive pixels of one box's rect (binary search of its
 // global tile number in the prefix `tile_prefix`).
+// (round 5: the workgroup's 256 threads look at 256 prefix entries at ONCE - the prefix is ascending, so the step is the
+//  number of entries <= tile, minus one: one memory round trip and a ballot instead of log2(count) DEPENDENT loads at the
+//  head of a kernel whose whole life is a chain of five round trips.  Every thread of the 256-thread block must call it.)
 __device__ __forceinline__ int find_step(const int* __restrict__ tile_prefix, int first, int count, int tile) {
-    int lo = first, hi = first + count - 1;        // last step whose prefix <= tile
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tile_prefix[mid] <= tile) lo = mid; else hi = mid - 1;
+    __shared__ int below_sh[4];
+    const int wave = threadIdx.x >> 6;
+    int below = 0;
+    for (int base = 0; base < count; base += 256) {
+        const int j = base + (int)threadIdx.x;
+        const bool le = j < count && tile_prefix[first + j] <= tile;
+        const unsigned long long m = __ballot(le);
+        if ((threadIdx.x & 63) == 0) below_sh[wave] = __popcll(m);
+        __syncthreads();
+        const int c = below_sh[0] + below_sh[1] + below_sh[2] + below_sh[3];
+        __syncthreads();
+        below += c;
+        if (c < 256) break;                        // (uniform) the prefix passed `tile` inside this chunk
     }
-    return lo;
+    return first + below - 1;                      // last step whose prefix <= tile (tile_prefix[first] <= tile always)
 }
 
 // 8 source bytes = the two horizontally adjacent taps (3 + 3 bytes) of one source row in ONE unaligned 8-byte load
