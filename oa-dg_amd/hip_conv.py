@@ -224,7 +224,10 @@ def flush_colsums():
 # launches fill later - the same arrangement, with the same aliasing rules, as the deferred column sums above.
 DEFER_WGRAD = False
 WGRAD_SMALL = int(os.environ.get('OADG_WGRAD_SMALL', 40000))        # weight tiles x K-tiles below which a layer is deferred
-WGRAD_GROUP = int(os.environ.get('OADG_WGRAD_GROUP', 65536))        # ... and the sum at which a group is launched
+# ... and the sum at which a group is launched.  Round 5: 65536 -> 196608 - with lists of several rounds (the planner's dispatch
+# replay) a larger group packs better and pays fewer launch tails: 27.3 -> 27.0 ms per step (131072: 27.1, 262144: 27.5 - a
+# list of more than three rounds is not planned), R101-DC5 18.4 -> 18.0
+WGRAD_GROUP = int(os.environ.get('OADG_WGRAD_GROUP', 196608))
 _WQ = []
 _WQ_WORK = 0
 SHARED_GROUP = os.environ.get('OADG_WGRAD_SHARED', '1') == '1'      # the uses of a shared weight as ONE grouped launch
