@@ -78,6 +78,52 @@ def physical_cores(cpus):
     return sorted(first.values())
 
 
+def _cpu_busy_jiffies():
+    """{cpu id: busy jiffies since boot} from /proc/stat (user + nice + system + irq + softirq + steal)"""
+    out = {}
+    try:
+        with open('/proc/stat') as f:
+            for line in f:
+                if line.startswith('cpu') and line[3:4].isdigit():
+                    p = line.split()
+                    v = [int(t) for t in p[1:9]]
+                    out[int(p[0][3:])] = v[0] + v[1] + v[2] + v[5] + v[6] + v[7]
+    except (OSError, ValueError):
+        return {}
+    return out
+
+
+def quietest_window(cores, want, probe_s=0.1):
+    """index of the window of ``want`` consecutive entries of ``cores`` (physical cores, aligned to multiples of ``want`` -
+    a CCD) that was least busy over the next ``probe_s`` seconds, both hardware threads counted; 0 when /proc/stat cannot
+    tell.  OADG_AFFINITY_PROBE=0: always the first window."""
+    if os.environ.get('OADG_AFFINITY_PROBE', '1') != '1':
+        return 0
+    a = _cpu_busy_jiffies()
+    if not a:
+        return 0
+    time.sleep(probe_s)
+    b = _cpu_busy_jiffies()
+    sib = {}
+    for c in cores:
+        try:
+            with open(f'/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list') as f:
+                txt = f.read().strip()
+            ids = []
+            for part in txt.split(','):
+                lo, _, hi = part.partition('-')
+                ids += list(range(int(lo), int(hi or lo) + 1))
+            sib[c] = ids
+        except (OSError, ValueError):
+            sib[c] = [c]
+    busy = [(sum(b.get(t, 0) - a.get(t, 0) for c in cores[s0:s0 + want] for t in sib[c]), s0)
+            for s0 in range(0, len(cores) - want + 1, want)]
+    floor = min(v for v, _ in busy)
+    # the FIRST window that is (nearly) as quiet as the quietest: 3 jiffies = 30 ms of CPU time in the probe over the
+    # window's hardware threads is noise; early windows keep a single rank on socket 0 unless it is occupied
+    return next(s0 for v, s0 in busy if v <= floor + 3)
+
+
 def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
     """Every rank runs a main thread (~20 ms of launch work per step), the autograd thread, the pipeline worker and its
     planner threads.  Left to the scheduler on a 2 x 64-core host they wander over both sockets: the SAME binary needed
@@ -97,7 +143,12 @@ def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
     if per < 1:
         return None
     want = max(1, int(cores_per_rank))
-    mine = phys[local_rank * per:(local_rank + 1) * per][:want]
+    mine_slice = phys[local_rank * per:(local_rank + 1) * per]
+    # which `want` consecutive cores of the slice?  The quietest ones: another tenant of the host may be sitting on the first
+    # ones (a pinned rank cannot walk away from a noisy neighbour: the same box measured 27.2 - 29.9 ms per step while
+    # something else ran on CPUs 0-7) - 100 ms of /proc/stat decide.
+    start = quietest_window(mine_slice, want) if len(mine_slice) > want else 0
+    mine = mine_slice[start:start + want]
     os.sched_setaffinity(0, mine)
     torch.set_num_threads(max(1, min(len(mine), 16)))
     return (f'{len(mine)} of {len(phys)} physical cores ({len(cores)} CPUs) per rank, slices of {per} '
