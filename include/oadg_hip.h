@@ -690,8 +690,9 @@ int oadg_roi_targets_dev(const oadg_roi_target_entry* entries_host, int n_entrie
  *          mmdet/core/bbox/samplers/base_sampler.py:38-103, random_sampler.py:32-82 (torch.randperm(n)[:k] on the CPU
  *          generator: ATen randperm_cpu = forward Fisher-Yates on mt19937 outputs)
  * images_host [B] (HOST array, device pointers inside): gt_inds [n] int64 = the image's assignment with the gts added as
- * proposals in front (> 0 positive, 0 negative, < 0 ignored), n <= oadg_roi_sample_max_rows().  mt_state (device,
- * in/out) [626] uint32 = at::mt19937 state words [624], left, next.  Outputs: sel [B][num] int64 = per image the sorted
+ * proposals in front (> 0 positive, 0 negative, < 0 ignored), n <= oadg_roi_sample_max_rows().  mt_state (device, in,
+ * never written) [626] uint32 = at::mt19937 state words [624], left, next; mt_state_out (device, a DIFFERENT buffer)
+ * [626] = the advanced state (every workgroup of the launch reads mt_state in no defined order).  Outputs: sel [B][num] int64 = per image the sorted
  * positive indices, then the sorted negative indices; counts [B][2] = k_pos, k_neg; flags [B]: bit 0 = fewer than num rows
  * sampled (the fixed-capacity layout has padding rows), bit 1 = image outside the kernel's domain (nothing sampled). */
 typedef struct oadg_roi_sample_image {
@@ -700,7 +701,8 @@ typedef struct oadg_roi_sample_image {
 } oadg_roi_sample_image;
 int oadg_roi_sample_max_rows(void);
 int oadg_roi_sample_device(const oadg_roi_sample_image* images_host, int B, int num, int num_pos_exp, float neg_pos_ub,
-                           uint32_t* mt_state, int64_t* sel, int* counts, int* flags, void* stream);
+                           const uint32_t* mt_state, uint32_t* mt_state_out, int64_t* sel, int* counts, int* flags,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp32 convolution on the fp32 matrix cores (exact fp32 FMA chains) - the fp32 PARITY path (csrc/conv_f32.hip)

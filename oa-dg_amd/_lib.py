@@ -142,7 +142,7 @@ SIGNATURES = {
     'oadg_roi_targets': (ci, [vp, ci, ci, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_roi_targets_dev': (ci, [vp, ci, ci, ci, vp, c_int64, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'oadg_roi_sample_max_rows': (ci, []),
-    'oadg_roi_sample_device': (ci, [vp, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
+    'oadg_roi_sample_device': (ci, [vp, ci, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     'oadg_conv2d_f32': (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]),
     'oadg_conv2d_wgrad_f32_splits': (ci, [ci, ci, ci, ci, ci, ci, ci]),
     'oadg_conv2d_wgrad_f32': (ci, [vp, vp, vp, vp, cs, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]),

@@ -143,13 +143,20 @@ def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
     if per < 1:
         return None
     want = max(1, int(cores_per_rank))
+    # (LOCAL_RANK set without LOCAL_WORLD_SIZE gives local_rank >= world: wrap around instead of an empty slice)
+    local_rank = int(local_rank) % max(world, 1)
     mine_slice = phys[local_rank * per:(local_rank + 1) * per]
     # which `want` consecutive cores of the slice?  The quietest ones: another tenant of the host may be sitting on the first
     # ones (a pinned rank cannot walk away from a noisy neighbour: the same box measured 27.2 - 29.9 ms per step while
     # something else ran on CPUs 0-7) - 100 ms of /proc/stat decide.
     start = quietest_window(mine_slice, want) if len(mine_slice) > want else 0
     mine = mine_slice[start:start + want]
-    os.sched_setaffinity(0, mine)
+    if not mine:
+        return None
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:                  # (a cpuset that changed under us, a container that forbids it: run unpinned)
+        return None
     torch.set_num_threads(max(1, min(len(mine), 16)))
     return (f'{len(mine)} of {len(phys)} physical cores ({len(cores)} CPUs) per rank, slices of {per} '
             f'(rank {local_rank}: CPUs {mine[0]}-{mine[-1]})')
@@ -386,6 +393,7 @@ class FlatGradReducer:
         self._hooks = []
         if hip_ops.GRAD_SINK is self.views:
             hip_ops.GRAD_SINK = None
+        hip_ops.sink_reset()
 
     @staticmethod
     def _dense(t):
@@ -472,6 +480,8 @@ class FlatGradReducer:
         self.steps += 1
         for p in self.params:
             p.grad = self.views[p]
+        from . import hip_ops
+        hip_ops.sink_reset()
 
 
 class TrainEngine:
@@ -537,6 +547,12 @@ class TrainEngine:
             t.record_stream(caller)
         return out
 
+    def _lockstep_world(self):
+        """number of ranks that step together (their collectives must match call for call)"""
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.reducer.group if self.reducer is not None else None)
+
     def _foreign_grad_hooks(self):
         """Deferred weight gradients / column sums hand AccumulateGrad tensors that are FILLED LATER (hip_conv.flush_deferred):
         a tensor hook or post-accumulate hook of someone else's would read them too early.  With such a hook on
@@ -563,7 +579,8 @@ class TrainEngine:
         # (torch DDP copies gradients into its buckets from autograd hooks: nothing may be pending there)
         hip_conv.begin_step(defer=self.amp_dtype is torch.bfloat16 and self.ddp is None and not self._foreign_grad_hooks())
         if speculate:
-            _bbox.begin_speculation()
+            _bbox.begin_speculation(group=self.reducer.group if self.reducer is not None else None,
+                                    collective=self._lockstep_world() > 1)
         try:
             (loss, log_vars), n = self.forward_losses(data)
             with _rf('sec:backward'):
@@ -585,20 +602,32 @@ class TrainEngine:
         # step's forward pass (the rest of the step is queued behind it - the device never idles on it).  A short image
         # (fewer candidates than `num`: a handful of proposals survived the NMS) repeats the step through the host path
         # from the saved generator states - same draws, same result as if it had run there in the first place.
-        speculate = self.speculative_sampling and self.ddp is None and next(self.module.parameters()).is_cuda
-        saved = (torch.get_rng_state(), np.random.get_state()) if speculate else None
+        # (more than one rank: the repeat decision is shared through a device-side all-reduce of the flags, which only the
+        #  RCCL backend can do on device memory without a host round trip - any other backend draws on the host)
+        speculate = self.speculative_sampling and self.ddp is None and next(self.module.parameters()).is_cuda and \
+            (self._lockstep_world() == 1 or dist.get_backend(self.reducer.group if self.reducer is not None else None) == 'nccl')
+        # (saved for a repeat: torch's CPU generator, numpy's and python's global streams, the device generator.  Module
+        #  buffers need no saving: every BatchNorm of the named configs is frozen / eval - train-mode statistics of a custom
+        #  model WOULD be updated twice by a repeated step)
+        saved = (torch.get_rng_state(), np.random.get_state(), random.getstate(),
+                 torch.cuda.get_rng_state(next(self.module.parameters()).device)) if speculate else None
         # (integrate_data merges the views into the dict it is given, base.py:22-48: the first pass works on a copy so that
         #  a repeat starts from the batch as it was handed in)
         first = {k: (list(v) if isinstance(v, list) else v) for k, v in data.items()} if speculate else data
         loss, log_vars, n, recs = self._forward_backward(first, speculate)
         short = False
         for r in recs:
-            r['gen'].sync_host()         # (also brings torch's CPU generator up to date with the device's draws)
+            if r['gen'] is not None:
+                r['gen'].sync_host()     # (also brings torch's CPU generator up to date with the device's draws)
+            else:
+                r['event'].synchronize()  # (a call this rank drew on the host: only the shared flags travel)
             short = short or bool(r['meta'][2 * r['B']:].any())
         if short:
             self.respeculated += 1
             torch.set_rng_state(saved[0])
             np.random.set_state(saved[1])
+            random.setstate(saved[2])
+            torch.cuda.set_rng_state(saved[3], next(self.module.parameters()).device)
             loss, log_vars, n, _ = self._forward_backward(data, False)
         elif first is not data:          # the caller's dict ends up merged, as train_step leaves it (base.py:22-48)
             data.clear()

@@ -347,9 +347,16 @@ DEVICE_SAMPLER = os.environ.get('OADG_DEVICE_SAMPLER', '1') == '1'
 _SPEC = None
 
 
-def begin_speculation():
-    global _SPEC
+_SPEC_GROUP = None          # the process group whose ranks must take the same repeat decision (None: single process)
+
+
+def begin_speculation(group=None, collective=False):
+    """``collective``: more than one rank steps in lockstep - the flags of every sampler call are all-reduced (MAX) over
+    ``group`` so that all ranks repeat a step together; EVERY rank must then issue that collective for every call,
+    whatever its own data looks like (see _finish_device)."""
+    global _SPEC, _SPEC_GROUP
     _SPEC = [] if DEVICE_SAMPLER else None
+    _SPEC_GROUP = (group, True) if collective else None
 
 
 def end_speculation():
@@ -509,12 +516,24 @@ class PendingSampling:
         L = _lib.lib()
         images = (_lib.RoiSampleImage * B)()
         max_rows = L.oadg_roi_sample_max_rows()
+        dev = self.prepared[0][1].device
+        import torch.distributed as dist
         for i, prep in enumerate(self.prepared):
             gi = prep[0].gt_inds
             if not (gi.is_cuda and gi.dtype == torch.long and gi.is_contiguous() and gi.numel() <= max_rows):
+                # data-dependent: the other ranks may be eligible and will issue the flags collective - take part in it
+                # with "outside the domain" flags (every rank then repeats the step on the host path) and draw on the host
+                if _SPEC_GROUP is not None:
+                    meta = torch.zeros(3 * B, dtype=torch.int32, device=dev)
+                    meta[2 * B:] = 2
+                    dist.all_reduce(meta[2 * B:], op=dist.ReduceOp.MAX, group=_SPEC_GROUP[0])
+                    host = torch.empty(3 * B, dtype=torch.int32).pin_memory()
+                    host.copy_(meta, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    _SPEC.append(dict(meta=host, B=B, gen=None, event=ev))
                 return None
             images[i].gt_inds, images[i].n = gi.data_ptr(), gi.numel()
-        dev = self.prepared[0][1].device
         num = int(sampler.num)
         sel = torch.empty((B, num), dtype=torch.long, device=dev)
         meta = torch.empty(3 * B, dtype=torch.int32, device=dev)          # counts [B][2] | flags [B]
@@ -522,14 +541,13 @@ class PendingSampling:
         gen = device_rng.generator(dev)
         if gen.pending():
             gen.sync_host()
-        state = gen.upload()
+        state, state_out = gen.upload()
         _lib.check(L.oadg_roi_sample_device(ctypes.cast(images, ctypes.c_void_p), B, num, int(num * sampler.pos_fraction),
-                                            float(sampler.neg_pos_ub), _lib.ptr(state), _lib.ptr(sel), _lib.ptr(counts),
+                                            float(sampler.neg_pos_ub), _lib.ptr(state), _lib.ptr(state_out), _lib.ptr(sel), _lib.ptr(counts),
                                             _lib.ptr(flags), _lib.stream_ptr()), 'oadg_roi_sample_device')
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() == 'nccl':
+        if _SPEC_GROUP is not None:
             # every rank must take the same decision about repeating the step (its collectives): share the flags
-            dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=_SPEC_GROUP[0])
         host = torch.empty(3 * B, dtype=torch.int32).pin_memory()
         host.copy_(meta, non_blocking=True)
         gen.download_async()                      # (its event also covers the copy above: same stream)

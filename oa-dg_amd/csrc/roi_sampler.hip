@@ -32,7 +32,8 @@ struct RoiSampleArgs {
     int n[RS_MAX_IMAGES];
     int B, num, num_pos_exp;
     float neg_pos_ub;
-    unsigned* mt;              // [626]: state[624], left, next
+    const unsigned* mt;        // [626]: state[624], left, next - read-only for the whole launch
+    unsigned* mt_out;          // [626]: the advanced state (written by the last image's workgroup only)
     long long* sel;            // [B][num]
     int* counts;               // [B][2] = k_pos, k_neg
     int* flags;                // [B]: bit 0 = fewer than num rows sampled, bit 1 = image larger than RS_MAXN (nothing sampled)
@@ -128,6 +129,10 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const RoiSampleArgs a) 
     __syncthreads();
     if (too_big || a.num > 512) {                   // outside this kernel's domain: the trainer takes the host path
         if (tid == 0) { a.flags[img] = 3; a.counts[img * 2] = 0; a.counts[img * 2 + 1] = 0; }
+        // (too_big covers images 0 .. img: the last workgroup sees every image - nothing is drawn, the state goes back as
+        //  it came)
+        if (img == a.B - 1)
+            for (int i = tid; i < MT_N + 2; i += 256) a.mt_out[i] = a.mt[i];
         return;
     }
     // ---- the plan of every image up to this one (base_sampler.py:71-100), uniform
@@ -177,8 +182,9 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const RoiSampleArgs a) 
         int nl, nx;
         if (reloads == 0) { nl = left - (int)total; nx = next + (int)total; }
         else { const int u = (int)(total - g0); nl = MT_N - u + 1; nx = u; }
-        for (int i = tid; i < MT_N; i += 256) a.mt[i] = s[i];
-        if (tid == 0) { a.mt[MT_N] = (unsigned)nl; a.mt[MT_N + 1] = (unsigned)nx; }
+        // (into its OWN buffer: the other workgroups of this launch read a.mt in no defined order)
+        for (int i = tid; i < MT_N; i += 256) a.mt_out[i] = s[i];
+        if (tid == 0) { a.mt_out[MT_N] = (unsigned)nl; a.mt_out[MT_N + 1] = (unsigned)nx; }
     }
 
     // ---- per class: Fisher-Yates prefix on the candidate ranks, then the chosen candidates in index order
@@ -239,10 +245,10 @@ __global__ __launch_bounds__(256) void roi_sample_kernel(const RoiSampleArgs a) 
 extern "C" int oadg_roi_sample_max_rows(void) { return RS_MAXN; }
 
 extern "C" int oadg_roi_sample_device(const oadg_roi_sample_image* images_host, int B, int num, int num_pos_exp,
-                                      float neg_pos_ub, uint32_t* mt_state, int64_t* sel, int* counts, int* flags,
-                                      void* stream) {
-    if (!images_host || B < 1 || B > RS_MAX_IMAGES || num < 1 || num_pos_exp < 0 || num_pos_exp > num || !mt_state || !sel ||
-        !counts || !flags)
+                                      float neg_pos_ub, const uint32_t* mt_state, uint32_t* mt_state_out, int64_t* sel,
+                                      int* counts, int* flags, void* stream) {
+    if (!images_host || B < 1 || B > RS_MAX_IMAGES || num < 1 || num_pos_exp < 0 || num_pos_exp > num || !mt_state ||
+        !mt_state_out || mt_state_out == mt_state || !sel || !counts || !flags)
         return OADG_EARG;
     RoiSampleArgs a;
     for (int i = 0; i < RS_MAX_IMAGES; ++i) { a.gt[i] = nullptr; a.n[i] = 0; }
@@ -252,7 +258,7 @@ extern "C" int oadg_roi_sample_device(const oadg_roi_sample_image* images_host, 
         a.n[i] = images_host[i].n;
     }
     a.B = B; a.num = num; a.num_pos_exp = num_pos_exp; a.neg_pos_ub = neg_pos_ub;
-    a.mt = mt_state; a.sel = (long long*)sel; a.counts = counts; a.flags = flags;
+    a.mt = mt_state; a.mt_out = mt_state_out; a.sel = (long long*)sel; a.counts = counts; a.flags = flags;
     hipLaunchKernelGGL(roi_sample_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     OADG_LAUNCH_CHECK();
     return OADG_OK;

@@ -38,7 +38,9 @@ class DeviceGenerator:
 
     def __init__(self, device):
         self.device = device
-        self.state = torch.empty(_WORDS, dtype=torch.int32, device=device)
+        # [0] = the state handed to the kernel (read-only for its whole launch), [1] = the state it leaves
+        self._both = torch.empty((2, _WORDS), dtype=torch.int32, device=device)
+        self.state, self.state_out = self._both[0], self._both[1]
         self._up = torch.empty(_WORDS, dtype=torch.int32).pin_memory()
         self._down = torch.empty(_WORDS, dtype=torch.int32).pin_memory()
         self._event = None            # fires when the advanced state has landed in ``_down``
@@ -51,11 +53,11 @@ class DeviceGenerator:
         self._up.numpy()[:] = _pack(st).view(np.int32)
         self.state.copy_(self._up, non_blocking=True)
         self._base = st
-        return self.state
+        return self.state, self.state_out
 
     def download_async(self):
         """device -> pinned host buffer behind the kernels enqueued so far"""
-        self._down.copy_(self.state, non_blocking=True)
+        self._down.copy_(self.state_out, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
 

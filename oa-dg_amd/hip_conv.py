@@ -84,6 +84,8 @@ def begin_step(defer):
     gradients of its backward pass"""
     global _STEP, DEFER_COLSUM, DEFER_WGRAD
     _STEP += 1
+    from . import hip_ops
+    hip_ops.sink_reset()
     DEFER_COLSUM = bool(defer) and os.environ.get('OADG_DEFER_COLSUM', '1') == '1'
     DEFER_WGRAD = bool(defer) and os.environ.get('OADG_DEFER_WGRAD', '1') == '1'
 
@@ -125,7 +127,18 @@ def _close_shared_leftovers():
             _WQ.append(j)
             _WQ_WORK += j.work
         flush_wgrads()
-        w.grad = dw if w.grad is None else w.grad + dw
+        # This runs AFTER the backward pass: AccumulateGrad and its hooks are bypassed.  With no gradient on the parameter
+        # yet (the normal case: none of the arrived uses returned one) a data-parallel reducer still sees it - its bucket
+        # has a pending member and is packed by FlatGradReducer.finish(), which runs after end_backward().  A parameter
+        # that ALREADY holds a gradient may sit in a bucket whose all-reduce is in flight: adding to it now would be lost.
+        from . import hip_ops
+        if w.grad is None:
+            w.grad = dw
+        elif hip_ops.GRAD_SINK is not None:
+            raise RuntimeError('a shared convolution weight received part of its gradient through autograd and part of it '
+                               'after the backward pass while a gradient reducer is active: set OADG_WGRAD_SHARED=0')
+        else:
+            w.grad.add_(dw)
     _SHARED_OPEN.clear()
 
 

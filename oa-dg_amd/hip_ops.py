@@ -279,16 +279,25 @@ FUSED_PARSE_LOSSES = os.environ.get('OADG_FUSED_PARSE_LOSSES', '1') == '1'
 # tensor: AccumulateGrad adopts a gradient it holds the only reference to, so ``param.grad`` IS the bucket slice and the
 # reducer has nothing to pack (the round-4 form copied every gradient into its bucket: 166 MB read + 166 MB written per step).
 GRAD_SINK = None
+_SINK_CLAIMED = set()       # ids of the parameters whose slice has been handed out in this backward pass
+
+
+def sink_reset():
+    """a new backward pass begins (FlatGradReducer.finish / hip_conv.begin_step): every slice may be handed out once again"""
+    _SINK_CLAIMED.clear()
 
 
 def grad_dest(param, like=None):
     """the tensor a producer should write ``param``'s gradient into: a fresh alias of the parameter's bucket slice when a
-    reducer is active and the parameter holds no gradient yet (a second contribution in the same step must be SUMMED by
-    autograd: it gets a tensor of its own), else a new fp32 tensor shaped and laid out like ``like`` (default: the parameter)"""
+    reducer is active, the parameter holds no gradient yet AND nobody has been handed the slice in this backward pass
+    (``param.grad`` is still None for every use of a leaf until AccumulateGrad runs, so a second contribution of the same
+    pass is recognised by the claim set: it gets a tensor of its own and autograd SUMS the two), else a new fp32 tensor
+    shaped and laid out like ``like`` (default: the parameter)"""
     sink = GRAD_SINK
-    if sink is not None and param is not None and param.grad is None:
+    if sink is not None and param is not None and param.grad is None and id(param) not in _SINK_CLAIMED:
         v = sink.get(param)
         if v is not None:
+            _SINK_CLAIMED.add(id(param))
             return v.detach()
     like = param if like is None else like
     return torch.empty_like(like, dtype=torch.float32)

@@ -254,6 +254,10 @@ def test_bench_workloads_and_clock_sampler_without_a_gpu(monkeypatch):
         desc = bench.pin_rank_to_cores(0, 1)
         assert 'physical cores' in desc and len(os.sched_getaffinity(0)) <= 8 and os.sched_getaffinity(0) <= before
         assert bench.baseline_cores() == len(before) and os.sched_getaffinity(0) == before
+        # LOCAL_RANK without LOCAL_WORLD_SIZE (local_rank >= world): wraps around instead of an empty CPU set
+        from oadg_amd.apis import pin_rank_to_cores
+        os.sched_setaffinity(0, before)
+        assert pin_rank_to_cores(3, 1) is not None and len(os.sched_getaffinity(0)) >= 1
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(max(1, min(len(before), 16)))

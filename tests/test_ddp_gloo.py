@@ -336,3 +336,32 @@ def test_bucket_plan_on_the_real_parameter_sets(monkeypatch):
     sizes, ends = plans['dc5']
     assert sizes == [416.7, 151.6, 134.5, 28.8, 5.4], sizes
     assert ends[0][1] == 'roi_head.bbox_head.shared_fcs.0.weight' and ends[-1][1] == 'backbone.layer2.0.conv1.weight'
+
+
+def test_grad_sink_slice_is_handed_out_once_per_backward_pass():
+    """``param.grad`` stays None for EVERY use of a leaf until AccumulateGrad runs, so a head whose forward runs
+    twice in one step asked twice for the same bucket slice and autograd summed two aliases (2 * g2 instead of g1 + g2).
+    The claim set gives the second request of a pass a tensor of its own; FlatGradReducer.finish / begin_step reset it."""
+    from oadg_amd import hip_ops, hip_conv
+    w = torch.nn.Parameter(torch.zeros(4, 3))
+    view = torch.zeros(4, 3)
+    old = hip_ops.GRAD_SINK
+    try:
+        hip_ops.GRAD_SINK = {w: view}
+        hip_ops.sink_reset()
+        # the RoI head's cast function twice on the same leaf inside one backward pass
+        a1, = hip_ops._CastAll.apply(w)
+        a2, = hip_ops._CastAll.apply(w)
+        g1, g2 = torch.full((4, 3), 1.0), torch.full((4, 3), 2.0)
+        (a1.float() * g1 + a2.float() * g2).sum().backward()
+        assert torch.equal(w.grad, g1 + g2), w.grad
+        first = hip_ops.grad_dest(torch.nn.Parameter(torch.zeros(2)))          # a parameter without a slice: its own tensor
+        assert first.shape == (2,)
+        w.grad = None
+        assert hip_ops.grad_dest(w).data_ptr() != view.data_ptr()              # still claimed in this pass
+        hip_conv.begin_step(False)                                              # the next step: handed out again
+        assert hip_ops.grad_dest(w).data_ptr() == view.data_ptr()
+        assert hip_ops.grad_dest(w).data_ptr() != view.data_ptr()
+    finally:
+        hip_ops.GRAD_SINK = old
+        hip_ops.sink_reset()

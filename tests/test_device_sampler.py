@@ -46,9 +46,9 @@ def _device_sample(gts, num, pos_fraction, neg_pos_ub, dev):
     sel = torch.full((B, num), -7, dtype=torch.long, device=dev)
     meta = torch.full((3 * B,), -1, dtype=torch.int32, device=dev)
     gen = device_rng.generator(dev)
-    state = gen.upload()
+    state, state_out = gen.upload()
     _lib.check(L.oadg_roi_sample_device(ctypes.cast(images, ctypes.c_void_p), B, num, int(num * pos_fraction),
-                                        float(neg_pos_ub), _lib.ptr(state), _lib.ptr(sel), _lib.ptr(meta[:2 * B]),
+                                        float(neg_pos_ub), _lib.ptr(state), _lib.ptr(state_out), _lib.ptr(sel), _lib.ptr(meta[:2 * B]),
                                         _lib.ptr(meta[2 * B:]), _lib.stream_ptr()), 'oadg_roi_sample_device')
     gen.download_async()
     gen.sync_host()
