@@ -10,7 +10,8 @@
  *   - every pointer is a DEVICE pointer unless its name ends in `_host`; the caller owns all memory
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work: no allocation, no
  *     synchronisation, no global mutable state (re-entrant across streams with distinct workspaces)
- *   - return value: 0 = ok, < 0 = argument error (OADG_EARG -1, OADG_ESIZE -2), > 0 = hipError_t
+ *   - return value: 0 = ok, < 0 = argument error (OADG_EARG -1, OADG_ESIZE -2; the host-side file decoder also
+ *     OADG_EIO -3, OADG_EUNSUPPORTED -4), > 0 = hipError_t
  *   - tensors are dense row-major in the stated shape; images/feature maps are NHWC
  */
 #ifndef OADG_HIP_H
@@ -285,7 +286,12 @@ typedef struct {
     const float* Mx;
     uint8_t* scratch;
     int H, W, n_levels, pad_;
+    const int* level_first_dev;   /* device copy of level_first_host (n_levels + 1 entries), or NULL */
 } oadg_bbox_chain;
+/* With a level_first_dev in a descriptor (round 6), that chain's runs of SMALL-RECT levels (<= 32 tiles of 1024 pixels per
+ * level: every level of a 4096-box image) are walked by ONE 1024-thread workgroup in one launch - blended in registers,
+ * written in place, a workgroup barrier between levels; levels with larger rects stay launch pairs shared by all chains that
+ * are at such a level.  Byte-identical to n calls of oadg_oamix_bbox_chain either way. */
 int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void* stream);
 int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
                        const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,
@@ -303,6 +309,17 @@ int oadg_oamix_final_tiles(const uint8_t* img, const float* acc, int H, int W, c
                            int out_dtype, int Hp, int Wp, void* workspace, size_t workspace_bytes, void* stream);
 int oadg_oamix_normalize(const uint8_t* img, int H, int W, const float* mean_host, const float* stdinv_host,
                          int to_rgb, void* out, int out_dtype, int Hp, int Wp, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Input files (HOST functions, no device work; csrc/png_decode.hip)
+ *   oadg_png_decode_bgr  LoadImageFromFile  mmdet/datasets/pipelines/loading.py:33-78 (mmcv.imfrombytes -> cv2.imdecode:
+ *                        colour, BGR byte order)
+ * PNG file -> uint8 [H][W][3] in B, G, R order at `out` (any host memory: the data set hands in a slice of a pinned
+ * batch buffer) - zlib inflate + the five PNG row filters, one call without the interpreter lock.  8-bit grey / RGB / RGBA,
+ * non-interlaced; OADG_EUNSUPPORTED for any other PNG variant (the caller decodes those with PIL), OADG_ESIZE when the
+ * file's extent is not H x W, OADG_EIO when it cannot be read.  oadg_png_size: the extent from the header. */
+int oadg_png_size(const char* path, int* height, int* width);
+int oadg_png_decode_bgr(const char* path, uint8_t* out, int H, int W);
 
 /* ------------------------------------------------------------------------------------------------
  * Geometric pipeline steps in front of OA-Mix on uint8 HWC images
@@ -438,6 +455,16 @@ int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const float* bia
                                   const void* zeros16, int N, int H, int W, int C, int K, int R, int S, int pad, int dil,
                                   int relu, int out_h, int out_w, int OH, int OW, int osh, int osw, int oph, int opw,
                                   const void* mask, float* colsum_part, const void* mask_bits, void* stream);
+/* dx of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0) in ONE launch: the parity classes of
+ * oadg_conv2d_nhwc_bf16_scatter together, equal-sized classes interleaved per XCD so that dy is fetched from HBM once
+ *   serves the data gradient of Bottleneck.conv2 / downsample of a stage's first block
+ *          mmdet/models/backbones/resnet.py:166-186 (stride on the 3x3, pytorch style) through autograd
+ * dy [N,Ho,Wo,K] bf16; wt = oadg_prep_conv_weights wt_mode 2 (class blocks [C][taps][K]); dx [N,H,W,C] bf16 (1x1: only
+ * the even rows / columns are written); residual / mask / mask_bits indexed like dx (residual may alias dx: in-place
+ * accumulate); colsum_part: per class ceil(N*ha*wa/128) rows, classes back to back.  Bit-identical to the class launches. */
+int oadg_conv2d_dgrad_s2_nhwc_bf16(const void* dy, const void* wt, const void* residual, void* dx, const void* zeros16,
+                                   int N, int Ho, int Wo, int K, int C, int R, int H, int W, const void* mask,
+                                   float* colsum_part, const void* mask_bits, void* stream);
 
 /* per-layer weight preparation for the kernels above (one launch): optional eval-mode BatchNorm fold
  * (resnet.py:648-657: scale = gamma / sqrt(var + eps), bias = beta - mean * scale; gamma == NULL: plain cast with

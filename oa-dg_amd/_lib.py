@@ -106,6 +106,7 @@ SIGNATURES = {
     'oadg_prep_conv_weights_multi': (ci, [vp, ci, ci, vp]),
     'oadg_prep_conv_weights_multi_blocks': (ci, [ci, ci, ci, ci]),
     'oadg_conv2d_nhwc_bf16_scatter': (ci, [vp, vp, vp, vp, vp, vp] + [ci] * 18 + [vp, vp, vp, vp]),
+    'oadg_conv2d_dgrad_s2_nhwc_bf16': (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp]),
     'oadg_prep_conv_weights_bwd': (ci, [vp, vp, vp, vp, vp, vp, cf, ci, ci, ci, ci, vp, vp, ci, vp]),
     'oadg_relu_bias_bwd_workspace_bytes': (ctypes.c_size_t, [cl, ci]),
     'oadg_relu_bias_bwd': (ci, [vp, ci, vp, vp, vp, vp, ctypes.c_size_t, cl, ci, vp]),
@@ -162,6 +163,8 @@ SIGNATURES = {
     'oadg_oamix_bbox_plan': (ci, [ci, cd, vp, vp, ci, vp, ci, ci, ci, vp, cs, vp, vp, vp]),
     'oadg_oamix_bbox_chain': (ci, [vp, ci, ci, vp, vp, POINTER(ci), ci, POINTER(ci), vp, vp, vp, vp]),
     'oadg_oamix_bbox_chain_multi': (ci, [vp, ci, vp]),
+    'oadg_png_size': (ci, [c_char_p, POINTER(ci), POINTER(ci)]),
+    'oadg_png_decode_bgr': (ci, [c_char_p, vp, ci, ci]),
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
                               ci, vp]),

@@ -124,6 +124,20 @@ def quietest_window(cores, want, probe_s=0.1):
     return next(s0 for v, s0 in busy if v <= floor + 3)
 
 
+_RANK_CORES = dict(mine=None, slice=None)      # what pin_rank_to_cores chose for this process (spare_cores reads it)
+
+
+def spare_cores(n):
+    """up to ``n`` physical cores of this rank's slice of the host that its pinned threads do NOT run on (the decode
+    workers of a real-file dataset: a 1024 x 2048 PNG is tens of ms of inflate, which must not sit on the CCD whose L3 the
+    launch threads share), or None when the rank is not pinned / its slice has no spare core"""
+    mine, sl = _RANK_CORES['mine'], _RANK_CORES['slice']
+    if not mine or not sl:
+        return None
+    rest = [c for c in sl if c not in set(mine)]
+    return rest[:max(0, int(n))] or None
+
+
 def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
     """Every rank runs a main thread (~20 ms of launch work per step), the autograd thread, the pipeline worker and its
     planner threads.  Left to the scheduler on a 2 x 64-core host they wander over both sockets: the SAME binary needed
@@ -157,6 +171,7 @@ def pin_rank_to_cores(local_rank, world, cores_per_rank=8):
         os.sched_setaffinity(0, mine)
     except OSError:                  # (a cpuset that changed under us, a container that forbids it: run unpinned)
         return None
+    _RANK_CORES['mine'], _RANK_CORES['slice'] = list(mine), list(mine_slice)
     torch.set_num_threads(max(1, min(len(mine), 16)))
     return (f'{len(mine)} of {len(phys)} physical cores ({len(cores)} CPUs) per rank, slices of {per} '
             f'(rank {local_rank}: CPUs {mine[0]}-{mine[-1]})')

@@ -7,6 +7,8 @@
 #define OADG_OK 0
 #define OADG_EARG (-1)     // bad argument (null pointer, negative size, unsupported shape)
 #define OADG_ESIZE (-2)    // workspace too small
+#define OADG_EIO (-3)      // host file could not be read (png_decode.hip)
+#define OADG_EUNSUPPORTED (-4)   // a file format variant the native decoder does not cover (the caller falls back)
 
 #define OADG_WAVE 64
 

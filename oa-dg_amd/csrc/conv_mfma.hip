@@ -133,8 +133,7 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 // PW: pointwise launch (R = S = 1, stride 1, pad 0, no scatter map): pixel m of y is row m of x, so the 64-bit
 // pixel -> (n, ho, wo) divisions and the per-tap bounds tests - 12-15 % of an HBM-bound 1x1 launch - are compiled out.
 template <int TBN, bool POST, int NST, bool PW = false>
-__global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const long bid, unsigned char* smem) {
     constexpr int WN = TBN / 64, WM = 4 / WN, AF = BM / WM / 32, NBP = TBN * 8 / 256;
     constexpr int TSTAGE = (BM + TBN) * BK * 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,7 +145,6 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
     // instead of being fetched through the fabric once per XCD.
     const int n_tiles = a.K / TBN;
     const long m_tiles = (a.M + BM - 1) / BM;
-    const long bid = blockIdx.x;
     long mt;
     int nt;
     {
@@ -351,6 +349,52 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(Con
     }
 }
 
+
+template <int TBN, bool POST, int NST, bool PW = false>
+__global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_igemm_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv_igemm_body<TBN, POST, NST, PW>(a, blockIdx.x, smem);
+}
+
+// The parity classes of a stride-2 data gradient in ONE launch (round 6; rounds 1-5: one scatter launch per class = dy read
+// four times from HBM, four launch ramps for 2 - 8 chunk reductions).  Each class is the stride-1 convolution over dy that
+// conv_igemm_kernel runs with a scatter map; here a workgroup picks its class from its index and runs the same body with
+// that class's filters / taps / output phase.  Equal-sized classes (even H, W) are INTERLEAVED at the granularity of one
+// workgroup per XCD: the four class tiles over the same dy pixels run back to back on the same XCD, so dy comes from HBM
+// once and from that L2 three times.  Same products in the same order per class: bit-identical to the per-class launches.
+struct S2Class {
+    const unsigned short* w;
+    float* colsum;
+    int R, S, Ho, Wo, oph, opw, block0;
+    long M;
+};
+struct S2Args {
+    ConvArgs base;
+    S2Class cls[4];
+    int n_cls, interleave;
+};
+template <int TBN, bool POST>
+__global__ __launch_bounds__(256, 4) void conv_igemm_s2_kernel(S2Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    long bid = blockIdx.x;
+    int ci = 0;
+    if (g.interleave) {
+        ci = (int)((bid >> 3) & 3);
+        bid = ((bid >> 5) << 3) | (bid & 7);
+    } else {
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+            if (k < g.n_cls && bid >= g.cls[k].block0) ci = k;
+    }
+    S2Class c = g.cls[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k == ci) c = g.cls[k];
+    if (!g.interleave) bid -= c.block0;
+    ConvArgs a = g.base;
+    a.w = c.w; a.colsum = c.colsum; a.R = c.R; a.S = c.S; a.Ho = c.Ho; a.Wo = c.Wo; a.oph = c.oph; a.opw = c.opw; a.M = c.M;
+    conv_igemm_body<TBN, POST, 1, false>(a, bid, smem);
+}
 
 // ================================================================================================ pointwise, streaming
 // HBM-bound 1x1 / stride 1 convolutions with C <= 256 (ResNet conv3 and its mirror, the data gradient of conv1; the
@@ -1095,6 +1139,65 @@ extern "C" int oadg_conv2d_nhwc_bf16_scatter(const void* x, const void* w, const
     const int sc[8] = {out_h, out_w, OH, OW, osh, osw, oph, opw};
     return conv_launch(x, w, bias, residual, y, zeros16, N, H, W, C, K, R, S, 1, pad, dil, relu, 3, stream, mask,
                        colsum_part, sc, mask_bits, nullptr);
+}
+
+// dx of a stride-2 convolution (3x3 / pad 1 or 1x1 / pad 0) in ONE launch: all parity classes of
+// oadg_conv2d_nhwc_bf16_scatter together (conv_igemm_s2_kernel).  dy [N,Ho,Wo,K] bf16; wt = the class filters
+// (oadg_prep_conv_weights wt_mode 2: class blocks [C][taps][K] in the order (0,0) (0,1) (1,0) (1,1)); dx [N,H,W,C];
+// residual (1x1 only in practice: dx += in place, may alias dx) / mask / mask_bits are indexed like dx; colsum_part: the
+// classes' partial rows back to back, ceil(N*ha*wa / 128) rows per class in class order.  Classes with no pixel are skipped.
+extern "C" int oadg_conv2d_dgrad_s2_nhwc_bf16(const void* dy, const void* wt, const void* residual, void* dx,
+                                              const void* zeros16, int N, int Ho, int Wo, int K, int C, int R, int H, int W,
+                                              const void* mask, float* colsum_part, const void* mask_bits, void* stream) {
+    if (!dy || !wt || !dx || !zeros16 || N < 1 || Ho < 1 || Wo < 1 || H < 1 || W < 1 || (R != 3 && R != 1)) return OADG_EARG;
+    if (K % BK != 0 || C % 64 != 0 || (mask_bits && C % 8 != 0)) return OADG_EARG;
+    static const int cls_tab[4][5] = {{0, 0, 1, 1, 0}, {0, 1, 1, 2, 1}, {1, 0, 2, 1, 3}, {1, 1, 2, 2, 5}};   // ph, pw, taps h, w, block
+    S2Args g;
+    ConvArgs& a = g.base;
+    a.x = (const unsigned short*)dy; a.w = nullptr; a.bias = nullptr; a.res = (const unsigned short*)residual;
+    a.y = (unsigned short*)dx; a.zeros = (const unsigned short*)zeros16; a.mask = (const unsigned short*)mask;
+    a.bits_in = (const unsigned char*)mask_bits; a.bits_out = nullptr; a.colsum = nullptr;
+    a.N = N; a.H = Ho; a.W = Wo; a.C = K; a.K = C; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.relu = 0;
+    a.Ho = a.Wo = 1; a.M = 0;
+    a.scatter = 1; a.OH = H; a.OW = W; a.osh = 2; a.osw = 2; a.oph = a.opw = 0;
+    a.res_up = 0; a.lh = a.lw = 0;
+    const int tbn = (C % BN == 0) ? BN : 64;
+    g.n_cls = 0;
+    long blocks = 0, rows = 0;
+    bool equal = true;
+    long first_blocks = -1;
+    for (int k = 0; k < (R == 3 ? 4 : 1); ++k) {
+        const int ph = cls_tab[k][0], pw = cls_tab[k][1];
+        const int ha = (H - ph + 1) / 2, wa = (W - pw + 1) / 2;
+        if (ha < 1 || wa < 1) continue;
+        // rows / columns of dy past its extent read the zero line (class taps reach dy[a + 1])
+        if ((long)(ha - 1) * 2 + ph >= H || (long)(wa - 1) * 2 + pw >= W) return OADG_EARG;
+        S2Class& c = g.cls[g.n_cls++];
+        c.w = (const unsigned short*)wt + (size_t)cls_tab[k][4] * C * K;
+        c.R = cls_tab[k][2]; c.S = cls_tab[k][3]; c.Ho = ha; c.Wo = wa; c.oph = ph; c.opw = pw;
+        c.M = (long)N * ha * wa;
+        const long m_tiles = (c.M + BM - 1) / BM;
+        c.colsum = colsum_part ? colsum_part + (size_t)rows * C : nullptr;
+        rows += m_tiles;
+        const long b = ((m_tiles + 7) / 8) * 8 * (C / tbn);
+        if (first_blocks < 0) first_blocks = b;
+        equal = equal && b == first_blocks;
+        if (blocks + b > 0x7fffffffL) return OADG_EARG;
+        c.block0 = (int)blocks;
+        blocks += b;
+    }
+    if (g.n_cls == 0) return OADG_OK;
+    for (int k = g.n_cls; k < 4; ++k) g.cls[k] = g.cls[0];
+    g.interleave = (g.n_cls == 4 && equal) ? 1 : 0;
+    const bool post = residual != nullptr || mask != nullptr || mask_bits != nullptr;
+    const unsigned lds1 = (BM + tbn) * BK * 2 + 8192;
+    hipStream_t st = (hipStream_t)stream;
+#define OADG_LS2(TB, PO) hipLaunchKernelGGL((conv_igemm_s2_kernel<TB, PO>), dim3((unsigned)blocks), dim3(256), lds1, st, g)
+    if (tbn == BN) { if (post) OADG_LS2(128, true); else OADG_LS2(128, false); }
+    else { if (post) OADG_LS2(64, true); else OADG_LS2(64, false); }
+#undef OADG_LS2
+    OADG_LAUNCH_CHECK();
+    return OADG_OK;
 }
 
 // rows of the colsum_part buffer for a problem / variant (0 = automatic)

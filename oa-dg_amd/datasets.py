@@ -9,6 +9,7 @@ there on everything is the device pipeline.  ``batch(indices)`` has ``SyntheticC
 """
 import json
 import os
+import threading
 from collections import defaultdict
 from concurrent.futures import ThreadPoolExecutor
 
@@ -16,6 +17,9 @@ import numpy as np
 import torch
 
 from .registry import DATASETS, build_from_cfg
+
+
+NATIVE_PNG = os.environ.get('OADG_NATIVE_PNG', '1') == '1'     # PNG files through csrc/png_decode.hip (else PIL)
 
 
 class _CocoIndex:
@@ -54,7 +58,7 @@ class CocoDataset:
     CLASSES = None
 
     def __init__(self, ann_file, pipeline=None, classes=None, data_root=None, img_prefix='', seg_prefix=None,
-                 proposal_file=None, test_mode=False, filter_empty_gt=True, device='cuda', decode_workers=4, **kwargs):
+                 proposal_file=None, test_mode=False, filter_empty_gt=True, device='cuda', decode_workers=None, **kwargs):
         self.ann_file, self.data_root, self.img_prefix = ann_file, data_root, img_prefix
         self.test_mode, self.filter_empty_gt, self.device = test_mode, filter_empty_gt, device
         self.pipeline_cfg = pipeline
@@ -69,7 +73,20 @@ class CocoDataset:
         if not test_mode:
             valid = self._filter_imgs()
             self.data_infos = [self.data_infos[i] for i in valid]
-        self._pool = ThreadPoolExecutor(decode_workers, thread_name_prefix='oadg-decode')
+        # Decode workers (PIL releases the interpreter lock inside its decoders, numpy inside the channel flip): a
+        # 1024 x 2048 PNG costs 30 - 50 ms of inflate on one core and the step consumes a batch of four every ~27 ms, so
+        # several BATCHES are decoded at once (tools/train.py keeps `loader_depth` of them in flight).  The workers run
+        # on spare cores of the rank's slice of the host - NOT on the CCD the launch threads are pinned to
+        # (apis.pin_rank_to_cores) - when there are any; default count: 12, or what the spare cores allow.
+        from .apis import spare_cores
+        want = 12 if decode_workers is None else int(decode_workers)
+        self._decode_cores = spare_cores(want)
+        if decode_workers is None and self._decode_cores is not None:
+            want = max(4, len(self._decode_cores))
+        self.decode_workers = want
+        self.ring_slots = 6            # pinned batch buffers per (batch, shape): more than tools/train.py keeps in flight
+        self._rings, self._ring_lock = {}, threading.Lock()
+        self._pool = ThreadPoolExecutor(want, thread_name_prefix='oadg-decode', initializer=self._place_worker)
         # custom.py:209-221 _set_group_flag: images with aspect ratio > 1 form group 1 (the samplers group by it)
         self.flag = np.array([1 if i['width'] / i['height'] > 1 else 0 for i in self.data_infos], dtype=np.uint8)
 
@@ -146,25 +163,82 @@ class CocoDataset:
         inter_h = max(0, min(y1 + h, img_info['height']) - max(y1, 0))
         return inter_w * inter_h == 0 or ann['area'] <= 0 or w < 1 or h < 1
 
+    def _place_worker(self):
+        if self._decode_cores and hasattr(os, 'sched_setaffinity'):
+            try:
+                os.sched_setaffinity(0, self._decode_cores)      # (pid 0 = the calling thread)
+            except OSError:
+                pass
+
     # ---- loading.py:33-78 LoadImageFromFile (color, BGR)
+    def _path(self, idx):
+        name = self.data_infos[idx]['filename']
+        return os.path.join(self.img_prefix, name) if self.img_prefix else name
+
     def decode(self, idx):
         from PIL import Image
-        path = os.path.join(self.img_prefix, self.data_infos[idx]['filename']) if self.img_prefix \
-            else self.data_infos[idx]['filename']
-        with Image.open(path) as im:
+        with Image.open(self._path(idx)) as im:
             rgb = np.asarray(im.convert('RGB'))
         return np.ascontiguousarray(rgb[:, :, ::-1])
+
+    def decode_into(self, idx, dst):
+        """image ``idx`` as BGR bytes into ``dst`` (uint8 [H,W,3] view of host memory).  PNG files go through the native
+        decoder (csrc/png_decode.hip: one call without the interpreter lock, pixels written at their final place); any other
+        format, or a PNG variant it does not cover, through PIL."""
+        path = self._path(idx)
+        if NATIVE_PNG and path.lower().endswith('.png'):
+            from . import _lib
+            rc = _lib.lib().oadg_png_decode_bgr(path.encode(), dst.ctypes.data, dst.shape[0], dst.shape[1])
+            if rc == 0:
+                return
+            if rc not in (-4,):                   # (-4: a PNG variant for PIL; anything else is an error worth seeing)
+                _lib.check(rc, f'oadg_png_decode_bgr({path})')
+        np.copyto(dst, self.decode(idx))
+
+    def _shape(self, idx):
+        info = self.data_infos[idx]
+        return int(info['height']), int(info['width'])
+
+    def _slot(self, n, H, W):
+        """a pinned [n,H,W,3] batch buffer from a small ring (allocated once per shape: pinning 25 MB per batch costs more
+        than decoding it); a slot is reused only after the upload that read it has finished"""
+        key = (n, H, W)
+        with self._ring_lock:
+            ring = self._rings.setdefault(key, dict(bufs=[], events=[], next=0))
+            if len(ring['bufs']) < self.ring_slots:
+                buf = torch.empty((n, H, W, 3), dtype=torch.uint8)
+                if torch.device(self.device).type == 'cuda':
+                    buf = buf.pin_memory()
+                ring['bufs'].append(buf)
+                ring['events'].append(None)
+                k = len(ring['bufs']) - 1
+            else:
+                k = ring['next']
+                ring['next'] = (k + 1) % self.ring_slots
+            ev = ring['events'][k]
+        if ev is not None:
+            ev.synchronize()
+        return ring, k
 
     def batch(self, indices):
         """(uint8 [N,H,W,3] on the device, list of float32 [n,4] boxes, list of int64 labels)."""
         indices = list(indices)
-        arrs = list(self._pool.map(self.decode, indices))
-        assert all(a.shape == arrs[0].shape for a in arrs), 'one image shape per batch (Cityscapes: 1024x2048)'
-        host = torch.from_numpy(np.stack(arrs))
+        shapes = {self._shape(i) for i in indices}
+        assert len(shapes) == 1, 'one image shape per batch (Cityscapes: 1024x2048)'
+        H, W = shapes.pop()
+        ring, k = self._slot(len(indices), H, W)
+        host = ring['bufs'][k]
+        views = host.numpy()
+        list(self._pool.map(lambda a: self.decode_into(a[1], views[a[0]]), enumerate(indices)))
         if torch.device(self.device).type == 'cuda':
-            host = host.pin_memory().to(self.device, non_blocking=True)
+            dev = host.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ring['events'][k] = ev
+        else:
+            dev = host.clone()
         anns = [self.get_ann_info(i) for i in indices]
-        return host, [a['bboxes'] for a in anns], [a['labels'] for a in anns]
+        return dev, [a['bboxes'] for a in anns], [a['labels'] for a in anns]
 
 
 @DATASETS.register_module()

@@ -499,6 +499,7 @@ def kernel_name(v, C, K, R, S, stride, pad, res, mask, bits_in, bits_out, scatte
 
 
 _S2_CLASSES = ((0, 0, 1, 1, 0), (0, 1, 1, 2, 1), (1, 0, 2, 1, 3), (1, 1, 2, 2, 5))    # ph, pw, taps_h, taps_w, block offset
+S2_ONE_LAUNCH = True        # the parity classes of a stride-2 data gradient in one launch (False: one scatter launch per class)
 
 
 def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=None, accumulate=None):
@@ -531,7 +532,15 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    for ph, pw, th, tw, off, ha, wa, tiles in geo:
+    if S2_ONE_LAUNCH:
+        # all classes in one launch (csrc conv_igemm_s2_kernel): dy from HBM once, one launch ramp
+        check(L.oadg_conv2d_dgrad_s2_nhwc_bf16(ptr(gy), ptr(wt), ptr(accumulate), ptr(gx), ptr(_zeros(gy.device)), N, Ho, Wo, K, C,
+                                               R, H, W, ptr(mask), ptr(part), ptr(mask_bits), stream_ptr()),
+              'oadg_conv2d_dgrad_s2_nhwc_bf16')
+        geo_loop = ()
+    else:
+        geo_loop = geo
+    for ph, pw, th, tw, off, ha, wa, tiles in geo_loop:
         wptr = ctypes.c_void_p(wt.data_ptr() + off * C * K * 2)
         pptr = ctypes.c_void_p(part.data_ptr() + row * C * 4) if part is not None else None
         check(L.oadg_conv2d_nhwc_bf16_scatter(ptr(gy), wptr, None, ptr(accumulate), ptr(gx), ptr(_zeros(gy.device)), N, Ho, Wo, K, C,

@@ -142,3 +142,57 @@ def test_integrate_data_uses_the_shared_allocation_of_adjacent_views():
     odd = img2.contiguous()
     out = integrate_data(data(img, odd), cfg)
     assert torch.equal(out['img'], both)
+
+
+def test_native_png_decoder_equals_pil(tmp_path):
+    """csrc/png_decode.hip (host code: zlib inflate + the five PNG row filters, BGR written in place) against PIL on RGB /
+    RGBA / grey files of odd extents, low-pass and noisy content (PIL's encoder picks the row filters adaptively: all five
+    occur), several zlib levels; a 16-bit file is declined (-4: the data set then decodes it with PIL), a wrong extent is
+    -2, a missing file -3; and CocoDataset.decode_into takes the native path for PNG and PIL for everything else."""
+    import ctypes
+    from PIL import Image
+    from oadg_amd import _lib
+    L = _lib.lib()
+    rs = np.random.RandomState(3)
+    cases = []
+    for k, (h, w, mode) in enumerate([(37, 53, 'RGB'), (64, 128, 'RGB'), (31, 17, 'RGBA'), (40, 33, 'L'), (1, 1, 'RGB'),
+                                      (129, 255, 'RGB')]):
+        ch = {'RGB': 3, 'RGBA': 4, 'L': 1}[mode]
+        a = rs.randint(0, 256, (h, w, ch)).astype(np.uint8)
+        if k % 2 == 1:                       # smooth content: Sub / Up / Average / Paeth rows
+            a = (np.cumsum(np.cumsum(a.astype(np.float64), 0), 1) / (np.arange(1, h + 1)[:, None, None] * np.arange(1, w + 1)[None, :, None])).astype(np.uint8)
+        img = Image.fromarray(a[:, :, 0] if ch == 1 else a, mode)
+        path = str(tmp_path / f'c{k}.png')
+        img.save(path, compress_level=(1, 6, 9)[k % 3])
+        cases.append((path, h, w))
+    filters = set()
+    for path, h, w in cases:
+        hh, ww = ctypes.c_int(0), ctypes.c_int(0)
+        assert L.oadg_png_size(path.encode(), ctypes.byref(hh), ctypes.byref(ww)) == 0 and (hh.value, ww.value) == (h, w)
+        out = np.full((h, w, 3), 7, np.uint8)
+        assert L.oadg_png_decode_bgr(path.encode(), out.ctypes.data, h, w) == 0, path
+        with Image.open(path) as im:
+            ref = np.asarray(im.convert('RGB'))[:, :, ::-1]
+        assert np.array_equal(out, ref), path
+        assert L.oadg_png_decode_bgr(path.encode(), out.ctypes.data, h + 1, w) == -2
+    a16 = (rs.randint(0, 65536, (9, 11)).astype(np.uint16))
+    Image.fromarray(a16).save(str(tmp_path / 'deep.png'))
+    out = np.zeros((9, 11, 3), np.uint8)
+    assert L.oadg_png_decode_bgr(str(tmp_path / 'deep.png').encode(), out.ctypes.data, 9, 11) == -4
+    assert L.oadg_png_decode_bgr(str(tmp_path / 'nope.png').encode(), out.ctypes.data, 9, 11) == -3
+    # through the data set: PNG natively, JPEG (and the declined PNG) through PIL - same bytes as decode()
+    from oadg_amd.datasets import CocoDataset
+    os.makedirs(tmp_path / 'img', exist_ok=True)
+    b = rs.randint(0, 256, (40, 48, 3)).astype(np.uint8)
+    Image.fromarray(b).save(str(tmp_path / 'img' / 'a.png'))
+    Image.fromarray(b).save(str(tmp_path / 'img' / 'b.jpg'))
+    images = [dict(id=0, file_name='a.png', height=40, width=48), dict(id=1, file_name='b.jpg', height=40, width=48)]
+    anns = [dict(id=i, image_id=i, category_id=1, iscrowd=0, area=50.0, bbox=[2, 3, 10, 5]) for i in range(2)]
+    with open(tmp_path / 'ann.json', 'w') as f:
+        json.dump(dict(images=images, annotations=anns, categories=[dict(id=1, name='car')]), f)
+    ds = CocoDataset(str(tmp_path / 'ann.json'), classes=('car',), img_prefix=str(tmp_path / 'img'), device='cpu')
+    imgs, boxes, labels = ds.batch([0, 1])
+    assert imgs.shape == (2, 40, 48, 3) and np.array_equal(imgs[0].numpy(), b[:, :, ::-1])
+    assert np.array_equal(imgs[1].numpy(), ds.decode(1)) and len(boxes) == 2
+    imgs2, _, _ = ds.batch([1, 0])                      # the ring's next slot; the first batch's tensor is untouched
+    assert np.array_equal(imgs2[1].numpy(), imgs[0].numpy()) and np.array_equal(imgs[0].numpy(), b[:, :, ::-1])

@@ -225,7 +225,9 @@ def test_bf16_mfma_step_matches_reference_on_gpu(dev, golden_dir, monkeypatch):
     acc 3.2e-2, gradient norms <= 8.9e-3, labels identical.  Asserted at ~3x that: 1.5e-2 / 1e-1 (acc) / 2.5e-2 /
     99.9 %.  north_star's 1e-4 bar is held by the per-kernel tests on identical operands and by the fp32 product
     step (1e-7..3.3e-4 against the same fixtures)."""
-    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_256x512.npz', CFG, True, 1.5e-2, 1e-1, 2.5e-2, 0.999, monkeypatch)
+    # round 6 (profiles/r06_parity.txt): loss terms <= 4.3e-3, acc 5.7e-2, gradient norms <= 1.23e-2, labels identical: the loss
+    # gate now sits at 2x the measured deviation (was 3.5x)
+    _gpu_step_vs_fixture(dev, golden_dir, 'model_step_256x512.npz', CFG, True, 9e-3, 1e-1, 2.5e-2, 0.999, monkeypatch)
 
 
 @pytest.mark.gpu
@@ -238,7 +240,11 @@ def test_full_size_config1_step_matches_reference_on_gpu(dev, golden_dir, bf16, 
     # convolutions (3.6e-2 relative with tap-major K order, 7.5e-2 with the chunk-major order of round 2): 1.5e-1 asserted.
     # Measured (round 3): fp32 loss terms <= 2.5e-4, acc 4.1e-3, gradient norms <= 2e-4, labels identical; bf16 loss
     # terms <= 2e-3, gradient norms <= 7.1e-3, labels identical.  Asserted at ~3x the measured deviations.
-    tol = (6e-3, 1.5e-1, 2e-2, 0.999) if bf16 else (1e-3, 1.5e-2, 1e-3, 0.999)
+    # Round 6 (profiles/r06_parity.txt, the fp32 path on the csrc fp32-MFMA convolutions): fp32 loss terms <= 9.6e-5 - north_star's
+    # 1e-4 holds END TO END on the full-size step -, acc identical, gradient norms <= 2.8e-4, labels identical; bf16 loss terms
+    # <= 2.04e-3, acc 4.8e-2, gradient norms <= 5.7e-3, labels identical.  Gates at ~2x measured (a 10x regression
+    # passed the old 1e-3 / 1.5e-2 / 1e-3).  fp32 `acc`: identical today; 3e-3 admits two flipped argmaxes of 2048.
+    tol = (4.1e-3, 1e-1, 1.2e-2, 0.999) if bf16 else (2e-4, 3e-3, 6e-4, 0.999)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_1024x2048.npz', CFG, bf16, *tol, monkeypatch)
 
 
@@ -285,7 +291,9 @@ def test_r101_dc5_step_matches_reference_on_gpu(dev, golden_dir, bf16, monkeypat
     (loss_cls: 2 of 2048 sampled RoIs flip), acc 5.7e-4, gradient norms <= 2.1e-2, labels 99.9 %."""
     # (round 4: with the frozen stage-1 blocks fused into one launch the bf16 rounding pattern of their outputs changed and
     #  `acc` - an argmax over near-tied random-init logits, see the R50 test above - moved from 5.7e-4 to 1.0e-2)
-    tol = (5e-2, 2e-2, 6e-2, 0.998) if bf16 else (1e-4, 1e-3, 3e-4, 0.999)       # (acc gate 2e-2 for a measured 1.0e-2: ADVICE r4)
+    # Round 6 (profiles/r06_parity.txt): fp32 loss terms <= 1.3e-6, acc identical, gradient norms <= 7.9e-5; bf16 loss terms
+    # <= 3.6e-2 (loss_cls: two sampled RoIs flip), acc 1.02e-2, gradient norms <= 1.12e-2, labels 99.8 %.  Gates at <= 2x measured.
+    tol = (5e-2, 2e-2, 2.3e-2, 0.998) if bf16 else (1e-5, 3e-3, 2e-4, 0.999)
     _gpu_step_vs_fixture(dev, golden_dir, 'model_step_dc5_384x768.npz', DC5_CFG, bf16, *tol, monkeypatch)
 
 

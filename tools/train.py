@@ -58,6 +58,9 @@ def parse_args():
     p.add_argument('--allow-missing-pretrained', action='store_true',
                    help='train from random weights (with a warning) when a configured pretrained / load_from '
                         'checkpoint is not available locally, instead of stopping')
+    p.add_argument('--loader-depth', type=int, default=3,
+                   help='batches the loader keeps in flight ahead of the augmentation pipeline (decode of real files: a '
+                        'batch of 1024x2048 PNGs takes longer to inflate than a step takes to train)')
     p.add_argument('--no-cpu-affinity', action='store_true',
                    help='do not pin this rank\'s threads to a compact set of physical cores (oadg_amd.apis.pin_rank_to_cores)')
     a = p.parse_args()
@@ -212,10 +215,16 @@ def main():
             ready = torch.cuda.Event()
             ready.record()
         return item, batch, ready
-    loader = ThreadPoolExecutor(1, thread_name_prefix='oadg-loader')
+    depth = max(1, int(a.loader_depth))
+    loader = ThreadPoolExecutor(depth, thread_name_prefix='oadg-loader')
     wseed = seed + rank + 1000
     todo = index_lists()
-    pending_load = [loader.submit(load, i) for i in [next(todo, None)] if i is not None]
+    # `depth` batches in flight, consumed in order (the futures' list is FIFO: the training order is the sampler's)
+    pending_load = []
+    for _ in range(depth):
+        nxt = next(todo, None)
+        if nxt is not None:
+            pending_load.append(loader.submit(load, nxt))
     staged = []          # (epoch, k, prefetched batch)
 
     def advance():
