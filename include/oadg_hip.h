@@ -286,12 +286,7 @@ typedef struct {
     const float* Mx;
     uint8_t* scratch;
     int H, W, n_levels, pad_;
-    const int* level_first_dev;   /* device copy of level_first_host (n_levels + 1 entries), or NULL */
 } oadg_bbox_chain;
-/* With a level_first_dev in a descriptor (round 6), that chain's runs of SMALL-RECT levels (<= 32 tiles of 1024 pixels per
- * level: every level of a 4096-box image) are walked by ONE 1024-thread workgroup in one launch - blended in registers,
- * written in place, a workgroup barrier between levels; levels with larger rects stay launch pairs shared by all chains that
- * are at such a level.  Byte-identical to n calls of oadg_oamix_bbox_chain either way. */
 int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void* stream);
 int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oadg_region_op* ops_host,
                        const int* rects_host, int n_rects, const uint8_t* luts, const float* union_f,

@@ -20,7 +20,6 @@
 // weights), so outputs are compared bit-for-bit.  All kernels are HBM-streaming or box-local; masks are
 // never materialised as H x W x 3 float images (25 MB each in the reference): a blurred box mask is the
 // outer product My[y] * Mx[x] of two 1-D profiles.
-#include <vector>
 #include "common.h"
 #include <stdlib.h>
 #include "oadg_hip.h"
@@ -506,125 +505,18 @@ __global__ __launch_bounds__(256) void rect_copy_imgs_kernel(ChainLevel a) {
     copy_tile(s.img, s.W, s.steps, s.tile_prefix, s.first, s.count, s.tile_base + (tile - s.block0), blockIdx.x & 3, s.scratch);
 }
 
-// ---- runs of small-rect levels of a chain inside ONE workgroup (round 6) -------------------------------------------------
-// A chain is latency, not bytes: level l + 1 may not start before level l is in memory, and a launch pair per level pays
-// two dispatches (~20 us) for work that lasts 2 - 5 us (BASELINE config 5: 1,247 pairs per step = 26.7 of 47 ms).  A level
-// whose rects add up to at most SOLO_TILES tiles of 1024 pixels in at most SOLO_STEPS rects (the levels of a 4096-box image
-// behind its wide first ones: a dozen rects of 30 x 30 pixels) does not need the chip: ONE workgroup of 1024 threads per chain walks such levels by itself - read every
-// tap of the level, blend in registers, workgroup barrier, write the rects in place, barrier - with no scratch image, no
-// copy pass and nothing between levels but `s_waitcnt vmcnt(0)` + `s_barrier`: the waves of a workgroup share their
-// compute unit's L1, which is written through, so the next level's loads see this level's stores.  The host
-// (oadg_oamix_bbox_chain_multi) cuts every chain into runs of such levels (one launch per round for all chains that are in
-// a run) and levels with large rects (launch pairs over the whole chip, as before).  Per image the same arithmetic in the
-// same order as oadg_oamix_bbox_chain: byte-identical images.
-// (Measured and dropped on the way: every chain on a GROUP of workgroups that meet at a counter in memory between levels -
-//  write-through stores + agent-scope acquire per the MI355X guide's hand-over recipe, byte-exact: 64 arrivals per
-//  meeting and byte-wide write-through stores made a level 48 us instead of 21: BASELINE config 5 80.5 ms per step
-//  against 47.1, the default step 30.2 against 27.6.  The round-3 attempt met at barriers with L2 write-backs: 35 us each.)
-constexpr int SOLO_TILES = 32;           // tiles of 1024 pixels per level: two per wave, 24 result registers per lane
-constexpr int SOLO_STEPS = 192;          // steps per level (their 80-byte records and tile prefix sit in LDS, double-buffered)
-struct SoloChain {
-    uint8_t* img;
-    const oadg_bbox_step* steps;
-    const int* tile_prefix;
-    const int* level_first;
-    const float* My;
-    const float* Mx;
-    int H, W, l0, l1;                    // levels [l0, l1) of this chain
-};
-struct SoloArgs {
-    SoloChain c[8];
-};
-
-// The level's critical path is: table -> taps -> blend -> barrier -> stores -> barrier.  The tables (step records, tile
-// prefix) are STATIC, so level l + 1's travel into the second LDS buffer while level l is blended; a wave owns whole
-// tiles (tile t0 + wave, t0 + wave + 16: 16 pixels per lane and tile), so the sixteen waves' taps are in flight together
-// instead of tile after tile.
-__global__ __launch_bounds__(1024) void bbox_chain_solo_kernel(SoloArgs a) {
-    __shared__ __attribute__((aligned(16))) oadg_bbox_step stp[2][SOLO_STEPS];
-    __shared__ int pref[2][SOLO_STEPS + 1];
-    SoloChain c = a.c[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k)
-        if (k == (int)blockIdx.x) c = a.c[k];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    static_assert(sizeof(oadg_bbox_step) == 80 && SOLO_STEPS * 5 <= 1024, "step records are staged as five 16-byte pieces, one per thread");
-    // level l0's tables
-    int first = c.level_first[c.l0], count = c.level_first[c.l0 + 1] - first;
-    if (tid < count * 5) reinterpret_cast<uint4*>(&stp[0][0])[tid] = reinterpret_cast<const uint4*>(c.steps + first)[tid];
-    if (tid <= count) pref[0][tid] = c.tile_prefix[first + tid];
-    __syncthreads();
-    int cur = 0;
-    for (int l = c.l0; l < c.l1; ++l, cur ^= 1) {
-        // request level l + 1's tables (registers now, LDS after this level's taps have been read)
-        int first_n = 0, count_n = 0;
-        uint4 piece = {0u, 0u, 0u, 0u};
-        int pre_n = 0;
-        if (l + 1 < c.l1) {
-            first_n = c.level_first[l + 1];
-            count_n = c.level_first[l + 2] - first_n;
-            if (tid < count_n * 5) piece = reinterpret_cast<const uint4*>(c.steps + first_n)[tid];
-            if (tid <= count_n) pre_n = c.tile_prefix[first_n + tid];
-        }
-        const int* pf = pref[cur];
-        const int t0 = pf[0], t1 = pf[count];
-        unsigned pk0[4][3], pk1[4][3];
-        int s0 = -1, s1 = -1;
-        auto read_tile = [&](const int t, unsigned (&pk)[4][3], int& sidx) {
-            if (t < t1) {
-                int lo = 0, hi = count - 1;              // last step whose prefix <= t
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (pf[mid] <= t) lo = mid; else hi = mid - 1;
-                }
-                sidx = lo;
-                const oadg_bbox_step st = stp[cur][lo];
-                const int area = st.rect[2] * st.rect[3];
-                const float* my = c.My + (size_t)st.row * c.H;
-                const float* mx = c.Mx + (size_t)st.row * c.W;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int i0 = ((t - pf[lo]) * 256 + g * 64 + lane) * 4;
-                    if (i0 < area) blend4(c.img, c.H, c.W, st, my, mx, i0, pk[g]);
-                }
-            }
-        };
-        auto write_tile = [&](const int t, const unsigned (&pk)[4][3], const int sidx) {
-            if (sidx < 0) return;
-            const oadg_bbox_step* sp = &stp[cur][sidx];
-            const int rx = sp->rect[0], ry = sp->rect[1], rw = sp->rect[2], area = rw * sp->rect[3];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int i0 = ((t - pf[sidx]) * 256 + g * 64 + lane) * 4;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u;
-                    if (i < area) {
-                        const int yy = i / rw, xx = i - yy * rw;
-                        uint8_t* o = c.img + ((size_t)(ry + yy) * c.W + rx + xx) * 3;
-#pragma unroll
-                        for (int ch = 0; ch < 3; ++ch) {
-                            const int bi = u * 3 + ch;
-                            o[ch] = (uint8_t)(pk[g][bi >> 2] >> ((bi & 3) * 8));
-                        }
-                    }
-                }
-            }
-        };
-        read_tile(t0 + wave, pk0, s0);
-        read_tile(t0 + wave + 16, pk1, s1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                     // every tap of the level has been read: the rects may be overwritten
-        write_tile(t0 + wave, pk0, s0);
-        write_tile(t0 + wave + 16, pk1, s1);
-        // the next level's tables into the other buffer (its last readers passed the barrier above one level ago)
-        if (tid < count_n * 5) reinterpret_cast<uint4*>(&stp[cur ^ 1][0])[tid] = piece;
-        if (tid <= count_n && l + 1 < c.l1) pref[cur ^ 1][tid] = pre_n;
-        first = first_n; count = count_n;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the level is in memory (and in this CU's L1) before the next one reads
-        __syncthreads();
-    }
-}
+// (Round 6, three ways around the launch pair per level, all byte-exact, all measured on BASELINE config 5 and dropped:
+//  1. every chain on a GROUP of workgroups that walk its levels and meet at a counter in memory between them (write-through
+//     stores + one agent-scope acquire per meeting, the MI355X guide's hand-over recipe): 48 us per level against the pair's
+//     20 - 80.5 ms per step against 47.1 (64 arrivals per meeting, byte-wide write-through stores), default step 30.2 / 27.6;
+//  2. a chain's runs of narrow levels inside ONE 1024-thread workgroup (barrier-only, tables double-buffered in LDS): a
+//     level of a 4096-box image turned out to be ~40 rects of ~140 x 140 pixels = ~200 tiles (the blur support of a
+//     48-pixel box is three sigmas of 0.3 x its quarter-resolution size on every side) - 5 of ~110 levels qualified;
+//  3. one launch per level with workgroup = rect, blended in registers and written in place behind a workgroup barrier
+//     (round 4 had tried it with the rect's tiles walked one after the other: 57 us): 37.7 us per level - a rect is 5 - 20
+//     tiles of work for ONE workgroup where the pair spreads them over as many workgroups; 50.9 ms per step against 47.2.
+//  The pair IS the parallel form: ~1,600 tile workgroups per level (8 images) = one resident wave of the chip, 12 + 8.4 us.
+//  profiles/r06_oamix_chain_experiments.txt.)
 
 // ------------------------------------------------------------------------------------------------ compose
 struct ComposeArgs {
@@ -1273,6 +1165,7 @@ int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* step
 // oadg_oamix_bbox_chain: byte-identical images.  The images, scratch buffers and tables must be pairwise distinct.
 int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void* stream) {
     if (!chains_host || n < 1) return OADG_EARG;
+    int deepest = 0;
     for (int i = 0; i < n; ++i) {
         const oadg_bbox_chain& c = chains_host[i];
         if (!c.img || !c.steps_dev || !c.tile_prefix_dev || !c.level_first_host || !c.tile_prefix_host || !c.My || !c.Mx ||
@@ -1280,49 +1173,17 @@ int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void*
             return OADG_EARG;
         for (int j = 0; j < i; ++j)
             if (chains_host[j].img == c.img || chains_host[j].scratch == c.scratch) return OADG_EARG;
+        if (c.n_levels > deepest) deepest = c.n_levels;
     }
     hipStream_t st = (hipStream_t)stream;
-    // OADG_OAMIX_SOLO=0 (A/B probes): every level as a launch pair
-    static const bool solo_on = !(getenv("OADG_OAMIX_SOLO") && atoi(getenv("OADG_OAMIX_SOLO")) == 0);
-    // a level that ONE workgroup can take (bbox_chain_solo_kernel): few tiles, the step prefix fits its LDS table
-    auto solo_ok = [&](const oadg_bbox_chain& c, int l) {
-        if (!solo_on || !c.level_first_dev) return false;
-        const int first = c.level_first_host[l], last = c.level_first_host[l + 1];
-        return last - first >= 1 && last - first <= SOLO_STEPS &&
-               c.tile_prefix_host[last] - c.tile_prefix_host[first] <= SOLO_TILES;
-    };
-    std::vector<int> pos(n, 0);
-    // The chains are independent (own image, own tables): every round takes each chain's next SEGMENT - a run of solo
-    // levels (all of them in one launch, one workgroup per chain) or one level with large rects (a launch pair shared by
-    // all chains that are at such a level).  A run of a single level is only worth a launch of its own when no launch
-    // pair is needed in the round anyway.
-    while (true) {
+    for (int l = 0; l < deepest; ++l) {
         for (int i0 = 0; i0 < n; i0 += 8) {
-            const int i1 = i0 + 8 < n ? i0 + 8 : n;
-            bool any_big = false;
-            for (int i = i0; i < i1; ++i) {
-                const oadg_bbox_chain& c = chains_host[i];
-                if (pos[i] < c.n_levels && !solo_ok(c, pos[i])) any_big = true;
-            }
-            SoloArgs sa;
-            int ns = 0;
             ChainLevel a;
             a.n = 0;
             int blocks = 0;
-            for (int i = i0; i < i1; ++i) {
+            for (int i = i0; i < n && i < i0 + 8; ++i) {
                 const oadg_bbox_chain& c = chains_host[i];
-                const int l = pos[i];
                 if (l >= c.n_levels) continue;
-                int run = 0;
-                while (l + run < c.n_levels && solo_ok(c, l + run)) ++run;
-                if (run >= 2 || (run == 1 && !any_big)) {
-                    SoloChain& m = sa.c[ns++];
-                    m.img = c.img; m.steps = c.steps_dev; m.tile_prefix = c.tile_prefix_dev; m.level_first = c.level_first_dev;
-                    m.My = c.My; m.Mx = c.Mx; m.H = c.H; m.W = c.W; m.l0 = l; m.l1 = l + run;
-                    pos[i] = l + run;
-                    continue;
-                }
-                pos[i] = l + 1;
                 const int first = c.level_first_host[l], count = c.level_first_host[l + 1] - first;
                 if (count <= 0) continue;
                 const int tile_base = c.tile_prefix_host[first];
@@ -1334,22 +1195,13 @@ int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void*
                 m.block0 = blocks;
                 blocks += tiles;
             }
-            if (ns > 0) {
-                for (int k = ns; k < 8; ++k) sa.c[k] = sa.c[0];
-                hipLaunchKernelGGL(bbox_chain_solo_kernel, dim3(ns), dim3(1024), 0, st, sa);
-                OADG_LAUNCH_CHECK();
-            }
-            if (a.n > 0) {
-                for (int k = a.n; k < 8; ++k) a.im[k] = a.im[0];
-                hipLaunchKernelGGL(bbox_blend_imgs_kernel, dim3(blocks), dim3(256), 0, st, a);
-                OADG_LAUNCH_CHECK();
-                hipLaunchKernelGGL(rect_copy_imgs_kernel, dim3(blocks * 4), dim3(256), 0, st, a);
-                OADG_LAUNCH_CHECK();
-            }
+            if (a.n == 0) continue;
+            for (int k = a.n; k < 8; ++k) a.im[k] = a.im[0];
+            hipLaunchKernelGGL(bbox_blend_imgs_kernel, dim3(blocks), dim3(256), 0, st, a);
+            OADG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(rect_copy_imgs_kernel, dim3(blocks * 4), dim3(256), 0, st, a);
+            OADG_LAUNCH_CHECK();
         }
-        bool left = false;
-        for (int i = 0; i < n; ++i) left = left || pos[i] < chains_host[i].n_levels;
-        if (!left) break;
     }
     return OADG_OK;
 }

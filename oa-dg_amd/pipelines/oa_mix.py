@@ -55,11 +55,8 @@ BBOX_STEP_DTYPE = np.dtype([('minv', '<f8', (6,)), ('rect', '<i4', (4,)), ('row'
                             ('scratch_off', '<i8')])                                          # oadg_bbox_step
 BBOX_CHAIN_DTYPE = np.dtype([('img', '<u8'), ('steps_dev', '<u8'), ('tile_prefix_dev', '<u8'), ('level_first_host', '<u8'),
                              ('tile_prefix_host', '<u8'), ('My', '<u8'), ('Mx', '<u8'), ('scratch', '<u8'), ('H', '<i4'),
-                             ('W', '<i4'), ('n_levels', '<i4'), ('pad_', '<i4'), ('level_first_dev', '<u8')])   # oadg_bbox_chain
+                             ('W', '<i4'), ('n_levels', '<i4'), ('pad_', '<i4')])                        # oadg_bbox_chain
 LOCKSTEP = os.environ.get('OADG_OAMIX_LOCKSTEP', '1') == '1'    # the images of a batch advance their per-box chains together
-# a chain's runs of small-rect levels inside ONE workgroup (csrc bbox_chain_solo_kernel) instead of a launch pair per level
-# (the descriptors then carry the device copy of the level table; OADG_OAMIX_SOLO=0 switches it off in the library)
-SOLO_CHAINS = True
 BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
 PLAN_IN_C = os.environ.get('OADG_OAMIX_PLAN_C', '1') == '1'     # the op's host arithmetic in one C call (else numpy)
 PLAN_THREADS = int(os.environ.get('OADG_OAMIX_PLAN_THREADS', '4'))    # planner threads of the lockstep pass (0: none)
@@ -418,7 +415,6 @@ class OAMix:
                 r['img'], r['steps_dev'], r['tile_prefix_dev'] = c['img'], c['steps_dev'], c['tile_prefix_dev']
                 r['level_first_host'], r['tile_prefix_host'] = c['level_first'].ctypes.data, c['tile_prefix'].ctypes.data
                 r['My'], r['Mx'], r['scratch'], r['H'], r['W'], r['n_levels'] = c['My'], c['Mx'], c['scratch'], c['H'], c['W'], c['n_levels']
-                r['level_first_dev'] = c.get('level_first_dev', 0) if SOLO_CHAINS else 0
                 work += c['work']
             check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain_multi, tab.ctypes.data_as(ctypes.c_void_p),
                                  len(ready), stream_ptr(), work=work), 'oadg_oamix_bbox_chain_multi')
@@ -625,8 +621,7 @@ class OAMix:
                 self.stats['bbox_steps'] = self.stats.get('bbox_steps', 0) + n_live
             if n_live == 0:
                 return None
-            # steps, tile prefix, level table (the plan wrote them back to back)
-            used = n_live * BBOX_STEP_DTYPE.itemsize + (n_live + 1) * 4 + (n_levels + 1) * 4
+            used = n_live * BBOX_STEP_DTYPE.itemsize + (n_live + 1) * 4
             dst = torch.empty((used,), dtype=torch.uint8, device=st.img.device)
             dst.copy_(buf[:used], non_blocking=True)
             ev = ring.events[k] = ring.events[k] or torch.cuda.Event()
@@ -643,8 +638,7 @@ class OAMix:
                 img=T.data_ptr(), H=H, W=W, steps_dev=dst.data_ptr(), tile_prefix_dev=dst.data_ptr() + tiles_off,
                 level_first=lf[:n_levels + 1].copy(),
                 tile_prefix=buf[tiles_off:tiles_off + (n_live + 1) * 4].numpy().view(np.int32).copy(), n_levels=n_levels,
-                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=f['work'], keep=(T, dst, st),
-                level_first_dev=dst.data_ptr() + tiles_off + (n_live + 1) * 4)
+                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=f['work'], keep=(T, dst, st))
 
         if deferred:
             fut = _plan_pool().submit(L.oadg_oamix_bbox_plan, *args)
@@ -762,7 +756,7 @@ class OAMix:
         dev = st.img.device
         keep = step.setdefault('keepalive', [])              # descriptor tensors live until the step's launches ran
         steps_dev = _upload(steps.view(np.uint8).reshape(-1), dev)
-        tiles_dev = _upload(np.concatenate([tiles, first]), dev)          # tile prefix, then the level table
+        tiles_dev = _upload(tiles, dev)
         keep += [steps_dev, tiles_dev]
         from .. import hip_ops
         # model bytes of the chain (SURVEY 8d's sum 3 w h term, per blend: the rect is read, its warped source is read,
@@ -772,8 +766,7 @@ class OAMix:
             self._rec.append(('chain', dict(
                 img=T.data_ptr(), H=H, W=W, steps_dev=steps_dev.data_ptr(), tile_prefix_dev=tiles_dev.data_ptr(),
                 level_first=first, tile_prefix=tiles, n_levels=n_levels, My=st.My.data_ptr(), Mx=st.Mx.data_ptr(),
-                scratch=b['scratch'].data_ptr(), work=work, keep=(T, steps_dev, tiles_dev, st),
-                level_first_dev=tiles_dev.data_ptr() + tiles.nbytes)))
+                scratch=b['scratch'].data_ptr(), work=work, keep=(T, steps_dev, tiles_dev, st))))
             return
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
                              first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
