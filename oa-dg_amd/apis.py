@@ -516,13 +516,9 @@ class TrainEngine:
         self.speculative_sampling = os.environ.get('OADG_DEVICE_SAMPLER', '1') == '1'
         self.respeculated = 0           # steps repeated on the host path because an image came up short
         self.ddp = self.reducer = None
-        # Opt-in (OADG_STEP_PRIO=-1|0|1): run the train step on its own HIP stream of that priority
-        # (hipDeviceGetStreamPriorityRange: -1 high .. 1 low on MI355X) so its kernels are dispatched ahead of the data
-        # pipeline's side stream.  Measured (tools/probe/prio.sh): no gain beyond the +-1 ms run-to-run spread, so the
-        # default stays the caller's stream.
-        prio = os.environ.get('OADG_STEP_PRIO', 'none')
-        dev = next(model.parameters()).device
-        self.stream = torch.cuda.Stream(device=dev, priority=int(prio)) if (dev.type == 'cuda' and prio != 'none') else None
+        # (a prioritised stream for the step - kernels dispatched ahead of the data pipeline's side stream - was measured in
+        #  rounds 3-5: no gain beyond the run-to-run spread; the step runs on the caller's stream)
+        self.stream = None
         from . import hip_conv
         # bf16 training on the MI355X runs its convolutions on the csrc MFMA kernels (OADG_CONV=miopen: library path)
         if amp_dtype is torch.bfloat16 and next(model.parameters()).is_cuda and \
@@ -535,9 +531,9 @@ class TrainEngine:
             dev = next(model.parameters()).device
             self.ddp = DDP(model, device_ids=[dev.index] if dev.type == 'cuda' else None,
                            broadcast_buffers=False, find_unused_parameters=find_unused_parameters,
-                           bucket_cap_mb=int(os.environ.get('OADG_DDP_BUCKET_MB', bucket_cap_mb)),
-                           gradient_as_bucket_view=os.environ.get('OADG_DDP_BUCKET_VIEW', '1') == '1',
-                           static_graph=os.environ.get('OADG_DDP_STATIC', '0') == '1')
+                           bucket_cap_mb=int(bucket_cap_mb),
+                           gradient_as_bucket_view=True,
+                           static_graph=False)
 
     def forward_losses(self, data):
         data = integrate_data(data, self.module.train_cfg)

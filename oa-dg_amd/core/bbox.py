@@ -155,8 +155,6 @@ class MaxIoUAssigner:
         (list of AssignResult, counts [B,2] int32 on the device = #(gt_inds > 0), #(gt_inds == 0) per image),
         or None when the configuration / inputs are outside the kernel's domain (callers then loop)."""
         from .. import _lib
-        if os.environ.get('OADG_ASSIGN_LOOP'):      # A/B switch for debugging: force the per-image tensor path
-            return None
         B = len(gt_bboxes_list)
         shared = isinstance(boxes, torch.Tensor)
         first = boxes if shared else boxes[0]

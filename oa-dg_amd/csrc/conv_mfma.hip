@@ -965,10 +965,10 @@ namespace {
 //  - pointwise launches with C <= 256 and K a multiple of 256 (ResNet conv3 / the data gradient of conv1, P2 lateral):
 //    the streaming kernel (variant 4), 1.1-1.2x the 128-tile kernel there (4.2-5.3 TB/s of HBM traffic).
 int auto_variant(long M, int H, int W, int C, int K, int nchunks, int R = 0, int S = 0, int stride = 0, int pad = 0) {
-    // (K = 128: the 256 x 128 instantiation exists - explicit variant 2, or OADG_CONV_256X128=1 - but is NOT chosen: measured
+    // (K = 128: the 256 x 128 instantiation exists - explicit variant 2 - but is NOT chosen: measured
     //  on ResNet layer2's 3x3 (8 x 128 x 256 px, C = K = 128) 555 - 650 TFLOP/s against the 128-tile kernel's 650 - 715: its
     //  phases are 16 MFMAs between barriers, the interval this kernel's own ablation found too short)
-    static const bool narrow256 = getenv("OADG_CONV_256X128") && atoi(getenv("OADG_CONV_256X128")) == 1;
+    constexpr bool narrow256 = false;
     const int tnw = K % TN == 0 ? TN : 128;
     const long big = ((M + TM - 1) / TM) * (K / tnw);
     const bool ok256 = (K % TN == 0 || (K == 128 && narrow256)) && big >= 256 && (long)H * W * C < (1L << 31) && M < (1L << 31);
@@ -1068,9 +1068,9 @@ int conv_launch(const void* x, const void* w, const float* bias, const void* res
         const long m_tiles = (a.M + BM - 1) / BM;
         // 128 x 64 tiles also where 128 x 128 tiles would leave compute units without a workgroup (R101-DC5's 46 x 80 maps:
         // 115 pixel tiles x K / 128 = 230 workgroups of one wave per SIMD each; P5 / P6 of the FPN): twice the workgroups, the
-        // same products in the same order (bit-identical).  OADG_CONV_TBN64_MAX (A/B probes): the largest 128-tile
-        // workgroup count that still takes the narrow tile (default 256; 0 = off).
-        static const long tbn64_max = getenv("OADG_CONV_TBN64_MAX") ? atol(getenv("OADG_CONV_TBN64_MAX")) : 256;
+        // same products in the same order (bit-identical).  tbn64_max: the largest 128-tile workgroup count that still takes
+        // the narrow tile.
+        constexpr long tbn64_max = 256;
         const int tbn = (K % BN == 0 && m_tiles * (K / BN) > tbn64_max) ? BN : 64;
         const long blocks = ((m_tiles + 7) / 8) * 8 * (K / tbn);     // 8 equal XCD ranges (the kernel drops the padding)
         if (blocks > 0x7fffffffL) return OADG_EARG;
@@ -1842,8 +1842,7 @@ int wgrad_stages(int RS) { return RS > 1 ? 1 : 2; }
 // replaces splits / chunks_per_split by the equivalent row-aligned values (never more splits than before).
 int wgrad_strip(int N, int Ho, int Wo, int RS, int& splits, int& chunks_per_split) {
     const long rows = (long)N * Ho;
-    static const bool off = getenv("OADG_WGRAD_STRIP") && getenv("OADG_WGRAD_STRIP")[0] == '0';      // (A/B probes)
-    if (off || RS <= 1 || Wo % WP != 0 || rows < splits || splits < 1) return 0;
+    if (RS <= 1 || Wo % WP != 0 || rows < splits || splits < 1) return 0;
     const long per = (rows + splits - 1) / splits;
     splits = (int)((rows + per - 1) / per);
     chunks_per_split = (int)(per * (Wo / WP));

@@ -377,7 +377,10 @@ def wgrad_multi(jobs, target_blocks=256):
 
 
 def flush_wgrads():
-    """launch the deferred weight gradients collected so far as ONE group (+ one launch of their consumer)"""
+    """launch the deferred weight gradients collected so far as ONE group (+ one launch of their consumer).
+    (Round 6 re-measured the second stream for groups that fill up during the backward pass - this time only for small maps,
+    R101-DC5's 4 x 46 x 80 pixels, where the data-gradient launches leave most of the chip idle: 18.21 / 18.15 ms per step
+    against 18.11 / 18.88 without; R50-FPN with every group there 26.84 against 26.82.  Not kept.)"""
     global _WQ, _WQ_WORK
     jobs, _WQ, _WQ_WORK = _WQ, [], 0
     if not jobs:
@@ -946,7 +949,7 @@ class _Bank:
 
 
 _BANK = _Bank()
-PREP_BANK = os.environ.get('OADG_PREP_BANK', '1') == '1'
+PREP_BANK = True
 
 
 def refresh_prepared():
@@ -1023,8 +1026,8 @@ class GradToken:
         self.masked = masked        # False: t = P(...) without a ReLU (an FPN output): sums and column sums only
 
 
-RELU_BITS = os.environ.get('OADG_RELU_BITS', '1') == '1'
-DEPOSIT = os.environ.get('OADG_GRAD_DEPOSIT', '1') == '1'       # multi-consumer gradient sums inside the dgrad epilogues
+RELU_BITS = True
+DEPOSIT = True       # multi-consumer gradient sums inside the dgrad epilogues
 
 
 def y_numel(x, w, stride, pad, dil):

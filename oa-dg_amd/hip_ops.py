@@ -341,7 +341,7 @@ def cast_all_bf16(params):
     return _CastAll.apply(*params)
 
 
-FC_CAST_ONCE = os.environ.get('OADG_FC_CAST_ONCE', '1') == '1'
+FC_CAST_ONCE = True
 
 
 # --------------------------------------------------------------------------------------- FC weight on NHWC features
@@ -378,7 +378,7 @@ def fc_weight_permuted(weight, C, P):
     return _FcWeightPermute.apply(weight, int(C), int(P))
 
 
-FC_PERMUTE = os.environ.get('OADG_FC_PERMUTE', '1') == '1'
+FC_PERMUTE = True
 
 
 # --------------------------------------------------------------------------------------- RoIAlign
@@ -396,14 +396,14 @@ def _as_nhwc(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-ROI_LOCALITY_ORDER = os.environ.get('OADG_ROI_ORDER', '1') == '1'
+ROI_LOCALITY_ORDER = True
 # bf16 backward by output tiles (csrc roi_align_bwd_tiles: no fp32 maps, no zero fill, no atomics, no cast pass,
 # deterministic summation order).  Round 3: the default - with the pair loop pipelined (next slab in flight, bin ranges
 # per tile row / column, one barrier per pair, 8 waves) a hot coarse-level tile no longer dominates the launch; the
 # fp32 atomic scatter (OADG_ROI_BWD_TILES=0; fp32 atomics retire at ~1.2 TB/s of 4-byte adds on this chip whatever their
 # scope - tools/probe/atomic_lab.hip - so 236 M of them cannot take less than 0.8 ms) stays for fp32 maps and PH, PW > 8.
 BWD_TILES = os.environ.get('OADG_ROI_BWD_TILES', '1') == '1'
-ROI_ORDER_ONE_LAUNCH = os.environ.get('OADG_ROI_ORDER_ONE_LAUNCH', '1') == '1'
+ROI_ORDER_ONE_LAUNCH = True
 _GROUP_KEYS = {}
 
 

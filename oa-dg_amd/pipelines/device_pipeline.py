@@ -98,7 +98,7 @@ def _side_stream(device):
     """the pipeline's HIP stream.  (Round 5 tried a CU-masked stream here - hipExtStreamCreateWithCUMask, 16 / 32 / 64 of the
     256 compute units, so that OA-Mix's ~400 small launches stop taking compute units from under the training stream's
     one-workgroup-per-CU kernels: the pipeline itself became the bottleneck, 27.6 -> 42 - 62 ms per step)"""
-    return torch.cuda.Stream(device=device, priority=int(os.environ.get('OADG_PIPE_PRIO', '0')))
+    return torch.cuda.Stream(device=device)
 
 
 class DevicePipeline:
