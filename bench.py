@@ -229,7 +229,7 @@ FAMILIES = (('conv256 forward / data gradient', ('conv_igemm256_kernel',), 'mfma
              ('conv_wgrad256_kernel', 'conv_wgrad256_multi_kernel'), 'mfma'),
             ('weight gradient 128-tile', ('conv_wgrad_kernel',), 'hbm'),
             ('pointwise streaming (1x1, C <= 512)', ('conv_pw_stream_kernel',), 'hbm'),
-            ('128-tile convolution', ('conv_igemm_kernel',), 'mfma'),
+            ('128-tile convolution', ('conv_igemm_kernel', 'conv_igemm_s2_kernel'), 'mfma'),
             ('16-channel RPN head (rpn_cls + rpn_reg: forward, data gradient, weight gradient)', ('n16_',), 'hbm'),
             ('frozen stage-1 bottleneck blocks (one launch per block)', ('bottleneck_frozen',), 'hbm'))
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32 matrix (xf32-free) MFMA peak

@@ -52,9 +52,10 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 __device__ __forceinline__ long sat_int(double v) {
-    v = rint(v);
-    v = fmin(fmax(v, -2147483648.0), 2147483647.0);
-    return (long)v;
+    // cv::saturate_cast<int>(cvRound(v)): round to nearest even, clamp to the int range - exactly what v_cvt_i32_f64 does
+    // in ONE instruction (the rint / fmin / fmax / double -> int64 sequence it replaces was ~25: four of them per pixel were
+    // a third of the per-box blend kernel's instructions)
+    return (long)__double2int_rn(v);
 }
 
 struct Warp {
@@ -382,23 +383,39 @@ __device__ __forceinline__ void blend4(const uint8_t* img, int H, int W, const o
 #pragma unroll
     for (int k = 0; k < 6; ++k) wp.m[k] = st.minv[k];
     pk[0] = pk[1] = pk[2] = 0u;
+    int yy = i0 / rw, xx = i0 - yy * rw;           // (one division per thread; the next pixels step along the rect's rows)
+    int my_row = -1;
+    float my_val = 0.f;
+    long rowX = 0, rowY = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int i = i0 + u;
+        if (u > 0) {
+            ++xx;
+            while (xx >= rw) { xx -= rw; ++yy; }
+        }
         if (i < rw * rh) {
-            const int yy = i / rw, xx = i - yy * rw;
             const int x = st.rect[0] + xx, y = st.rect[1] + yy;
-            long X, Y;
-            warp_xy(wp, x, y, X, Y);
+            if (y != my_row) {                     // (the four pixels mostly share a row: its terms once - warp_xy's X0 / Y0)
+                my_row = y; my_val = my[y];
+                rowX = sat_int((wp.m[1] * (double)y + wp.m[2]) * 1024.0) + 16;
+                rowY = sat_int((wp.m[4] * (double)y + wp.m[5]) * 1024.0) + 16;
+            }
+            const long X = (rowX + sat_int(wp.m[0] * (double)x * 1024.0)) >> 5;
+            const long Y = (rowY + sat_int(wp.m[3] * (double)x * 1024.0)) >> 5;
             int wv[3];
             warp_pixel(img, H, W, X, Y, wv);
-            const float b = my[y] * mx[x];
+            const float b = my_val * mx[x];
             const float m = 1.0f - b;
             const float om = 1.0f - m;
             const size_t p = ((size_t)y * W + x) * 3;
+            // the pixel's three bytes in one unaligned 4-byte load (the image's very last pixel: byte by byte)
+            unsigned px;
+            if (p + 4 <= (size_t)H * W * 3) __builtin_memcpy(&px, img + p, 4);
+            else px = (unsigned)img[p] | ((unsigned)img[p + 1] << 8) | ((unsigned)img[p + 2] << 16);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = (float)img[p + c] * m + (float)wv[c] * om;
+                const float v = (float)((px >> (8 * c)) & 255u) * m + (float)wv[c] * om;
                 const unsigned byte = (unsigned)(uint8_t)v;
                 const int bi = u * 3 + c;
                 pk[bi >> 2] |= byte << ((bi & 3) * 8);
@@ -441,39 +458,73 @@ __global__ __launch_bounds__(256) void bbox_blend_multi_kernel(const uint8_t* __
     blend_tile(img, H, W, steps, tile_prefix, first, count, tile_base + blockIdx.x, My, Mx, scratch);
 }
 
-// one thread = one pixel; `quarter` = which 256 pixels of the 1024-pixel blend tile
+// one thread = the 4 consecutive pixels its blend thread wrote: 12 scratch bytes as three aligned dwords (the tail group of a
+// rect byte by byte), 12 image bytes.  (Rounds 2-5: one pixel per thread, four workgroups per tile - three single-byte loads
+// and stores per thread; with the chains of a whole batch x three mixture chains in one launch (round 6) the copy pass had
+// become the longer half of a level: 23.6 us against the blend's 20.)
 __device__ __forceinline__ void copy_tile(uint8_t* __restrict__ img, int W, const oadg_bbox_step* __restrict__ steps,
-                                          const int* __restrict__ tile_prefix, int first, int count, int tile, int quarter,
+                                          const int* __restrict__ tile_prefix, int first, int count, int tile,
                                           const uint8_t* __restrict__ scratch) {
     const int s = find_step(tile_prefix, first, count, tile);
     const oadg_bbox_step st = steps[s];
-    const int rw = st.rect[2], rh = st.rect[3];
-    const int i = (tile - tile_prefix[s]) * 1024 + quarter * 256 + threadIdx.x;
-    if (i >= rw * rh) return;
-    const int yy = i / rw, xx = i - yy * rw;
-    const size_t p = ((size_t)(st.rect[1] + yy) * W + st.rect[0] + xx) * 3;
-    const uint8_t* in = scratch + st.scratch_off + (size_t)i * 3;
-    img[p] = in[0];
-    img[p + 1] = in[1];
-    img[p + 2] = in[2];
+    const int rw = st.rect[2], area = rw * st.rect[3];
+    const int i0 = ((tile - tile_prefix[s]) * 256 + threadIdx.x) * 4;
+    if (i0 >= area) return;
+    const uint8_t* in = scratch + st.scratch_off + (size_t)i0 * 3;                              // 4-byte aligned
+    unsigned pk[3] = {0u, 0u, 0u};
+    const int left = area - i0;
+    if (left >= 4) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(in);
+        pk[0] = q[0]; pk[1] = q[1]; pk[2] = q[2];
+    } else {
+        for (int bi = 0; bi < left * 3; ++bi) pk[bi >> 2] |= (unsigned)in[bi] << ((bi & 3) * 8);
+    }
+    const int yy0 = i0 / rw, xx0 = i0 - yy0 * rw;
+    if (left >= 4 && xx0 + 3 < rw) {                 // the four pixels lie side by side in one image row: 12 contiguous bytes
+        uint8_t* o = img + ((size_t)(st.rect[1] + yy0) * W + st.rect[0] + xx0) * 3;
+        if ((reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+            unsigned* od = reinterpret_cast<unsigned*>(o);
+            od[0] = pk[0]; od[1] = pk[1]; od[2] = pk[2];
+        } else {
+#pragma unroll
+            for (int bi = 0; bi < 12; ++bi) o[bi] = (uint8_t)(pk[bi >> 2] >> ((bi & 3) * 8));
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u;
+        if (i < area) {
+            const int yy = i / rw, xx = i - yy * rw;
+            uint8_t* o = img + ((size_t)(st.rect[1] + yy) * W + st.rect[0] + xx) * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const int bi = u * 3 + ch;
+                o[ch] = (uint8_t)(pk[bi >> 2] >> ((bi & 3) * 8));
+            }
+        }
+    }
 }
 
-// (four workgroups per 1024-pixel tile of the blend kernel)
+// (one workgroup per 1024-pixel tile of the blend kernel)
 __global__ __launch_bounds__(256) void rect_copy_multi_kernel(uint8_t* __restrict__ img, int W,
                                                               const oadg_bbox_step* __restrict__ steps,
                                                               const int* __restrict__ tile_prefix, int first,
                                                               int count, int tile_base,
                                                               const uint8_t* __restrict__ scratch) {
-    copy_tile(img, W, steps, tile_prefix, first, count, tile_base + (blockIdx.x >> 2), blockIdx.x & 3, scratch);
+    copy_tile(img, W, steps, tile_prefix, first, count, tile_base + blockIdx.x, scratch);
 }
 
 // ---- the chains of SEVERAL images in lockstep (round 4) -----------------------------------------------------------------
 // The images of a batch are augmented independently (own work image, own mask profiles, own scratch), and a
 // bboxes_only_* chain needs its launch pair per dependency level only because of the dependencies INSIDE its image.  The
 // pipeline therefore advances the chains of all images of the batch together: level l of every chain in ONE launch pair -
-// launches per batch = 2 x the deepest chain instead of 2 x the sum over the images.  Up to 8 images per launch; their
+// launches per batch = 2 x the deepest chain instead of 2 x the sum over the images.  Up to CHAIN_MAX chains per launch; their
 // descriptors travel by value in the launch arguments and are selected with compile-time indices only (a dynamically
 // indexed argument block would be copied to scratch memory per thread).
+// chains per launch: the images of a batch x the chains of an image that are ready together (three mixture chains, up to
+// three region ops each; round 6) - 24 descriptors of 72 bytes travel in the kernel arguments
+constexpr int CHAIN_MAX = 24;
 struct ChainImg {
     uint8_t* img;
     const oadg_bbox_step* steps;
@@ -484,13 +535,13 @@ struct ChainImg {
     int H, W, first, count, tile_base, block0;        // block0: first workgroup of this image in the launch (blend tiles)
 };
 struct ChainLevel {
-    ChainImg im[8];
+    ChainImg im[CHAIN_MAX];
     int n;
 };
 __device__ __forceinline__ ChainImg pick_image(const ChainLevel& a, int tile) {
     ChainImg s = a.im[0];
 #pragma unroll
-    for (int k = 1; k < 8; ++k)
+    for (int k = 1; k < CHAIN_MAX; ++k)
         if (k < a.n && tile >= a.im[k].block0) s = a.im[k];
     return s;
 }
@@ -500,9 +551,9 @@ __global__ __launch_bounds__(256) void bbox_blend_imgs_kernel(ChainLevel a) {
                s.scratch);
 }
 __global__ __launch_bounds__(256) void rect_copy_imgs_kernel(ChainLevel a) {
-    const int tile = blockIdx.x >> 2;
+    const int tile = blockIdx.x;
     const ChainImg s = pick_image(a, tile);
-    copy_tile(s.img, s.W, s.steps, s.tile_prefix, s.first, s.count, s.tile_base + (tile - s.block0), blockIdx.x & 3, s.scratch);
+    copy_tile(s.img, s.W, s.steps, s.tile_prefix, s.first, s.count, s.tile_base + (tile - s.block0), s.scratch);
 }
 
 // (Round 6, three ways around the launch pair per level, all byte-exact, all measured on BASELINE config 5 and dropped:
@@ -525,7 +576,8 @@ struct ComposeArgs {
     int n_rects;
 };
 
-__device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const uint8_t* src, int H, int W,
+// ``sp``: the pixel's own three source bytes (the caller has them in registers: src[p .. p + 2])
+__device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const uint8_t* src, const uint8_t sp[3], int H, int W,
                                                 int x, int y, const uint8_t* lut_s, const float* uf,
                                                 const uint8_t* u8, uint8_t out[3]) {
     const size_t p = ((size_t)y * W + x) * 3;
@@ -533,14 +585,14 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
         case OADG_OP_LUT_AUTOCONTRAST:
         case OADG_OP_LUT_EQUALIZE: {
             const uint8_t* l = lut_s + (op.kind == OADG_OP_LUT_EQUALIZE ? 768 : 0);
-            out[0] = l[src[p]]; out[1] = l[256 + src[p + 1]]; out[2] = l[512 + src[p + 2]];
+            out[0] = l[sp[0]]; out[1] = l[256 + sp[1]]; out[2] = l[512 + sp[2]];
             break;
         }
         case OADG_OP_POSTERIZE:
-            for (int c = 0; c < 3; ++c) out[c] = src[p + c] & (uint8_t)op.param;
+            for (int c = 0; c < 3; ++c) out[c] = sp[c] & (uint8_t)op.param;
             break;
         case OADG_OP_SOLARIZE:
-            for (int c = 0; c < 3; ++c) { const int v = src[p + c]; out[c] = (uint8_t)(v < op.param ? v : 255 - v); }
+            for (int c = 0; c < 3; ++c) { const int v = sp[c]; out[c] = (uint8_t)(v < op.param ? v : 255 - v); }
             break;
         case OADG_OP_IMAGE: {
             const uint8_t* im = (const uint8_t*)op.image;
@@ -557,7 +609,7 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
             const double keep = fmax((double)uf[(size_t)y * W + x], wm);
             const double ok = 1.0 - keep;
             for (int c = 0; c < 3; ++c) {
-                const double v = keep * (double)src[p + c] + ok * (double)tap_fetch(t, src, 3, c);
+                const double v = keep * (double)sp[c] + ok * (double)tap_fetch(t, src, 3, c);
                 out[c] = (uint8_t)v;
             }
             break;
@@ -573,13 +625,13 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
             if (op.kind == OADG_OP_ENH_BRIGHTNESS) {
                 deg[0] = deg[1] = deg[2] = 0;
             } else if (op.kind == OADG_OP_ENH_COLOR) {
-                deg[0] = deg[1] = deg[2] = (src[p] * 19595 + src[p + 1] * 38470 + src[p + 2] * 7471 + 0x8000) >> 16;
+                deg[0] = deg[1] = deg[2] = (sp[0] * 19595 + sp[1] * 38470 + sp[2] * 7471 + 0x8000) >> 16;
             } else if (op.kind == OADG_OP_ENH_CONTRAST) {
                 const long long sum = *reinterpret_cast<const long long*>(op.image);
                 deg[0] = deg[1] = deg[2] = (int)((double)sum / (double)((long)H * W) + 0.5);
             } else {
                 if (x == 0 || y == 0 || x == W - 1 || y == H - 1) {
-                    deg[0] = src[p]; deg[1] = src[p + 1]; deg[2] = src[p + 2];
+                    deg[0] = sp[0]; deg[1] = sp[1]; deg[2] = sp[2];
                 } else {
                     const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
                     for (int c = 0; c < 3; ++c) {
@@ -594,7 +646,7 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
                 }
             }
             for (int c = 0; c < 3; ++c) {
-                const int a0 = deg[c], b0 = src[p + c];
+                const int a0 = deg[c], b0 = sp[c];
                 const float t = (float)a0 + alpha * (float)(b0 - a0);
                 if (alpha >= 0.f && alpha <= 1.f) out[c] = (uint8_t)t;
                 else out[c] = t <= 0.f ? 0 : (t >= 255.f ? 255 : (uint8_t)t);
@@ -611,7 +663,7 @@ __device__ __forceinline__ void apply_region_op(const oadg_region_op& op, const 
             break;
         }
         default:
-            out[0] = src[p]; out[1] = src[p + 1]; out[2] = src[p + 2];
+            out[0] = sp[0]; out[1] = sp[1]; out[2] = sp[2];
     }
 }
 
@@ -631,13 +683,69 @@ __global__ __launch_bounds__(256) void compose_kernel(const uint8_t* __restrict_
         for (int k = 0; k < a.n_rects; ++k)
             if (x >= a.rect[k][0] && x < a.rect[k][2] && y >= a.rect[k][1] && y < a.rect[k][3]) r = k;
         uint8_t o[3];
-        apply_region_op(a.op[r], src, H, W, x, y, lut_s, uf, u8, o);
+        const uint8_t sp[3] = {src[p * 3], src[p * 3 + 1], src[p * 3 + 2]};
+        apply_region_op(a.op[r], src, sp, H, W, x, y, lut_s, uf, u8, o);
         dst[p * 3] = o[0]; dst[p * 3 + 1] = o[1]; dst[p * 3 + 2] = o[2];
         if (acc_mode) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float t = acc_w * (float)o[c];
                 acc[p * 3 + c] = acc_mode == 1 ? t : acc[p * 3 + c] + t;
+            }
+        }
+    }
+}
+
+// the same pass with FOUR pixels per thread (W % 4 == 0, 16-byte aligned buffers): source, result and accumulator travel as
+// three 4-byte / 16-byte accesses per thread instead of twelve single-byte ones (round 6: the one-pixel form moved a
+// 6.3 MB image at 0.25 TB/s - 52 us per compose step, 25 steps per training step).  Per pixel the same arithmetic: byte-identical.
+__global__ __launch_bounds__(256) void compose4_kernel(const uint8_t* __restrict__ src,
+                                                       uint8_t* __restrict__ dst, int H, int W,
+                                                       ComposeArgs a, const uint8_t* __restrict__ luts,
+                                                       const float* __restrict__ uf,
+                                                       const uint8_t* __restrict__ u8,
+                                                       float* __restrict__ acc, float acc_w, int acc_mode) {
+    __shared__ uint8_t lut_s[2 * 768];
+    if (luts)
+        for (int i = threadIdx.x; i < 2 * 768; i += 256) lut_s[i] = luts[i];
+    __syncthreads();
+    const long nq = (long)H * W / 4;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nq; q += (long)gridDim.x * 256) {
+        const long p0 = q * 4;
+        const int y = (int)(p0 / W), x0 = (int)(p0 - (long)y * W);
+        const unsigned* s32 = reinterpret_cast<const unsigned*>(src + p0 * 3);
+        const unsigned sw[3] = {s32[0], s32[1], s32[2]};
+        unsigned ow[3] = {0u, 0u, 0u};
+        float of[12];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = x0 + u;
+            int r = 2;
+            for (int k = 0; k < a.n_rects; ++k)
+                if (x >= a.rect[k][0] && x < a.rect[k][2] && y >= a.rect[k][1] && y < a.rect[k][3]) r = k;
+            uint8_t sp[3], o[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { const int bi = u * 3 + c; sp[c] = (uint8_t)(sw[bi >> 2] >> ((bi & 3) * 8)); }
+            apply_region_op(a.op[r], src, sp, H, W, x, y, lut_s, uf, u8, o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int bi = u * 3 + c;
+                ow[bi >> 2] |= (unsigned)o[c] << ((bi & 3) * 8);
+                of[bi] = acc_w * (float)o[c];
+            }
+        }
+        unsigned* d32 = reinterpret_cast<unsigned*>(dst + p0 * 3);
+        d32[0] = ow[0]; d32[1] = ow[1]; d32[2] = ow[2];
+        if (acc_mode) {
+            float4* a4 = reinterpret_cast<float4*>(acc + p0 * 3);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                float4 t = make_float4(of[4 * v], of[4 * v + 1], of[4 * v + 2], of[4 * v + 3]);
+                if (acc_mode != 1) {
+                    const float4 old = a4[v];
+                    t.x = old.x + t.x; t.y = old.y + t.y; t.z = old.z + t.z; t.w = old.w + t.w;
+                }
+                a4[v] = t;
             }
         }
     }
@@ -881,17 +989,24 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     __syncthreads();
     fft64_lines(re, im, tw_re, tw_im, false, false);
     fft64_lines(re, im, tw_re, tw_im, true, false);
-    // log amplitude in `sal`-free storage: keep angle in im, log-magnitude in re
-    for (int i = tid; i < SN * SN; i += 256) {
+    // log amplitude -> re; the spectrum's unit phasors (cos, sin of its angle = re / |.|, im / |.|) stay in registers: thread
+    // tid owns the points tid + 256 k in every pass.  (Rounds 1-5 stored atan2(im, re) and took sincos of it again two passes
+    // later: three double-precision transcendentals per point for a division - the kernel was bound by them, 100 us per crop.)
+    double uc[16], us[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int i = tid + k * 256;
         const int p = (i >> 6) * SLD + (i & 63);
-        const double mag = hypot(re[p], im[p]);
-        const double ang = atan2(im[p], re[p]);
+        const double a = re[p], b_ = im[p];
+        const double mag = sqrt(a * a + b_ * b_);
+        uc[k] = a / mag;                        // (mag == 0: NaN here, and log(0) = -inf makes the whole map NaN anyway - as before)
+        us[k] = b_ / mag;
         re[p] = log(mag);
-        im[p] = ang;
     }
     __syncthreads();
     // residual = exp(L - boxblur3(L)) ; needs L intact while reading neighbours -> stage result in registers
     double resid[16];
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = tid + k * 256;
         const int y = i / SN, x = i - y * SN;
@@ -901,20 +1016,19 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
         resid[k] = exp(re[y * SLD + x] - s / 9.0);
     }
     __syncthreads();
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int i = tid + k * 256;
         const int p = (i >> 6) * SLD + (i & 63);
-        double sn, cs;
-        sincos(im[p], &sn, &cs);
-        re[p] = resid[k] * cs;
-        im[p] = resid[k] * sn;
+        re[p] = resid[k] * uc[k];
+        im[p] = resid[k] * us[k];
     }
     __syncthreads();
     fft64_lines(re, im, tw_re, tw_im, false, true);
     fft64_lines(re, im, tw_re, tw_im, true, true);
     for (int i = tid; i < SN * SN; i += 256) {
         const int p = (i >> 6) * SLD + (i & 63);
-        re[p] = hypot(re[p], im[p]);
+        re[p] = sqrt(re[p] * re[p] + im[p] * im[p]);
     }
     __syncthreads();
     // 5x5 Gaussian sigma 8 (separable, reflect101): horizontal into im, vertical back into re
@@ -1153,7 +1267,7 @@ int oadg_oamix_bbox_chain(uint8_t* img, int H, int W, const oadg_bbox_step* step
         hipLaunchKernelGGL(bbox_blend_multi_kernel, dim3(tiles), dim3(256), 0, st, (const uint8_t*)img, H, W,
                            steps_dev, tile_prefix_dev, first, count, tile_base, My, Mx, scratch);
         OADG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles * 4), dim3(256), 0, st, img, W, steps_dev,
+        hipLaunchKernelGGL(rect_copy_multi_kernel, dim3(tiles), dim3(256), 0, st, img, W, steps_dev,
                            tile_prefix_dev, first, count, tile_base, (const uint8_t*)scratch);
         OADG_LAUNCH_CHECK();
     }
@@ -1177,11 +1291,11 @@ int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void*
     }
     hipStream_t st = (hipStream_t)stream;
     for (int l = 0; l < deepest; ++l) {
-        for (int i0 = 0; i0 < n; i0 += 8) {
+        for (int i0 = 0; i0 < n; i0 += CHAIN_MAX) {
             ChainLevel a;
             a.n = 0;
             int blocks = 0;
-            for (int i = i0; i < n && i < i0 + 8; ++i) {
+            for (int i = i0; i < n && i < i0 + CHAIN_MAX; ++i) {
                 const oadg_bbox_chain& c = chains_host[i];
                 if (l >= c.n_levels) continue;
                 const int first = c.level_first_host[l], count = c.level_first_host[l + 1] - first;
@@ -1196,10 +1310,10 @@ int oadg_oamix_bbox_chain_multi(const oadg_bbox_chain* chains_host, int n, void*
                 blocks += tiles;
             }
             if (a.n == 0) continue;
-            for (int k = a.n; k < 8; ++k) a.im[k] = a.im[0];
+            for (int k = a.n; k < CHAIN_MAX; ++k) a.im[k] = a.im[0];
             hipLaunchKernelGGL(bbox_blend_imgs_kernel, dim3(blocks), dim3(256), 0, st, a);
             OADG_LAUNCH_CHECK();
-            hipLaunchKernelGGL(rect_copy_imgs_kernel, dim3(blocks * 4), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(rect_copy_imgs_kernel, dim3(blocks), dim3(256), 0, st, a);
             OADG_LAUNCH_CHECK();
         }
     }
@@ -1222,10 +1336,15 @@ int oadg_oamix_compose(const uint8_t* src, uint8_t* dst, int H, int W, const oad
     }
     for (int k = 0; k < 2; ++k)
         for (int j = 0; j < 4; ++j) a.rect[k][j] = (k < n_rects) ? rects_host[4 * k + j] : 0;
-    int g = grid1d((long)H * W, 256);
+    const bool quad = (W & 3) == 0 && ((((uintptr_t)src) | ((uintptr_t)dst)) & 3) == 0 && (((uintptr_t)acc) & 15) == 0;
+    int g = grid1d(quad ? (long)H * W / 4 : (long)H * W, 256);
     if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(compose_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, a, luts,
-                       union_f, union_u8, acc, acc_w, acc_mode);
+    if (quad)
+        hipLaunchKernelGGL(compose4_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, a, luts,
+                           union_f, union_u8, acc, acc_w, acc_mode);
+    else
+        hipLaunchKernelGGL(compose_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, a, luts,
+                           union_f, union_u8, acc, acc_w, acc_mode);
     OADG_LAUNCH_CHECK();
     return OADG_OK;
 }

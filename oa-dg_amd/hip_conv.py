@@ -558,8 +558,10 @@ def conv_dgrad_s2(gy, wt, xshape, R, mask=None, want_colsum=False, mask_bits=Non
         TIMERS.append((e0, e1, 2.0 * N * Ho * Wo * K * C * R * R,
                        2.0 * (N * Ho * Wo * K + K * C * R * R + N * H * W * C * (1 + (accumulate is not None) + (mask is not None)))
                        + N * H * W * C / 8.0 * (mask_bits is not None),
-                       kernel_name(3, K, C, 2, 2, 1, 0, accumulate is not None, mask is not None, mask_bits is not None, False,
-                                   scatter=True) + ' x%d (stride-2 dgrad classes)' % len(geo),
+                       ('conv_igemm_s2_kernel<%d, %s>' % (128 if C % 128 == 0 else 64, 'true' if post else 'false')
+                        if S2_ONE_LAUNCH else
+                        kernel_name(3, K, C, 2, 2, 1, 0, accumulate is not None, mask is not None, mask_bits is not None, False,
+                                    scatter=True)) + ' x%d (stride-2 dgrad classes)' % len(geo),
                        (N, Ho, Wo, K, C, R, 2, accumulate is not None, mask is not None, 1)))
     if want_colsum:
         return gx, _colsum(part, C)

@@ -57,6 +57,8 @@ BBOX_CHAIN_DTYPE = np.dtype([('img', '<u8'), ('steps_dev', '<u8'), ('tile_prefix
                              ('tile_prefix_host', '<u8'), ('My', '<u8'), ('Mx', '<u8'), ('scratch', '<u8'), ('H', '<i4'),
                              ('W', '<i4'), ('n_levels', '<i4'), ('pad_', '<i4')])                        # oadg_bbox_chain
 LOCKSTEP = os.environ.get('OADG_OAMIX_LOCKSTEP', '1') == '1'    # the images of a batch advance their per-box chains together
+LANES = int(os.environ.get('OADG_OAMIX_LANES', '3'))    # buffer sets per image inside the lockstep pass (one per mixture
+                                                        # chain; 1: the chains share a set and follow each other)
 BATCH_BOXES = True      # bboxes_only_*: all boxes of an image in 2 launches per dependency level (False: 2 per box)
 PLAN_IN_C = os.environ.get('OADG_OAMIX_PLAN_C', '1') == '1'     # the op's host arithmetic in one C call (else numpy)
 PLAN_THREADS = int(os.environ.get('OADG_OAMIX_PLAN_THREADS', '4'))    # planner threads of the lockstep pass (0: none)
@@ -64,6 +66,11 @@ MIX_TILES_MIN_TARGETS = 64      # from this many mixing targets on object_aware_
 UNION_RECTS_MIN_BOXES = 64      # from this many boxes on the fg-mask union is built from the masks' support rects
 ASYNC_PLAN_MIN_BOXES = 512      # below this a plan call takes less than the hand-over to a thread
 _PLAN_POOL = None
+
+
+def _ids(tensors):
+    """resource ids of a command's operands (the buffers' addresses)"""
+    return tuple(t.data_ptr() for t in tensors if t is not None)
 
 
 def _plan_pool():
@@ -347,17 +354,19 @@ class OAMix:
         self.kwargs = kwargs            # unknown kwargs are swallowed like the reference (oa_mix.py:72)
         self._bufs = {}
         self._rec = None                # a list while oamix_many() records an image's device commands
+        self._lane = 0                  # which private buffer set the commands being recorded work on (see _buffers)
         self._pending_plans = 0         # plans handed to planner threads whose staging slots are still taken
         self.trace = None               # set to [] to record the op sequence (tests)
         self.stats = None               # set to {} to count compose steps / bbox-step pixels (tools/bench_oamix.py)
 
     # ------------------------------------------------------------------------------------------ lockstep
-    def _do(self, fn):
-        """a device command of the current image: now, or - inside oamix_many() - appended to the image's command list"""
+    def _do(self, fn, reads=(), writes=()):
+        """a device command of the current image: now, or - inside oamix_many() - appended to the image's command list
+        together with the buffers it reads / writes (tensors; ``execute`` orders commands by them)"""
         if self._rec is None:
             fn()
         else:
-            self._rec.append(('call', fn))
+            self._rec.append(('call', fn, _ids(reads), _ids(writes)))
 
     def oamix_many(self, states, out_norms, norm, pad_shape):
         """``oamix`` for the images of a batch with their ``bboxes_only_*`` chains advanced in LOCKSTEP.  The host side runs
@@ -380,6 +389,7 @@ class OAMix:
         it would have issued (``execute`` runs the lists of a batch in lockstep).  ``slot`` selects the image's private
         work buffers.  Returns (command list, history)."""
         st.slot = slot
+        self._lane = 0
         self._history, self._rec = {}, []
         try:
             self.oamix(st, out_u8=None, out_norm=out_norm, norm=norm, pad_shape=pad_shape)
@@ -388,61 +398,115 @@ class OAMix:
         return rec, self._history
 
     def execute(self, recs):
-        """issue the recorded command lists of a batch's images on the current stream: every image up to its next per-box
-        chain, then those chains together, level by level (csrc oadg_oamix_bbox_chain_multi)"""
+        """issue the recorded command lists of a batch's images on the current stream.  Every command carries the buffers
+        it reads and writes; a command may go out as soon as every EARLIER command of its image that touches one of them
+        in a conflicting way has gone out (one stream: issue order = execution order), so commands on disjoint buffers -
+        the three mixture chains of a view, the up to three region ops of a compose step, each on a buffer set of its own -
+        overtake each other freely, while e.g. the accumulator still receives the chains' results in the reference's
+        order.  All per-box chains that are ready at the same time - of all images, all mixture chains, all region ops -
+        advance level by level TOGETHER in one csrc oadg_oamix_bbox_chain_multi call (round 6; rounds 4-5 batched one
+        chain per image at a time: a third as many launch rounds now)."""
+        import heapq
         L = _lib.lib()
-        at = [0] * len(recs)
         from .. import hip_ops
-        while True:
-            for i, rec in enumerate(recs):
-                while at[i] < len(rec) and rec[at[i]][0] != 'chain':
-                    kind, payload = rec[at[i]]
+        graphs, heaps = [], []
+        for rec in recs:
+            nodes, last_w, readers = [], {}, {}
+            for idx, cmd in enumerate(rec):
+                reads, writes = cmd[2], cmd[3]
+                deps = set()
+                for r in reads:
+                    if r in last_w:
+                        deps.add(last_w[r])
+                for w in writes:
+                    if w in last_w:
+                        deps.add(last_w[w])
+                    deps.update(readers.get(w, ()))
+                for d in deps:
+                    nodes[d][3].append(idx)
+                for r in reads:
+                    readers.setdefault(r, []).append(idx)
+                for w in writes:
+                    last_w[w] = idx
+                    readers[w] = []
+                nodes.append([cmd[0], cmd[1], len(deps), []])        # kind, payload, open dependencies, successors
+            graphs.append(nodes)
+            heaps.append([i for i, nd in enumerate(nodes) if nd[2] == 0])        # (ascending = a valid heap)
+
+        def complete(g, i):
+            for s_ in graphs[g][i][3]:
+                graphs[g][s_][2] -= 1
+                if graphs[g][s_][2] == 0:
+                    heapq.heappush(heaps[g], s_)
+
+        left = sum(len(nodes) for nodes in graphs)
+        while left:
+            batch = []
+            for g, heap in enumerate(heaps):
+                while heap:
+                    i = heapq.heappop(heap)
+                    kind, payload = graphs[g][i][0], graphs[g][i][1]
+                    if kind == 'plan':              # a plan that ran on a planner thread: its chain, or nothing
+                        payload = payload()
+                        kind = 'chain' if payload is not None else 'done'
+                    if kind == 'chain':
+                        batch.append((g, i, payload))
+                        continue
                     if kind == 'call':
                         payload()
-                    else:                       # 'plan': a plan that ran on a planner thread - its chain, or nothing
-                        c = payload()
-                        if c is not None:
-                            rec[at[i]] = ('chain', c)
-                            continue
-                    at[i] += 1
-            ready = [i for i, rec in enumerate(recs) if at[i] < len(rec)]
-            if not ready:
+                    left -= 1
+                    complete(g, i)
+            if not batch:
+                assert left == 0, 'OA-Mix command graph did not drain'
                 break
-            tab = np.zeros((len(ready),), BBOX_CHAIN_DTYPE)
+            tab = np.zeros((len(batch),), BBOX_CHAIN_DTYPE)
             work = 0.0
-            for r, i in zip(tab, ready):
-                c = recs[i][at[i]][1]
+            for r, (_, _, c) in zip(tab, batch):
                 r['img'], r['steps_dev'], r['tile_prefix_dev'] = c['img'], c['steps_dev'], c['tile_prefix_dev']
                 r['level_first_host'], r['tile_prefix_host'] = c['level_first'].ctypes.data, c['tile_prefix'].ctypes.data
                 r['My'], r['Mx'], r['scratch'], r['H'], r['W'], r['n_levels'] = c['My'], c['Mx'], c['scratch'], c['H'], c['W'], c['n_levels']
                 work += c['work']
             check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain_multi, tab.ctypes.data_as(ctypes.c_void_p),
-                                 len(ready), stream_ptr(), work=work), 'oadg_oamix_bbox_chain_multi')
+                                 len(batch), stream_ptr(), work=work), 'oadg_oamix_bbox_chain_multi')
             if self.stats is not None:
                 self.stats['lockstep_rounds'] = self.stats.get('lockstep_rounds', 0) + 1
                 self.stats['lockstep_levels'] = self.stats.get('lockstep_levels', 0) + int(tab['n_levels'].max())
-            for i in ready:
-                at[i] += 1
+                self.stats['lockstep_chains'] = self.stats.get('lockstep_chains', 0) + len(batch)
+            for g, i, _ in batch:
+                left -= 1
+                complete(g, i)
 
     # ------------------------------------------------------------------------------------------ buffers
     def _buffers(self, st):
-        key = (st.H, st.W, str(st.img.device), getattr(st, 'slot', 0))
+        """the work buffers of (image slot, lane): two ping-pong images, three region-op images with a scratch image each,
+        histogram / LUT / grey-sum cells; the fp32 accumulator belongs to the slot (all lanes add into it).  Lane 0 is the
+        only one outside the lockstep pass; inside it every mixture chain of a view records on a lane of its own, so that
+        ``execute`` may run the chains' per-box levels side by side."""
+        lane = self._lane
+        key = (st.H, st.W, str(st.img.device), getattr(st, 'slot', 0), lane)
         b = self._bufs.get(key)
         if b is None:
             dev, H, W = st.img.device, st.H, st.W
             u8 = lambda: torch.empty((H, W, 3), dtype=torch.uint8, device=dev)  # noqa: E731
-            b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()],
-                     scratch=torch.empty((H * W * 3 + 4 * 8192 + 64,), dtype=torch.uint8, device=dev),
-                     acc=torch.empty((H, W, 3), dtype=torch.float32, device=dev),
+            sc = lambda: torch.empty((H * W * 3 + 4 * 8192 + 64,), dtype=torch.uint8, device=dev)  # noqa: E731
+            b = dict(ping=[u8(), u8()], tmp=[u8(), u8(), u8()], scratch=[sc(), sc(), sc()],
                      hist=torch.empty((768,), dtype=torch.int32, device=dev),
                      luts=torch.empty((2 * 768,), dtype=torch.uint8, device=dev),
                      gray=torch.empty((1,), dtype=torch.int64, device=dev))
-            # bounded by BYTES (ADVICE r4): a set is 30 bytes per pixel (six uint8 images + the fp32 accumulator = 63 MB at
-            # 1024 x 2048); per-sample multi-scale brings a new shape per image, so the oldest sets go once the cache
-            # holds more than OADG_OAMIX_CACHE_MB (default 768: twelve full-size sets - the lockstep pass of a batch of
-            # eight plus headroom).  A set still referenced by recorded commands stays alive through their closures.
-            b['bytes'] = 30 * H * W
-            limit = int(os.environ.get('OADG_OAMIX_CACHE_MB', 768)) << 20
+            if lane == 0:
+                b['acc'] = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            else:
+                self._lane = 0
+                try:
+                    b['acc'] = self._buffers(st)['acc']
+                finally:
+                    self._lane = lane
+            # bounded by BYTES (ADVICE r4): a lane's set is 24 bytes per pixel (eight uint8 images = 50 MB at 1024 x 2048),
+            # the accumulator 12; per-sample multi-scale brings a new shape per image, so the oldest sets go once the cache
+            # holds more than OADG_OAMIX_CACHE_MB (default 2048: the lockstep pass of a batch of eight with three lanes
+            # each plus headroom).  A set still referenced by recorded commands stays alive through their closures.
+            b['bytes'] = (24 + (12 if lane == 0 else 0)) * H * W
+            limit = int(os.environ.get('OADG_OAMIX_CACHE_MB', 2048)) << 20
             while self._bufs and sum(v['bytes'] for v in self._bufs.values()) + b['bytes'] > limit:
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[key] = b
@@ -486,7 +550,7 @@ class OAMix:
             def run(src=src, b=b, n=st.H * st.W):
                 check(L.oadg_oamix_hist(ptr(src), n, ptr(b['hist']), stream_ptr()), 'oadg_oamix_hist')
                 check(L.oadg_oamix_luts(ptr(b['hist']), ptr(b['luts']), stream_ptr()), 'oadg_oamix_luts')
-            self._do(run)
+            self._do(run, reads=(src,), writes=(b['hist'], b['luts']))
             step['luts_for'] = src
 
     def _aug(self, st, src, step):
@@ -518,7 +582,8 @@ class OAMix:
                 if step.get('gray_for') is not src:
                     b = self._buffers(st)
                     self._do(lambda src=src, b=b, n=st.H * st.W: check(
-                        _lib.lib().oadg_oamix_gray_sum(ptr(src), n, ptr(b['gray']), stream_ptr()), 'oadg_oamix_gray_sum'))
+                        _lib.lib().oadg_oamix_gray_sum(ptr(src), n, ptr(b['gray']), stream_ptr()), 'oadg_oamix_gray_sum'),
+                        reads=(src,), writes=(b['gray'],))
                     step['gray_for'] = src
                 op.image = self._buffers(st)['gray'].data_ptr()
         else:
@@ -539,8 +604,9 @@ class OAMix:
         L = _lib.lib()
         b = self._buffers(st)
         T = b['tmp'][step['n_tmp']]
+        step['scratch'] = b['scratch'][step['n_tmp']]          # (a scratch image per region op: their chains may run side by side)
         step['n_tmp'] += 1
-        self._do(lambda T=T, src=src: T.copy_(src))
+        self._do(lambda T=T, src=src: T.copy_(src), reads=(src,), writes=(T,))
         H, W = st.H, st.W
         if BATCH_BOXES and PLAN_IN_C:
             self._bbox_chain_c(st, T, kind, step)
@@ -559,11 +625,11 @@ class OAMix:
                 if sup is None or sup[2] <= 0 or sup[3] <= 0:
                     continue                                     # mask identically zero: image unchanged
                 minv = (ctypes.c_double * 6)(*invert_affine(M))
-                self._do(lambda minv=minv, sup=sup, i=i: check(
+                self._do(lambda minv=minv, sup=sup, i=i, scr=step['scratch']: check(
                     L.oadg_oamix_bbox_step(ptr(T), H, W, minv, sup[0], sup[1], sup[2], sup[3],
                                            ctypes.c_void_p(st.My.data_ptr() + 4 * i * H),
-                                           ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(b['scratch']),
-                                           stream_ptr()), 'oadg_oamix_bbox_step'))
+                                           ctypes.c_void_p(st.Mx.data_ptr() + 4 * i * W), ptr(scr),
+                                           stream_ptr()), 'oadg_oamix_bbox_step'), writes=(T, step['scratch']))
         if self.stats is not None:
             self.stats['bbox_ops'] = self.stats.get('bbox_ops', 0) + 1
             sup_ = st.plan_arrays()[1].astype(np.int64)
@@ -580,7 +646,7 @@ class OAMix:
         stream order; nothing of the plan is needed before the batch's commands are executed): the ~0.8 ms per op of a
         4096-box image overlap the recording of the following ops and images."""
         L = _lib.lib()
-        b = self._buffers(st)
+        scratch = step['scratch']
         H, W = st.H, st.W
         ib, sup, m = st.plan_arrays()
         n = st.n
@@ -638,7 +704,7 @@ class OAMix:
                 img=T.data_ptr(), H=H, W=W, steps_dev=dst.data_ptr(), tile_prefix_dev=dst.data_ptr() + tiles_off,
                 level_first=lf[:n_levels + 1].copy(),
                 tile_prefix=buf[tiles_off:tiles_off + (n_live + 1) * 4].numpy().view(np.int32).copy(), n_levels=n_levels,
-                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=b['scratch'].data_ptr(), work=f['work'], keep=(T, dst, st))
+                My=st.My.data_ptr(), Mx=st.Mx.data_ptr(), scratch=scratch.data_ptr(), work=f['work'], keep=(T, dst, st, scratch))
 
         if deferred:
             fut = _plan_pool().submit(L.oadg_oamix_bbox_plan, *args)
@@ -648,20 +714,20 @@ class OAMix:
                 self._pending_plans -= 1
                 f = finish(fut.result())
                 return None if f is None else chain_rec(f)
-            self._rec.append(('plan', resolve))
+            self._rec.append(('plan', resolve, (), _ids((T, scratch))))
             return
         f = finish(L.oadg_oamix_bbox_plan(*args))
         if f is None:
             return
         if self._rec is not None:
-            self._rec.append(('chain', chain_rec(f)))
+            self._rec.append(('chain', chain_rec(f), (), _ids((T, scratch))))
             return
         dst, tiles_off = f['dst'], f['tiles_off']
         from .. import hip_ops
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, dst.data_ptr(),
                              dst.data_ptr() + tiles_off, lf.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), f['n_levels'],
                              ctypes.cast(buf.data_ptr() + tiles_off, ctypes.POINTER(ctypes.c_int)), ptr(st.My),
-                             ptr(st.Mx), ptr(b['scratch']), stream_ptr(), work=f['work']), 'oadg_oamix_bbox_chain')
+                             ptr(st.Mx), ptr(scratch), stream_ptr(), work=f['work']), 'oadg_oamix_bbox_chain')
 
     def _box_matrices(self, st, kind):
         """The per-box loop above for ALL boxes at once: (rows, rects [m,4], inverted matrices [m,6]) of the boxes that
@@ -726,7 +792,7 @@ class OAMix:
         """all boxes of one bboxes_only_* op: steps sorted by dependency level, one descriptor upload, 2 launches per
         level (csrc oadg_oamix_bbox_chain)"""
         L = _lib.lib()
-        b = self._buffers(st)
+        scratch = step['scratch']
         H, W = st.H, st.W
         n = len(rows)
         rects = np.ascontiguousarray(rects, np.int32)
@@ -766,12 +832,12 @@ class OAMix:
             self._rec.append(('chain', dict(
                 img=T.data_ptr(), H=H, W=W, steps_dev=steps_dev.data_ptr(), tile_prefix_dev=tiles_dev.data_ptr(),
                 level_first=first, tile_prefix=tiles, n_levels=n_levels, My=st.My.data_ptr(), Mx=st.Mx.data_ptr(),
-                scratch=b['scratch'].data_ptr(), work=work, keep=(T, steps_dev, tiles_dev, st))))
+                scratch=scratch.data_ptr(), work=work, keep=(T, steps_dev, tiles_dev, st, scratch)), (), _ids((T, scratch))))
             return
         check(hip_ops._timed('oamix_bbox_chain', L.oadg_oamix_bbox_chain, ptr(T), H, W, ptr(steps_dev), ptr(tiles_dev),
                              first.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n_levels,
                              tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ptr(st.My), ptr(st.Mx),
-                             ptr(b['scratch']), stream_ptr(), work=work), 'oadg_oamix_bbox_chain')
+                             ptr(scratch), stream_ptr(), work=work), 'oadg_oamix_bbox_chain')
 
     # ------------------------------------------------------------------------------------------ one view
     def oamix(self, st, out_u8=None, out_norm=None, norm=None, pad_shape=None):
@@ -787,21 +853,29 @@ class OAMix:
         for i in range(self.mixture_width):
             depth = self.mixture_depth if self.mixture_depth > 0 else rng.randint(1, 4)
             cur = st.img
+            # every mixture chain starts from the ORIGINAL image (oa_mix.py:224-231) and only meets the others in the
+            # accumulator: inside the lockstep pass it records on a buffer set of its own, so that execute() may advance the
+            # chains' per-box levels together
+            self._lane = i % LANES if self._rec is not None else 0
+            lb = self._buffers(st)
             for d in range(depth):
                 step = dict(n_tmp=0, luts_for=None)
                 ops = (RegionOp * 3)()
                 for k in range(len(rboxes)):
                     ops[k] = self._aug(st, cur, step)
                 ops[2] = self._aug(st, cur, step)
-                dst = b['ping'][d & 1]
+                dst = lb['ping'][d & 1]
                 last = d == depth - 1
-                self._do(lambda cur=cur, dst=dst, ops=ops, w=float(ws[i]), mode=(1 if i == 0 else 2) if last else 0: check(
-                    L.oadg_oamix_compose(ptr(cur), ptr(dst), H, W, ops, rects, len(rboxes), ptr(b['luts']),
-                                         ptr(st.union_f), ptr(st.union_u8), ptr(b['acc']), w, mode, stream_ptr()),
-                    'oadg_oamix_compose'))
+                mode = (1 if i == 0 else 2) if last else 0
+                self._do(lambda cur=cur, dst=dst, ops=ops, w=float(ws[i]), mode=mode, lb=lb: check(
+                    L.oadg_oamix_compose(ptr(cur), ptr(dst), H, W, ops, rects, len(rboxes), ptr(lb['luts']),
+                                         ptr(st.union_f), ptr(st.union_u8), ptr(lb['acc']), w, mode, stream_ptr()),
+                    'oadg_oamix_compose'),
+                    reads=(cur, lb['luts'], lb['gray'], *lb['tmp']), writes=(dst,) + ((lb['acc'],) if mode else ()))
                 cur = dst
                 if self.stats is not None:
                     self.stats['compose_steps'] = self.stats.get('compose_steps', 0) + 1
+        self._lane = 0
         # get_regions_for_object_aware_mixing (oa_mix.py:245-262)
         scores = st.scores()
         targets = []
@@ -847,12 +921,12 @@ class OAMix:
             self._do(lambda: check(
                 L.oadg_oamix_final_tiles(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(fg_rects), ptr(st.My),
                                          ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp, Wp,
-                                         ptr(ws), nb, stream_ptr()), 'oadg_oamix_final_tiles'))
+                                         ptr(ws), nb, stream_ptr()), 'oadg_oamix_final_tiles'), reads=(b['acc'],))
             return out_u8
         self._do(lambda: check(
             L.oadg_oamix_final(ptr(st.img), ptr(b['acc']), H, W, ptr(tg_dev), len(targets), ptr(st.My),
                                ptr(st.Mx), float(m), mean, stdinv, to_rgb, ptr(out_u8), ptr(out_norm), dt, Hp,
-                               Wp, stream_ptr()), 'oadg_oamix_final'))
+                               Wp, stream_ptr()), 'oadg_oamix_final'), reads=(b['acc'],))
         return out_u8
 
     # ------------------------------------------------------------------------------------------ dict API
