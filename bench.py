@@ -604,7 +604,8 @@ def main():
         init_dist('pytorch', backend='gloo' if plumbing else 'nccl')
     rank = dist.get_rank() if distributed else 0
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    affinity = pin_rank_to_cores(int(os.environ.get('LOCAL_RANK', 0)), world)
+    # (OADG_BENCH_PIN_WORLD: pin as one of that many ranks although this process runs alone - tools/probe/eight_rank_host_proxy.sh)
+    affinity = pin_rank_to_cores(int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('OADG_BENCH_PIN_WORLD', world)))
     if plumbing:
         return plumbing_run(a, plumbing, rank, world, distributed, affinity)
     local = int(os.environ.get('LOCAL_RANK', 0))
