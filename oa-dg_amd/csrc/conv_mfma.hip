@@ -254,25 +254,40 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const long bi
         if (NST == 2 && kc + 1 < nchunks) stage(kc + 1, cur ^ 1);
         const unsigned char* sa = smem + cur * TSTAGE;
         const unsigned char* sb = sa + BM * BK * 2;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
+        // Two-stage form (two workgroups per CU, 256 registers per wave to spend): the fragments of k-step kk + 1 are requested
+        // BEFORE the MFMAs of k-step kk (round 6: the loop used to be { 4 ds_read_b128, s_waitcnt lgkmcnt(0), 4 MFMAs } per
+        // k-step - every MFMA group behind a full LDS round trip).  The one-stage form runs four workgroups per CU on 128
+        // registers: its neighbours cover the round trip, and the second fragment set would spill.
+        constexpr bool PIPE = NST == 2;
+        bf16x8 fa[PIPE ? 2 : 1][AF], fb[PIPE ? 2 : 1][2];
+        auto frags = [&](const int kk, const int b) {
             const int sg = kk * 2 + lh;
-            bf16x8 fa[AF], fb[2];
 #pragma unroll
             for (int i = 0; i < AF; ++i) {
                 const int row = wm * (AF * 32) + i * 32 + l31;
-                fa[i] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
+                fa[b][i] = *reinterpret_cast<const bf16x8*>(sa + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = wn * 64 + j * 32 + l31;
-                fb[j] = *reinterpret_cast<const bf16x8*>(sb + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
+                fb[b][j] = *reinterpret_cast<const bf16x8*>(sb + row * 128 + ((sg ^ ((row >> 1) & 7)) << 4));
+            }
+        };
+        if (PIPE) frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (PIPE) {
+                if (kk + 1 < BK / 16) frags(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks the reads below the MFMAs again)
+            } else {
+                frags(kk, 0);
             }
 #pragma unroll
             for (int i = 0; i < AF; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PIPE ? (kk & 1) : 0][i], fb[PIPE ? (kk & 1) : 0][j],
+                                                                        acc[i][j], 0, 0, 0);
         }
         if (NST == 1) {
             __syncthreads();                           // every wave is done reading the single stage
@@ -1412,18 +1427,30 @@ __global__ __launch_bounds__(256, (NST == 1 ? 4 : 2)) void conv_wgrad_kernel(Wgr
             if (NST == 2 && ch + 1 < ch1) stage(ch + 1, cur ^ 1);
             const unsigned char* sa = smem + cur * WSTAGE;
             const unsigned char* sb = sa + WP * 256;
+            // (two-stage form: the fragments of step t + 1 are requested before the MFMAs of step t - see conv_igemm_body)
+            constexpr bool PIPE = NST == 2;
+            bf16x8 fa[PIPE ? 2 : 1][2], fb[PIPE ? 2 : 1][2];
+            auto frags = [&](const int t, const int b) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[b][i] = frag(sa, faoff[i], t);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[b][j] = frag(sb, fboff[j], t);
+            };
+            if (PIPE) frags(0, 0);
 #pragma unroll
             for (int t = 0; t < WP / 16; ++t) {
-                bf16x8 fa[2], fb[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i] = frag(sa, faoff[i], t);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j] = frag(sb, fboff[j], t);
+                if (PIPE) {
+                    if (t + 1 < WP / 16) frags(t + 1, (t + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    frags(t, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PIPE ? (t & 1) : 0][i], fb[PIPE ? (t & 1) : 0][j],
+                                                                            acc[i][j], 0, 0, 0);
             }
             if (NST == 1) {
                 __syncthreads();
