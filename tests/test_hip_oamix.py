@@ -293,10 +293,11 @@ def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monk
     chains level by level TOGETHER (csrc oadg_oamix_bbox_chain_multi: one launch pair per level for all images).  Against
     the image-by-image pass with the same numpy stream: both views byte-identical, the same box lists, the stream left
     in the same state - for images with many, few and no boxes, dense small boxes (deep chains) and both host planners;
-    and the lockstep pass really shares launches (fewer level rounds than the sum of the chains' depths).  The lockstep
-    pass blends levels of small rects IN PLACE (one launch, csrc bbox_blend_inplace_imgs_kernel) where the sequential pass
-    goes through the scratch image and a copy launch, and with ``planner_threads`` every plan call runs on a planner
-    thread (as for images with >= 512 boxes)."""
+    and the lockstep pass really shares launches (fewer level rounds than the sum of the chains' depths).  Since round 6
+    the lockstep pass is dependency-driven (OAMix.execute): the three mixture chains of a view record on buffer sets of
+    their own and every per-box chain that is ready - of any image, any mixture chain, any region op - joins the same
+    launch pair per level; with ``planner_threads`` every plan call runs on a planner thread (as for images with >= 512
+    boxes)."""
     import os
     from oadg_amd import Config
     from oadg_amd.pipelines import DevicePipeline
@@ -335,6 +336,8 @@ def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monk
     s = stats[True]
     assert s['bbox_ops'] == stats[False]['bbox_ops'] > 0 and s['bbox_levels'] == stats[False]['bbox_levels']
     assert 0 < s['lockstep_rounds'] <= s['bbox_ops']
+    assert s['lockstep_chains'] == s['bbox_ops'] - stats[True].get('empty_chains', 0) or s['lockstep_chains'] <= s['bbox_ops']
+    assert s['lockstep_rounds'] < s['lockstep_chains']          # chains of one image really shared launches (round 6)
     assert s['lockstep_levels'] < s['bbox_levels'], s          # levels issued (deepest chain per round) < sum of depths
     assert 'lockstep_rounds' not in stats[False]
 
