@@ -336,7 +336,7 @@ def test_oamix_lockstep_batch_is_byte_identical_to_the_sequential_pass(dev, monk
     s = stats[True]
     assert s['bbox_ops'] == stats[False]['bbox_ops'] > 0 and s['bbox_levels'] == stats[False]['bbox_levels']
     assert 0 < s['lockstep_rounds'] <= s['bbox_ops']
-    assert s['lockstep_chains'] == s['bbox_ops'] - stats[True].get('empty_chains', 0) or s['lockstep_chains'] <= s['bbox_ops']
+    assert 0 < s['lockstep_chains'] <= s['bbox_ops']
     assert s['lockstep_rounds'] < s['lockstep_chains']          # chains of one image really shared launches (round 6)
     assert s['lockstep_levels'] < s['bbox_levels'], s          # levels issued (deepest chain per round) < sum of depths
     assert 'lockstep_rounds' not in stats[False]
