@@ -216,6 +216,11 @@ def main():
             ready.record()
         return item, batch, ready
     depth = max(1, int(a.loader_depth))
+    inner = ds
+    while hasattr(inner, 'dataset'):                  # (RepeatDataset and friends)
+        inner = inner.dataset
+    if hasattr(inner, 'ring_slots'):                  # a pinned batch buffer per load in flight + the ones still uploading
+        inner.ring_slots = max(inner.ring_slots, depth + 3)
     loader = ThreadPoolExecutor(depth, thread_name_prefix='oadg-loader')
     wseed = seed + rank + 1000
     todo = index_lists()
