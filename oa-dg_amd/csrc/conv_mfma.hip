@@ -257,7 +257,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a, const long bi
         // Two-stage form (two workgroups per CU, 256 registers per wave to spend): the fragments of k-step kk + 1 are requested
         // BEFORE the MFMAs of k-step kk (round 6: the loop used to be { 4 ds_read_b128, s_waitcnt lgkmcnt(0), 4 MFMAs } per
         // k-step - every MFMA group behind a full LDS round trip).  The one-stage form runs four workgroups per CU on 128
-        // registers: its neighbours cover the round trip, and the second fragment set would spill.
+        // registers: its neighbours cover the round trip, and the second fragment set would spill; pipelined at THREE
+        // workgroups per CU (146 registers) it lost on the shape it exists for (layer2's 3x3: 106.7 us against 100.2).
         constexpr bool PIPE = NST == 2;
         bf16x8 fa[PIPE ? 2 : 1][AF], fb[PIPE ? 2 : 1][2];
         auto frags = [&](const int kk, const int b) {
