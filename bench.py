@@ -480,8 +480,9 @@ def oamix_stress_run(a, rank, distributed, dev, affinity=None):
             'bytes_model': 'SURVEY 8d: 3 H W (2 S + C + 2) per view for the S compose steps drawn + 3 w h per per-box step',
             'ms_per_view': round(ms_pass / views, 3), 'compose_steps_per_view': round(S / views, 2),
             'bbox_ops_per_view': round(st.get('bbox_ops', 0) / views, 2),
-            'note': 'host-bound: the pass is ~70 % host planning (4096-box plans on planner threads) - see '
-                    'profiles/r05_stress_kernel_stats.csv for the kernel split',
+            'note': 'host-bound since round 6: one pass = ~36 ms of host work (recording 8 x 4096-box images ~17 ms, ~1,070 '
+                    'chain launches ~8.5 ms, image states ~7.5 ms: tools/probe/stress_host.py) against ~27.6 ms of kernels - '
+                    'see profiles/r06_stress_kernel_stats.csv for the kernel split',
             'families': [{'family': 'OA-Loss supcon forward + backward', 'kernels': ['supcon_tile_kernel'], 'bound': 'mfma-f32',
                           'launches_per_step': 2.0, 'ms_per_step': round(ms_sup / a.steps, 3),
                           'achieved': round(flops / (ms_sup * 1e-3) / 1e12, 2), 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
