@@ -236,6 +236,10 @@ int oadg_oamix_fg_union_rects(const float* My, const float* Mx, const int* rects
 size_t oadg_oamix_saliency_workspace_bytes(int n);
 int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
                         double* scores, void* workspace, size_t workspace_bytes, void* stream);
+/* the boxes of several images of ONE uint8 [N,H,W,3] batch in one call (round 6): image i at imgs + i * img_stride bytes,
+ * box b in image box_img[b] (device int32 [n]); the scores of n / N separate oadg_oamix_saliency calls */
+int oadg_oamix_saliency_batch(const uint8_t* imgs, long long img_stride, const int* box_img, int H, int W, const int* boxes,
+                              int n, int min_side, double* scores, void* workspace, size_t workspace_bytes, void* stream);
 int oadg_oamix_hist(const uint8_t* img, long npix, int* hist, void* stream);
 int oadg_oamix_luts(const int* hist, uint8_t* luts, void* stream);
 int oadg_oamix_gray_sum(const uint8_t* img, long npix, long long* sum, void* stream);

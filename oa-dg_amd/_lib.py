@@ -154,6 +154,7 @@ SIGNATURES = {
     'oadg_oamix_fg_union_rects': (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     'oadg_oamix_saliency_workspace_bytes': (cs, [ci]),
     'oadg_oamix_saliency': (ci, [vp, ci, ci, vp, ci, ci, vp, vp, cs, vp]),
+    'oadg_oamix_saliency_batch': (ci, [vp, ctypes.c_longlong, vp, ci, ci, vp, ci, ci, vp, vp, ctypes.c_size_t, vp]),
     'oadg_oamix_hist': (ci, [vp, cl, vp, vp]),
     'oadg_oamix_luts': (ci, [vp, vp, vp]),
     'oadg_oamix_gray_sum': (ci, [vp, cl, vp, vp]),

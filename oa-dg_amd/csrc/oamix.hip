@@ -955,9 +955,11 @@ __device__ __forceinline__ void lin_axis(int d, int n_src, int n_dst, int& s0, i
     s0 = (int)s; s1 = s + 1 < n_src ? (int)s + 1 : n_src - 1; f = ff;
 }
 
-__global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict__ img, int H, int W,
+// (box_img / img_stride: the boxes of SEVERAL images of one [N,H,W,3] batch in one launch - box b lies in image box_img[b])
+__global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict__ img0, int H, int W,
                                                        const int* __restrict__ boxes, int min_side,
-                                                       float* __restrict__ sal_maps) {
+                                                       float* __restrict__ sal_maps, const int* __restrict__ box_img,
+                                                       long long img_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* re = reinterpret_cast<double*>(smem);            // [64][65]
     double* im = re + SN * SLD;                               // [64][65]
@@ -965,6 +967,7 @@ __global__ __launch_bounds__(256) void saliency_kernel(const uint8_t* __restrict
     __shared__ double s_max;
     __shared__ double tw_re[32], tw_im[32];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* __restrict__ img = img0 + (box_img ? (size_t)box_img[b] * (size_t)img_stride : (size_t)0);
     const int x1 = boxes[4 * b], y1 = boxes[4 * b + 1], x2 = boxes[4 * b + 2], y2 = boxes[4 * b + 3];
     const int w = x2 - x1, h = y2 - y1;
     if (w < min_side || h < min_side) return;      // score -1 (saliency_mean_kernel)
@@ -1173,8 +1176,24 @@ size_t oadg_oamix_saliency_workspace_bytes(int n) {
     return n > 0 ? (size_t)n * (SN * SN * sizeof(float) + sizeof(unsigned long long)) : 0;
 }
 
+static int saliency_launch(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side, double* scores,
+                           void* workspace, size_t workspace_bytes, const int* box_img, long long img_stride, void* stream);
+
 int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side,
                         double* scores, void* workspace, size_t workspace_bytes, void* stream) {
+    return saliency_launch(img, H, W, boxes, n, min_side, scores, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+// the boxes of several images of ONE [N,H,W,3] uint8 batch (image i at imgs + i * img_stride bytes) in one launch triple:
+// box b belongs to image box_img[b] (device int32 [n]).  Same scores as one oadg_oamix_saliency call per image.
+int oadg_oamix_saliency_batch(const uint8_t* imgs, long long img_stride, const int* box_img, int H, int W, const int* boxes,
+                              int n, int min_side, double* scores, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n > 0 && (!box_img || img_stride < (long long)H * W * 3)) return OADG_EARG;
+    return saliency_launch(imgs, H, W, boxes, n, min_side, scores, workspace, workspace_bytes, box_img, img_stride, stream);
+}
+
+static int saliency_launch(const uint8_t* img, int H, int W, const int* boxes, int n, int min_side, double* scores,
+                           void* workspace, size_t workspace_bytes, const int* box_img, long long img_stride, void* stream) {
     if (n == 0) return OADG_OK;
     if (!img || !boxes || !scores || !workspace || n < 0) return OADG_EARG;
     if (workspace_bytes < oadg_oamix_saliency_workspace_bytes(n)) return OADG_ESIZE;
@@ -1191,7 +1210,7 @@ int oadg_oamix_saliency(const uint8_t* img, int H, int W, const int* boxes, int 
     }
     hipError_t e = hipMemsetAsync(totals, 0, (size_t)n * sizeof(unsigned long long), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(saliency_kernel, dim3(n), dim3(256), lds, st, img, H, W, boxes, min_side, maps);
+    hipLaunchKernelGGL(saliency_kernel, dim3(n), dim3(256), lds, st, img, H, W, boxes, min_side, maps, box_img, img_stride);
     OADG_LAUNCH_CHECK();
     // crops are up to the whole image: ~64k pixels per workgroup, at most 32 workgroups per box
     int per_box = n >= 512 ? 1 : (n >= 64 ? 4 : 32);

@@ -226,46 +226,71 @@ def _upload(arr, device):
 class _ImageState:
     """Device-side state of one image: profiles of the fg masks, their union, saliency scores (async)."""
 
+    @classmethod
+    def batch(cls, imgs, gt_bboxes_list, spatial_ratio, sigma_ratio):
+        """the states of the images of ONE contiguous uint8 [N,H,W,3] batch (round 6): the boxes of all images go through
+        one upload, ONE mask-profile launch and ONE saliency launch triple (per image: 3 uploads, 5 launches and a
+        device -> host copy of their own - 20 workgroups per launch at 20 boxes per image); every image's profiles / scores
+        are row ranges of the batch's tensors.  Same values as N separate states."""
+        L = _lib.lib()
+        N, H, W = int(imgs.shape[0]), int(imgs.shape[1]), int(imgs.shape[2])
+        dev = imgs.device
+        states = [cls.__new__(cls) for _ in range(N)]
+        rows, nb = [], 0
+        for i, st in enumerate(states):
+            st._host_part(imgs[i], gt_bboxes_list[i], spatial_ratio, sigma_ratio)
+            rows.append(nb)
+            nb += max(st.n, 1)
+        My = torch.empty((nb, H), dtype=torch.float32, device=dev)
+        Mx = torch.empty((nb, W), dtype=torch.float32, device=dev)
+        tot = sum(st.n for st in states)
+        if tot:
+            # boxes in PROFILE-ROW order (an image without boxes still owns one unused row): qbox, sigma, integer boxes, image id
+            qb = np.zeros((nb, 4), np.int32)
+            sg = np.zeros((nb, 2), np.float64)
+            for st, r in zip(states, rows):
+                qb[r:r + st.n], sg[r:r + st.n] = st._qbox_host, st._sigma_host
+            qbox_dev, sigma_dev = _upload(qb, dev), _upload(sg, dev)
+            check(L.oadg_oamix_box_profiles(ptr(qbox_dev), ptr(sigma_dev), nb, H, W, spatial_ratio, ptr(My), ptr(Mx),
+                                            stream_ptr()), 'oadg_oamix_box_profiles')
+        for st, r in zip(states, rows):
+            k = max(st.n, 1)
+            st.My, st.Mx = My[r:r + k], Mx[r:r + k]
+            st._keep = (My, Mx)
+            st._union()
+        if tot:
+            ib = np.concatenate([np.array(st.gt, dtype=np.int32).reshape(-1, 4) for st in states], 0)
+            img_of = np.concatenate([np.full((st.n,), i, np.int32) for i, st in enumerate(states)])
+            ib_dev, of_dev = _upload(ib, dev), _upload(img_of, dev)
+            scores_dev = torch.empty((tot,), dtype=torch.float64, device=dev)
+            nbytes = L.oadg_oamix_saliency_workspace_bytes(tot)
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            check(L.oadg_oamix_saliency_batch(ptr(imgs), int(imgs.stride(0)), ptr(of_dev), H, W, ptr(ib_dev), tot, spatial_ratio,
+                                              ptr(scores_dev), ptr(ws), nbytes, stream_ptr()), 'oadg_oamix_saliency_batch')
+            host = torch.empty((tot,), dtype=torch.float64, pin_memory=True)
+            host.copy_(scores_dev, non_blocking=True)
+            evt = torch.cuda.Event()
+            evt.record()
+            off = 0
+            for st in states:
+                st._scores_host, st._scores_evt = host[off:off + st.n], evt
+                st._keep += (ib_dev, of_dev, scores_dev, ws, qbox_dev, sigma_dev)
+                off += st.n
+        return states
+
     def __init__(self, img, gt_bboxes, spatial_ratio, sigma_ratio):
         L = _lib.lib()
-        self.img = img                                     # uint8 [H,W,3] on the device
-        self.H, self.W = int(img.shape[0]), int(img.shape[1])
-        self.gt = np.asarray(gt_bboxes, dtype=np.float32).reshape(-1, 4)
-        n = self.n = self.gt.shape[0]
-        dev = img.device
-        H, W = self.H, self.W
-        # --- blurred-mask profiles (oa_mix.py:74-93) -------------------------------------------------
-        # (vectorised over the boxes: per box  x1, y1, x2, y2 = np.array(gt // ratio, dtype=np.int32);
-        #  sx = (x2 - x1) * sigma_ratio / 3 * 2  as in oa_mix.py:83-90)
-        qbox = np.array(self.gt // spatial_ratio, dtype=np.int32).reshape(n, 4)
-        sxy = np.stack([(qbox[:, 2] - qbox[:, 0]) * sigma_ratio / 3 * 2,
-                        (qbox[:, 3] - qbox[:, 1]) * sigma_ratio / 3 * 2], 1).astype(np.float64).reshape(n, 2)
-        blur = ~((sxy[:, 0] <= 0) | (sxy[:, 1] <= 0))
-        sigma = np.where(blur[:, None], sxy, 0.0)
-        # conservative rect per box where its mask can be non-zero: arrays now (rows int64 [n, 4], empty bool [n]), the list
-        # of tuples / None the per-box paths index only when one of them asks (``support``: 3 ms of tolist() at 4096 boxes)
-        self._support_rows, self._support_empty = self._supports(qbox, sxy, blur, spatial_ratio)
-        self._support_list = None
-        assert (qbox >= 0).all(), 'gt boxes must have non-negative coordinates'
+        self._host_part(img, gt_bboxes, spatial_ratio, sigma_ratio)
+        n, H, W, dev = self.n, self.H, self.W, img.device
         self.My = torch.empty((max(n, 1), H), dtype=torch.float32, device=dev)
         self.Mx = torch.empty((max(n, 1), W), dtype=torch.float32, device=dev)
-        self.union_f = torch.empty((H, W), dtype=torch.float32, device=dev)
-        self.union_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
         if n:
-            self._qbox = _upload(qbox, dev)
-            self._sigma = _upload(sigma, dev)
+            self._qbox = _upload(self._qbox_host, dev)
+            self._sigma = _upload(self._sigma_host, dev)
             check(L.oadg_oamix_box_profiles(ptr(self._qbox), ptr(self._sigma), n, H, W, spatial_ratio,
                                             ptr(self.My), ptr(self.Mx), stream_ptr()), 'oadg_oamix_box_profiles')
-        self._rects = None
-        if n >= UNION_RECTS_MIN_BOXES:
-            # many boxes: the union from the masks' support rects (work ~ rect areas, not n x H x W); byte-identical
-            check(L.oadg_oamix_fg_union_rects(ptr(self.My), ptr(self.Mx), ptr(self.rects_dev()), n, H, W, ptr(self.union_f),
-                                              ptr(self.union_u8), stream_ptr()), 'oadg_oamix_fg_union_rects')
-        else:
-            check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
-                                        stream_ptr()), 'oadg_oamix_fg_union')
+        self._union()
         # --- saliency scores (oa_mix.py:98-111): launched now, read when object-aware mixing needs them -----
-        self._scores = None
         if n:
             ib = np.array(self.gt, dtype=np.int32)
             self._ibox = _upload(ib, dev)
@@ -279,6 +304,43 @@ class _ImageState:
             self._scores_host.copy_(self._scores_dev, non_blocking=True)
             self._scores_evt = torch.cuda.Event()
             self._scores_evt.record()
+
+    def _union(self):
+        """union of the blurred fg masks (oa_mix.py:95-120 / bbox_augmentation.py:240-302's np.max over the masks)"""
+        L = _lib.lib()
+        n, H, W, dev = self.n, self.H, self.W, self.img.device
+        self.union_f = torch.empty((H, W), dtype=torch.float32, device=dev)
+        self.union_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        self._rects = None
+        if n >= UNION_RECTS_MIN_BOXES:
+            # many boxes: the union from the masks' support rects (work ~ rect areas, not n x H x W); byte-identical
+            check(L.oadg_oamix_fg_union_rects(ptr(self.My), ptr(self.Mx), ptr(self.rects_dev()), n, H, W, ptr(self.union_f),
+                                              ptr(self.union_u8), stream_ptr()), 'oadg_oamix_fg_union_rects')
+        else:
+            check(L.oadg_oamix_fg_union(ptr(self.My), ptr(self.Mx), n, H, W, ptr(self.union_f), ptr(self.union_u8),
+                                        stream_ptr()), 'oadg_oamix_fg_union')
+
+    def _host_part(self, img, gt_bboxes, spatial_ratio, sigma_ratio):
+        """everything of the state that is host arithmetic on the boxes"""
+        self.img = img                                     # uint8 [H,W,3] on the device
+        self.H, self.W = int(img.shape[0]), int(img.shape[1])
+        self.gt = np.asarray(gt_bboxes, dtype=np.float32).reshape(-1, 4)
+        n = self.n = self.gt.shape[0]
+        self._scores = None
+        H, W = self.H, self.W
+        # --- blurred-mask profiles (oa_mix.py:74-93) -------------------------------------------------
+        # (vectorised over the boxes: per box  x1, y1, x2, y2 = np.array(gt // ratio, dtype=np.int32);
+        #  sx = (x2 - x1) * sigma_ratio / 3 * 2  as in oa_mix.py:83-90)
+        qbox = np.array(self.gt // spatial_ratio, dtype=np.int32).reshape(n, 4)
+        sxy = np.stack([(qbox[:, 2] - qbox[:, 0]) * sigma_ratio / 3 * 2,
+                        (qbox[:, 3] - qbox[:, 1]) * sigma_ratio / 3 * 2], 1).astype(np.float64).reshape(n, 2)
+        blur = ~((sxy[:, 0] <= 0) | (sxy[:, 1] <= 0))
+        self._qbox_host, self._sigma_host = qbox, np.where(blur[:, None], sxy, 0.0)
+        # conservative rect per box where its mask can be non-zero: arrays now (rows int64 [n, 4], empty bool [n]), the list
+        # of tuples / None the per-box paths index only when one of them asks (``support``: 3 ms of tolist() at 4096 boxes)
+        self._support_rows, self._support_empty = self._supports(qbox, sxy, blur, spatial_ratio)
+        self._support_list = None
+        assert (qbox >= 0).all(), 'gt boxes must have non-negative coordinates'
 
     def rects_dev(self):
         """device int32 [n, 4]: (x0, y0, w, h) of every fg mask's support, zeros for an empty mask (uploaded once)"""

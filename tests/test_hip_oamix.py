@@ -394,3 +394,36 @@ def test_oamix_many_box_paths_are_byte_identical(dev, monkeypatch):
     assert not torch.equal(out[True]['img2'], out[True]['img'])
     for i in range(len(cases)):
         assert np.array_equal(out[True]['oamix_boxes'][i].numpy(), out[False]['oamix_boxes'][i].numpy())
+
+
+def test_batched_image_states_equal_the_per_image_states(dev, monkeypatch):
+    """_ImageState.batch (round 6: the boxes of a whole same-shape batch through ONE profile launch and ONE saliency launch
+    triple) against one _ImageState per image: mask profiles, unions, saliency scores bit for bit (an image without boxes
+    and a 70-box image take part), and the views of the whole pipeline byte for byte."""
+    import os
+    from oadg_amd import Config
+    from oadg_amd.pipelines import DevicePipeline, device_pipeline
+    from oadg_amd.pipelines.oa_mix import _ImageState
+    cases = [_case(90 + i, 256, 384, n, small=True) for i, n in enumerate((9, 0, 70, 4))]
+    imgs = torch.from_numpy(np.stack([c[0] for c in cases])).to(dev)
+    gts = [c[1] for c in cases]
+    bs = _ImageState.batch(imgs, gts, 4, 0.3)
+    for i, st in enumerate(bs):
+        one = _ImageState(imgs[i], gts[i], 4, 0.3)
+        n = one.n
+        assert st.n == n and st.scores() == one.scores()
+        assert torch.equal(st.My[:n], one.My[:n]) and torch.equal(st.Mx[:n], one.Mx[:n])
+        assert torch.equal(st.union_f, one.union_f) and torch.equal(st.union_u8, one.union_u8)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, 'configs/oadg/faster_rcnn_r50_fpn_1x_cityscapes_oadg.py'))
+    labels = [np.zeros(len(g), np.int64) for g in gts]
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(device_pipeline, 'BATCH_STATES', flag)
+        pipe = DevicePipeline(cfg.data.train.pipeline, dtype=torch.float32)
+        np.random.seed(33)
+        out[flag] = pipe(imgs, gts, labels)
+        torch.cuda.synchronize()
+    assert torch.equal(out[True]['img2'], out[False]['img2']) and torch.equal(out[True]['img'], out[False]['img'])
+    for i in range(len(cases)):
+        assert np.array_equal(out[True]['oamix_boxes'][i].numpy(), out[False]['oamix_boxes'][i].numpy())
