@@ -321,6 +321,19 @@ int oadg_png_size(const char* path, int* height, int* width);
 int oadg_png_decode_bgr(const char* path, uint8_t* out, int H, int W);
 
 /* ------------------------------------------------------------------------------------------------
+ * Robustness-benchmark corruptions (HOST functions, no device work; csrc/corrupt_host.hip) - the two sequential
+ * per-pixel loops of `Corrupt`, mmdet/datasets/pipelines/transforms.py:1277-1317 -> imagecorruptions.corrupt
+ * (third party, v1.1.2), tools/analysis_tools/test_robustness.py:222-235
+ *   oadg_glass_shuffle_u8  glass_blur's local shuffle: `iters` sweeps over h = H - delta ... delta + 1, w = W - delta ...
+ *                          delta + 1 (both descending), pixel (h, w) swapped with (h + dy, w + dx); dxdy = the draws in
+ *                          loop order, int32 [iters][H - 2 delta][W - 2 delta][2] = (dx, dy), each in [-delta, delta)
+ *                          (OADG_EARG otherwise).  In place on uint8 [H][W][C], C <= 4.
+ *   oadg_chamfer_l2_5x5    cv2.distanceTransform(src, DIST_L2, 5) of spatter: distance to the nearest ZERO pixel,
+ *                          two-pass chamfer with weights 1 / 1.4 / 2.1969 in 16-bit fixed point, float32 [H][W] out. */
+int oadg_glass_shuffle_u8(uint8_t* img, int H, int W, int C, int delta, int iters, const int32_t* dxdy);
+int oadg_chamfer_l2_5x5(const uint8_t* src, int H, int W, float* dist);
+
+/* ------------------------------------------------------------------------------------------------
  * Geometric pipeline steps in front of OA-Mix on uint8 HWC images
  *   oadg_resize_bilinear_u8  Resize._resize_img  mmdet/datasets/pipelines/transforms.py:210-239
  *                            (mmcv.imrescale / imresize -> cv2.resize INTER_LINEAR, 8-bit fixed-point path)

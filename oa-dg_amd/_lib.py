@@ -166,6 +166,8 @@ SIGNATURES = {
     'oadg_oamix_bbox_chain_multi': (ci, [vp, ci, vp]),
     'oadg_png_size': (ci, [c_char_p, POINTER(ci), POINTER(ci)]),
     'oadg_png_decode_bgr': (ci, [c_char_p, vp, ci, ci]),
+    'oadg_glass_shuffle_u8': (ci, [vp, ci, ci, ci, ci, ci, vp]),
+    'oadg_chamfer_l2_5x5': (ci, [vp, ci, ci, vp]),
     'oadg_oamix_compose': (ci, [vp, vp, ci, ci, POINTER(RegionOp), POINTER(ci), ci, vp, vp, vp, vp, cf, ci, vp]),
     'oadg_oamix_final': (ci, [vp, vp, ci, ci, vp, ci, vp, vp, cd, POINTER(cf), POINTER(cf), ci, vp, vp, ci, ci,
                               ci, vp]),

@@ -13,8 +13,9 @@ corruption) and rPC (relative) are printed as robustness_eval.py:37-118 does, an
 test_robustness.py:283-299) swaps ``img_prefix`` to ``.../cityscapes-c/.../<corruption>/<severity>/``.
 ``--load-dataset original`` corrupts on the fly with the ``Corrupt`` transform inserted after the loading step
 (test_robustness.py:269-277); the reference's transform calls the ``imagecorruptions`` package, which is not installed
-in this image: oadg_amd/pipelines/corrupt.py restates 13 of its 19 corruptions (the ones that need only numpy / scipy /
-Pillow) and stops with a message for the other six.  On a box without the dataset the synthetic source is used.
+in this image: oadg_amd/pipelines/corrupt.py restates all 19 corruptions on numpy / scipy / Pillow and two host loops of
+the library (``frost`` needs the package's six photographs: OADG_FROST_DIR).  On a box without the dataset the synthetic
+source is used.
 """
 import argparse
 import copy
