@@ -503,6 +503,10 @@ class TrainEngine:
     """model.train_step + backward + optimizer step for one process/GPU (the runner's hot loop,
     SURVEY.md 3.1): OptimizerHook semantics = zero_grad, loss.backward(), (no grad clip), step."""
 
+    # backends whose all-reduce of the device sampler's flags stays on the device (see _step); tests/test_two_ranks_one_gpu.py
+    # adds 'gloo' to run the lockstep logic with two real ranks on the one GPU a test box has
+    SPECULATION_BACKENDS = ('nccl',)
+
     def __init__(self, model, optimizer, distributed=False, amp_dtype=None, bucket_cap_mb=50,
                  find_unused_parameters=False, grad_clip=None):
         self.module = model
@@ -616,7 +620,8 @@ class TrainEngine:
         # (more than one rank: the repeat decision is shared through a device-side all-reduce of the flags, which only the
         #  RCCL backend can do on device memory without a host round trip - any other backend draws on the host)
         speculate = self.speculative_sampling and self.ddp is None and next(self.module.parameters()).is_cuda and \
-            (self._lockstep_world() == 1 or dist.get_backend(self.reducer.group if self.reducer is not None else None) == 'nccl')
+            (self._lockstep_world() == 1 or
+             dist.get_backend(self.reducer.group if self.reducer is not None else None) in self.SPECULATION_BACKENDS)
         # (saved for a repeat: torch's CPU generator, numpy's and python's global streams, the device generator.  Module
         #  buffers need no saving: every BatchNorm of the named configs is frozen / eval - train-mode statistics of a custom
         #  model WOULD be updated twice by a repeated step)
