@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# Reproducer of the packed-fp32 hazard (round 6): builds the library AS IT WAS BUILT BEFORE (SLP vectorizer on) next to the
+# Reproducer of the packed-fp32 hazard (round 6): builds the library AS IT WAS BUILT BEFORE (packed fp32 instructions allowed) next to the
 # shipped one, builds the co-tenant micro-kernels, and runs the victim beside each co-tenant with both libraries.
 #   bash tools/probe/packed_fp32_hazard/run.sh  ->  gpurun_out/packed_fp32_hazard.txt
 cd ${GRAFT_REPO_ROOT:-$(dirname $0)/../../..}
