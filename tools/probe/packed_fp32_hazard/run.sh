@@ -11,7 +11,8 @@ for f in oa-dg_amd/csrc/*.hip; do
 done; wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC $D/o/*.o -lz -o $D/liboadg_hip_slp_vectorized.so
 $HIPCC --offload-arch=gfx950 -O3 -shared -fPIC tools/probe/packed_fp32_hazard/mfma_tenant.hip -o $D/libtenant.so
-export TENANT_LIB=$PWD/$D/libtenant.so
+$HIPCC --offload-arch=gfx950 -O3 -fno-slp-vectorize -shared -fPIC tools/probe/packed_fp32_hazard/micro_victims.hip -o $D/libvictims.so
+export TENANT_LIB=$PWD/$D/libtenant.so VICTIM_LIB=$PWD/$D/libvictims.so
 {
 for lib in $PWD/$D/liboadg_hip_slp_vectorized.so shipped; do
   for t in none valu mfma16 mfma32 conv128; do
@@ -19,4 +20,6 @@ for lib in $PWD/$D/liboadg_hip_slp_vectorized.so shipped; do
     TENANT=$t timeout 120 python tools/probe/packed_fp32_hazard/victim.py 2>&1 | grep "^library"
   done
 done
+echo; echo "instruction forms (micro_victims.hip, 2048 x 256 lanes x 4000 dependent iterations per launch):"
+timeout 200 python tools/probe/packed_fp32_hazard/micro.py 2>&1 | grep "^co-tenant"
 } | tee gpurun_out/packed_fp32_hazard.txt
