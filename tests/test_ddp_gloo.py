@@ -145,7 +145,7 @@ def test_flat_reducer_parameter_without_gradient_on_one_rank():
             assert np.array_equal(red0[i], red1[i])
 
 
-def _worker_sink(rank, world, port, q):
+def _worker_sink(rank, world, port, q, overlap=True):
     """gradients produced by a function with a kernel of its own (here hip_ops.cast_all_bf16, which runs on CPU tensors
     too) are written into the reducer's bucket slices: ``param.grad`` lies inside the flat buffer BEFORE the collective"""
     sys.path.insert(0, ROOT)
@@ -159,12 +159,14 @@ def _worker_sink(rank, world, port, q):
     from oadg_amd.apis import FlatGradReducer
     torch.manual_seed(0)
     net = nn.ModuleList([nn.Linear(32, 64), nn.Linear(64, 16), nn.Linear(16, 4)])
-    red = FlatGradReducer(net, bucket_mb=1e-3, tail_mb=0)          # 262 floats per bucket: three buckets
+    red = FlatGradReducer(net, bucket_mb=1e-3, tail_mb=0, overlap=overlap)          # 262 floats per bucket: three buckets
+    phase, phases = ['-'], []
     assert hip_ops.GRAD_SINK is red.views
     lo, hi = red.flat.data_ptr(), red.flat.data_ptr() + red.flat.numel() * 4
     seen = []
 
     def pre(r, b):       # right before the bucket's all-reduce is issued
+        phases.append(phase[0])
         for p_ in b['params']:
             seen.append((p_.grad is not None and lo <= p_.grad.data_ptr() < hi and
                          p_.grad.data_ptr() == r.views[p_].data_ptr(), p_.grad.clone()))
@@ -181,25 +183,30 @@ def _worker_sink(rank, world, port, q):
         h = F.linear(x.bfloat16(), c[net[0].weight], c[net[0].bias]).relu()
         h = F.linear(h, c[net[1].weight], c[net[1].bias]).relu()
         y = net[2](h.float()).sum()                                      # layer 2: a torch operator produces its gradients
+        phases.clear()
+        phase[0] = 'backward'
         y.backward()
+        phase[0] = 'finish'
         red.finish()
         out.append(([f_ for f_, _ in seen], [g_.numpy() for _, g_ in seen],
                     [p_.grad.clone().numpy() for b in red.buckets for p_ in b['params']],
-                    red.in_place_bytes, red.packed_bytes))
+                    red.in_place_bytes, red.packed_bytes, list(phases)))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_flat_reducer_gradients_are_written_into_the_buckets():
+@pytest.mark.parametrize('overlap', [True, False])
+def test_flat_reducer_gradients_are_written_into_the_buckets(overlap):
     """no packing copy - the producers' gradients ARE bucket slices before the collective (4 of the 6
     parameters here; the last layer's come from torch operators and are packed by the multi-tensor copy), and the result
-    is the mean of the two ranks' local gradients either way."""
+    is the mean of the two ranks' local gradients either way.  ``overlap=False`` (round 6, the safety valve of
+    FlatGradReducer): the same buckets, the same result, every collective issued by finish() instead of from the hooks."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 25500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker_sink, args=(r, 2, port, q)) for r in range(2)]
+    port = 25500 + (os.getpid() % 2000) + (0 if overlap else 3)
+    procs = [ctx.Process(target=_worker_sink, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = _collect(procs, q, 240)
@@ -208,8 +215,10 @@ def test_flat_reducer_gradients_are_written_into_the_buckets():
         assert p.exitcode == 0
     (_, out0), (_, out1) = res
     for step in range(2):
-        in0, loc0, red0, ipb0, pkb0 = out0[step]
-        in1, loc1, red1, _, _ = out1[step]
+        in0, loc0, red0, ipb0, pkb0, ph0 = out0[step]
+        in1, loc1, red1, _, _, ph1 = out1[step]
+        # with overlap every bucket is reduced from the hooks while the backward pass runs, without it by finish()
+        assert len(ph0) >= 2 and ph0 == ph1 == ['backward' if overlap else 'finish'] * len(ph0), (ph0, ph1)
         # bucket order = reverse registration: layer 2 (bias, weight: packed), then layers 1 and 0 (in place)
         assert in0 == in1 == [False, False, True, True, True, True], in0
         for a, b, r0, r1 in zip(loc0, loc1, red0, red1):
