@@ -284,3 +284,60 @@ def test_head_parameters_cast_in_one_pass_give_identical_results(dev):
     assert set(res[0][1]) == set(res[1][1]) and len(res[0][1]) >= 12
     for n in res[0][1]:
         assert res[0][1][n].dtype == torch.float32 and torch.equal(res[0][1][n], res[1][1][n]), n
+
+
+@pytest.mark.gpu
+def test_roi_align_is_bit_stable_beside_matrix_kernels(dev):
+    """Round 6 (profiles/r06_packed_fp32_hazard.txt): built with packed fp32 instructions, RoIAlign's forward-by-rows and
+    backward-by-tiles kernels returned wrong values in lanes 48-63 of a wave WHENEVER waves issuing matrix instructions shared
+    their SIMD - 14,926 of 14,926 launches beside the 128-tile convolution on another stream.  The library is built without
+    them (csrc/Makefile); this keeps it that way: 150 forward + backward launches beside that convolution, every result
+    bit-identical to the one computed alone."""
+    import threading
+    import time
+    from oadg_amd import hip_conv, hip_ops
+    N, C, H, W, K = 4, 256, 384, 768, 2048
+    g = torch.Generator().manual_seed(1)
+    feats = [(torch.randn(N, C, H // s, W // s, generator=g) * 0.5).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+             .requires_grad_() for s in (4, 8, 16, 32)]
+    ctr = torch.rand(24, 2, generator=g) * torch.tensor([W, H])
+    pick = torch.randint(0, 24, (K,), generator=g)
+    cx, cy = (ctr[pick] + torch.randn(K, 2, generator=g) * 12).unbind(1)
+    w = torch.rand(K, generator=g) ** 2 * 160 + 12
+    h = torch.rand(K, generator=g) ** 2 * 120 + 12
+    rois = torch.stack([torch.randint(0, N, (K,), generator=g).float(), (cx - w / 2).clamp(0, W - 1), (cy - h / 2).clamp(0, H - 1),
+                        (cx + w / 2).clamp(1, W), (cy + h / 2).clamp(1, H)], 1).to(dev)
+    gout = (torch.randn(K, C, 7, 7, generator=g) * 1e-3).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def once():
+        out = hip_ops.roi_align_fpn(feats, rois, 7, (1 / 4, 1 / 8, 1 / 16, 1 / 32))
+        grads = torch.autograd.grad(out, feats, gout)
+        return [out.detach()] + list(grads)
+
+    ref = [t.clone() for t in once()]
+    torch.cuda.synchronize()
+    stop = []
+
+    def tenant():
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            cl = torch.channels_last
+            x3 = torch.randn(8, 256, 32, 64, device=dev).bfloat16().contiguous(memory_format=cl)
+            w3 = (torch.randn(256, 256, 3, 3, device=dev) * 0.02).bfloat16().contiguous(memory_format=cl)
+            b3 = torch.randn(256, device=dev)
+            while not stop:
+                for _ in range(50):
+                    hip_conv.conv_forward(x3, w3, b3, None, 1, 1, 1, True, variant=3)       # the 128-tile kernel, 4 workgroups per CU
+                st.synchronize()
+
+    th = threading.Thread(target=tenant, daemon=True)
+    th.start()
+    time.sleep(1.0)
+    try:
+        bad = 0
+        for _ in range(150):
+            bad += any(not torch.equal(a, b) for a, b in zip(once(), ref))
+    finally:
+        stop.append(1)
+        th.join(30)
+    assert bad == 0, f'{bad} of 150 launches beside the 128-tile convolution differ from the result computed alone'
