@@ -8,6 +8,7 @@ import ctypes
 import os
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check, ptr, require_cuda, stream_ptr
@@ -379,6 +380,51 @@ def fc_weight_permuted(weight, C, P):
 
 
 FC_PERMUTE = True
+
+
+class _LinearBiasGrad(torch.autograd.Function):
+    """y = [relu](x @ W^T + b) on bf16 operands (the RoI head's linears under autocast) with the backward pass of the bias /
+    ReLU part on the library's own kernel: g = dy * (y > 0) and db = column sums of g in ONE pass with fixed-order partials
+    (csrc/eltwise.hip oadg_relu_bias_bwd - what the convolutions use), then dx = g @ W, dW = g^T @ x through the library
+    GEMMs as before.  Replaces torch's threshold_backward + sum(0) pair per layer; round 6: that column reduction was the one
+    piece of a training step that was not bit-reproducible beside a second process on the device
+    (profiles/r06_packed_fp32_hazard.txt item 8).  Out-feature counts that are not a multiple of 8 (fc_cls: 9) stay on
+    F.linear."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        y = F.linear(x, w, b)
+        if relu:
+            y = torch.relu_(y)
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import hip_conv
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        M, K = gy.shape
+        g, db = hip_conv.relu_bias_bwd(gy.view(M, K, 1, 1), y.view(M, K, 1, 1) if y is not None else None, ctx.has_b)
+        g = g.reshape(M, K)
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x if ctx.needs_input_grad[1] else None
+        return gx, gw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def linear_bias_grad(x, w, b, relu=False):
+    """``[relu](F.linear(x, w, b))`` for bf16 CUDA operands - see :class:`_LinearBiasGrad`; anything else goes to F.linear"""
+    if LINEAR_BIAS_GRAD and x.is_cuda and x.dim() == 2 and x.dtype == w.dtype == torch.bfloat16 and w.shape[0] % 8 == 0 and \
+            (b is None or b.dtype == torch.bfloat16) and x.is_contiguous() and torch.is_grad_enabled():
+        return _LinearBiasGrad.apply(x, w, b, bool(relu))
+    y = F.linear(x, w, b)
+    return torch.relu_(y) if relu else y
+
+
+LINEAR_BIAS_GRAD = True
 
 
 # --------------------------------------------------------------------------------------- RoIAlign

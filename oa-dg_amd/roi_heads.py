@@ -417,17 +417,27 @@ class ConvFCBBoxHead(BBoxHead):
         if ps:
             self._cast = dict(zip(ps, hip_ops.cast_all_bf16(ps)))
 
-    def _lin(self, fc, x):
-        """``fc(x)`` on the pre-cast parameters when :meth:`_cast_params` made them"""
+    def _lin(self, fc, x, relu=False):
+        """``[relu](fc(x))`` on the pre-cast parameters when :meth:`_cast_params` made them (hip_ops.linear_bias_grad: the
+        bias gradient / ReLU mask of the backward pass on the library's kernel)"""
         c = self._cast
         w = c.get(fc.weight) if c else None
         if w is None:
-            return fc(x)
-        return F.linear(x, w, c.get(fc.bias) if fc.bias is not None else None)
+            return self.relu(fc(x)) if relu else fc(x)
+        return hip_ops.linear_bias_grad(x, w, c.get(fc.bias) if fc.bias is not None else None, relu)
 
     def _seq(self, seq, x):
-        for m in seq:
-            x = self._lin(m, x) if isinstance(m, nn.Linear) else m(x)
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                x = self._lin(m, x, relu=fuse)
+                i += 2 if fuse else 1
+            else:
+                x = m(x)
+                i += 1
         return x
 
     def _trunk(self, x):
@@ -443,17 +453,17 @@ class ConvFCBBoxHead(BBoxHead):
             K, C, PH, PW = x.shape
             self._cast_params(x, skip_weight_of=fc.weight)
             w = hip_ops.fc_weight_permuted(fc.weight, C, PH * PW)
-            x = self.relu(F.linear(x.permute(0, 2, 3, 1).reshape(K, PH * PW * C), w, self._cast.get(fc.bias, fc.bias)))
+            x = hip_ops.linear_bias_grad(x.permute(0, 2, 3, 1).reshape(K, PH * PW * C), w, self._cast.get(fc.bias, fc.bias), True)
         else:
             self._cast_params(x)
             x = x.flatten(1)        # (c, ph, pw) order, as the reference's NCHW flatten
         for fc in fcs:
-            x = self.relu(self._lin(fc, x))
+            x = self._lin(fc, x, relu=True)
         x_cls, x_reg = x, x
         for fc in self.cls_fcs:
-            x_cls = self.relu(self._lin(fc, x_cls))
+            x_cls = self._lin(fc, x_cls, relu=True)
         for fc in self.reg_fcs:
-            x_reg = self.relu(self._lin(fc, x_reg))
+            x_reg = self._lin(fc, x_reg, relu=True)
         return x, x_cls, x_reg
 
     def forward(self, x):
