@@ -8,6 +8,7 @@ import time
 import torch
 
 V = ctypes.CDLL(os.environ['VICTIM_LIB'])
+V9 = ctypes.CDLL(os.environ['VICTIM9_LIB'])
 T = ctypes.CDLL(os.environ['TENANT_LIB'])
 dev = torch.device('cuda:0')
 blocks = 2048
@@ -15,7 +16,8 @@ x = torch.rand(blocks * 256, device=dev) + 0.5
 names = ['scalar v_fma_f32 / v_mul_f32', 'v_pk_fma_f32 / v_pk_mul_f32, plain operands', 'v_pk_mul_f32 op_sel_hi:[1,0] / v_pk_add_f32',
          'v_mov_b32 then v_pk_mul_f32 on its pair', 'v_mov_b32, s_nop 0, v_pk_mul_f32 on its pair',
          'ds_read_b64, waitcnt, v_pk_mul_f32', 'ds_read_b64, waitcnt, scalar v_mul/v_add', 'global_load_dwordx2, waitcnt, v_pk_mul_f32',
-         'global_load_dwordx2, waitcnt, scalar v_mul/v_add']
+         'global_load_dwordx2, waitcnt, scalar v_mul/v_add',
+         'C++ loop: LDS float4 weights in flight + packed mul/add']
 stop = False
 
 
@@ -31,12 +33,16 @@ def tenant(kind):
 
 def run(kind):
     out = torch.empty(2 * blocks * 256, device=dev)
+    if kind == 9:
+        V9.launch_victim9(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), blocks, 1500,
+                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return out
     V.launch_victim(kind, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), blocks, 4000 if kind < 5 else 1500,
                     ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     return out
 
 
-refs = [run(k).clone() for k in range(9)]
+refs = [run(k).clone() for k in range(10)]
 torch.cuda.synchronize()
 for tname, tk in (('none', None), ('valu', 2), ('mfma16', 1), ('mfma32', 0)):
     stop = False
@@ -45,7 +51,7 @@ for tname, tk in (('none', None), ('valu', 2), ('mfma16', 1), ('mfma32', 0)):
         th = threading.Thread(target=tenant, args=(tk,), daemon=True)
         th.start()
         time.sleep(1.5)
-    for k in range(9):
+    for k in range(10):
         bad = n = 0
         lanes = set()
         t0 = time.time()

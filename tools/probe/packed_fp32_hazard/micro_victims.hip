@@ -80,6 +80,9 @@ __global__ __launch_bounds__(256) void victim(int kind, const float* __restrict_
     out[2 * i] = a0; out[2 * i + 1] = a1;
 }
 
+// 9: written in C++, compiled WITH packed fp32 and the SLP vectorizer (this file is otherwise built with -fno-slp-vectorize:
+// see run.sh, which builds this kernel from micro_victim9.hip): weights read from LDS as float4, several reads in flight while
+// packed multiplies / adds consume the ones that have arrived - the shape of the RoIAlign kernels' inner loops
 extern "C" int launch_victim(int kind, const float* in, float* out, int blocks, int iters, void* stream) {
     hipLaunchKernelGGL(victim, dim3(blocks), dim3(256), 0, (hipStream_t)stream, kind, in, out, iters);
     return (int)hipGetLastError();

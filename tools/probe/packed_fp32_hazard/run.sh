@@ -12,7 +12,8 @@ done; wait
 $HIPCC --offload-arch=gfx950 -shared -fPIC $D/o/*.o -lz -o $D/liboadg_hip_slp_vectorized.so
 $HIPCC --offload-arch=gfx950 -O3 -shared -fPIC tools/probe/packed_fp32_hazard/mfma_tenant.hip -o $D/libtenant.so
 $HIPCC --offload-arch=gfx950 -O3 -fno-slp-vectorize -shared -fPIC tools/probe/packed_fp32_hazard/micro_victims.hip -o $D/libvictims.so
-export TENANT_LIB=$PWD/$D/libtenant.so VICTIM_LIB=$PWD/$D/libvictims.so
+$HIPCC --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC tools/probe/packed_fp32_hazard/micro_victim9.hip -o $D/libvictim9.so
+export TENANT_LIB=$PWD/$D/libtenant.so VICTIM_LIB=$PWD/$D/libvictims.so VICTIM9_LIB=$PWD/$D/libvictim9.so
 {
 for lib in $PWD/$D/liboadg_hip_slp_vectorized.so shipped; do
   for t in none valu mfma16 mfma32 conv128; do
