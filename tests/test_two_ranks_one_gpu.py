@@ -173,3 +173,22 @@ def test_two_ranks_repeat_a_step_together_when_one_meets_a_short_image():
         assert r['same'] and r['err'] == 0.0, r['err']
     assert r0['logs'] == r1['logs'] and r0['logs1'] == r1['logs1']
     print('two ranks, one device: repeated step vs host-sampler step, relative update difference', r0['err'], 'bit-identical', r0['same'])
+
+
+@pytest.mark.gpu
+def test_check_allreduce_tool_plumbing_with_two_gloo_ranks_on_one_device():
+    """tools/check_allreduce.py (the check a multi-GPU node has to make: overlapped all-reduce == all-reduce of the same inputs
+    on the idle device, bit for bit, and on every rank) runs end to end with two gloo ranks sharing the device and reports no
+    difference (gloo reduces on the host: this validates the script, not RCCL)."""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    port = 26500 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'tools', 'check_allreduce.py'), '--backend', 'gloo',
+                        '--share-device', '--steps', '2', '--height', '384', '--width', '768', '--batch', '2'],
+                       env=env, capture_output=True, text=True, timeout=500)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('check_allreduce:')]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    assert 'overlapped != quiet in 0 bucket-checks' in line[0] and 'ranks disagree in 0' in line[0], line[0]
